@@ -1,0 +1,150 @@
+/*
+ * rnvp_hip.h -- C ABI of librnvp_hip.so: the MI355X (gfx950) implementation of the
+ * conditional RealNVP hot path of hse-cs/probaforms.
+ *
+ * The reference has no FFI: its replaceable seam is the Python `InvertibleLayer`
+ * protocol (/root/reference/probaforms/models/nflow.py:30-67) consumed by
+ * `NormalizingFlow.log_prob/sample` (nflow.py:90-145) and `RealNVP.fit/sample`
+ * (/root/reference/probaforms/models/realnvp.py:210-282).  Each entry point below
+ * names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer except `shape` is a DEVICE pointer;
+ *   - the caller owns all device memory including the workspace (no hidden hipMalloc);
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call
+ *     returns without synchronising; safe to capture into a hipGraph;
+ *   - return value: 0 ok; <0 argument error (RNVP_E*); >0 a hipError_t;
+ *   - no global mutable state other than one-time kernel attribute setup => thread-safe
+ *     per stream.
+ *
+ * Data layout
+ *   x, z : [n, d] float32 row-major;  c : [n, cdim] float32 row-major (NULL iff cdim==0)
+ *   masks: [L, d] uint8 in {0,1};  1 = pass-through and fed to the s/t nets (realnvp.py:92),
+ *          0 = transformed.  The reference builds (j + l) % 2 (realnvp.py:199).
+ *   params: flat float32 in `nf.parameters()` order (realnvp.py:69-70,196-204): for each
+ *          layer: net t then net s; per net, for each Linear: weight [out,in] row-major, bias.
+ *   row_index: optional int64 [n_rows]; row r of the batch is x[row_index[r]] (the
+ *          DataLoader shuffle of realnvp.py:237 fused into the row loads). NULL = identity.
+ */
+#ifndef RNVP_HIP_H
+#define RNVP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNVP_MAX_HIDDEN 8
+
+#define RNVP_OK            0
+#define RNVP_EINVAL       (-1)   /* bad shape / NULL pointer / negative size            */
+#define RNVP_EUNSUPPORTED (-2)   /* shape exceeds what the kernels can hold in LDS      */
+#define RNVP_EWORKSPACE   (-3)   /* workspace smaller than rnvp_workspace_bytes() says  */
+
+#define RNVP_ACT_TANH 0
+#define RNVP_ACT_RELU 1          /* anything but 'tanh' is ReLU, realnvp.py:32-37       */
+
+/* which kernel family serves a call (rnvp_kernel_path); informational */
+#define RNVP_PATH_GENERIC 0      /* any shape, VALU + LDS                               */
+#define RNVP_PATH_MFMA    1      /* register-chained f32 MFMA path (benchmark shapes)   */
+
+typedef struct rnvp_shape {
+    int32_t L;                        /* n_layers                  realnvp.py:160,196   */
+    int32_t d;                        /* var_size                  realnvp.py:182       */
+    int32_t c;                        /* cond_size, 0 for C=None   realnvp.py:183-186   */
+    int32_t n_hidden;                 /* len(hidden)               realnvp.py:22        */
+    int32_t hidden[RNVP_MAX_HIDDEN];
+    int32_t act;                      /* RNVP_ACT_*                                     */
+} rnvp_shape;
+
+/* operations, for rnvp_workspace_bytes */
+#define RNVP_OP_FORWARD  0
+#define RNVP_OP_INVERSE  1
+#define RNVP_OP_TRAIN    2
+
+int         rnvp_version(void);
+const char *rnvp_status_string(int status);
+
+/* number of float32 parameters of the whole flow (2 nets x L layers). */
+size_t rnvp_param_count(const rnvp_shape *shape);
+
+/* bytes of device workspace `op` needs for up to max_rows rows in one call. */
+size_t rnvp_workspace_bytes(const rnvp_shape *shape, int op, int64_t max_rows);
+
+/* RNVP_PATH_* the library will use for this shape/masks (masks is a HOST pointer here,
+ * may be NULL meaning the default alternating masks). */
+int rnvp_kernel_path(const rnvp_shape *shape, const uint8_t *host_masks, int op);
+
+/*
+ * Forward transform + log-det + prior log-prob.
+ * Replaces RealNVPLayer.f (realnvp.py:73-101) for every layer and
+ * NormalizingFlow.log_prob (nflow.py:107-117).  With shape->L == 1 and `params`/`masks`
+ * pointing at one layer it is exactly RealNVPLayer.f: z_out = X_new, logdet_out = log_det.
+ *   z_out      [n_rows, d]  transformed rows              (nullable)
+ *   logdet_out [n_rows]     sum over layers of log_det    (nullable)
+ *   logp_out   [n_rows]     logdet + N(0,I).log_prob(z)   (nullable)   nflow.py:115
+ *   logp_sum   [1]          sum over rows of logp_out     (nullable; overwritten)
+ */
+int rnvp_forward_logprob(void *stream, const rnvp_shape *shape,
+                         const float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *row_index,
+                         int64_t n_rows,
+                         float *z_out, float *logdet_out, float *logp_out, float *logp_sum,
+                         void *workspace, size_t workspace_bytes);
+
+/*
+ * Inverse transform (sampling): layers in reverse order.
+ * Replaces RealNVPLayer.g (realnvp.py:104-129) and the loop of NormalizingFlow.sample
+ * (nflow.py:142-143); the caller supplies z (prior draw, nflow.py:141).  x_out may alias z.
+ */
+int rnvp_inverse(void *stream, const rnvp_shape *shape,
+                 const float *params, const uint8_t *masks,
+                 const float *z, const float *c, int64_t n_rows, float *x_out,
+                 void *workspace, size_t workspace_bytes);
+
+/*
+ * loss = -(sum_rows logp) * inv_B and d(loss)/d(params) for one (shard of a) batch.
+ * Replaces `loss = -nf.log_prob(X, C); opt.zero_grad(); loss.backward()`
+ * (realnvp.py:246-250).  inv_B = 1 / (global batch size) so that shards from several GPUs
+ * add up to the reference's batch mean.  grad_out [P] and loss_out [1] are OVERWRITTEN
+ * (n_rows == 0 writes zeros).  Deterministic: no float atomics.
+ */
+int rnvp_loss_grad(void *stream, const rnvp_shape *shape,
+                   const float *params, const uint8_t *masks,
+                   const float *x, const float *c, const int64_t *row_index,
+                   int64_t n_rows, float inv_B,
+                   float *grad_out, float *loss_out,
+                   void *workspace, size_t workspace_bytes);
+
+/*
+ * torch.optim.Adam step over the flat parameter buffer (realnvp.py:205-207,251):
+ * betas/eps as given, amsgrad off, L2 weight decay folded into the gradient.
+ * `step` is the 1-based step number of THIS update.
+ */
+int rnvp_adam_step(void *stream, float *params, const float *grad,
+                   float *exp_avg, float *exp_avg_sq, int64_t n_params,
+                   double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step);
+
+/*
+ * rnvp_loss_grad followed by rnvp_adam_step on the same stream (single-GPU training step,
+ * realnvp.py:246-254).  loss_out [1] receives the batch loss (the value the reference
+ * appends to loss_history).  grad_buf [P] is scratch owned by the caller.
+ */
+int rnvp_train_step(void *stream, const rnvp_shape *shape,
+                    float *params, const uint8_t *masks,
+                    const float *x, const float *c, const int64_t *row_index,
+                    int64_t n_rows, float inv_B,
+                    float *grad_buf, float *loss_out,
+                    float *exp_avg, float *exp_avg_sq,
+                    double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step,
+                    void *workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNVP_HIP_H */

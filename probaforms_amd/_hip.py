@@ -1,0 +1,175 @@
+"""ctypes binding of librnvp_hip.so (C ABI: include/rnvp_hip.h).
+
+The shared library is built in-tree by `make -C probaforms_amd/csrc` (see
+__graft_entry__.build).  There is NO fallback: if the library is missing, or a
+tensor is not on a HIP device, the call raises.  PyTorch is used only to own
+device memory and streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+MAX_HIDDEN = 8
+OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
+PATH_GENERIC, PATH_MFMA = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librnvp_hip.so")
+
+
+class RnvpShape(C.Structure):
+    """mirror of `rnvp_shape` (include/rnvp_hip.h)"""
+    _fields_ = [("L", C.c_int32), ("d", C.c_int32), ("c", C.c_int32),
+                ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
+                ("act", C.c_int32)]
+
+    @classmethod
+    def make(cls, L, d, c, hidden, activation):
+        hidden = tuple(int(h) for h in hidden)
+        if not 1 <= len(hidden) <= MAX_HIDDEN:
+            raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
+        s = cls()
+        s.L, s.d, s.c, s.n_hidden = int(L), int(d), int(c), len(hidden)
+        for i, h in enumerate(hidden):
+            s.hidden[i] = h
+        s.act = 0 if activation == "tanh" else 1     # anything else is ReLU, realnvp.py:32-37
+        return s
+
+    def key(self):
+        return (self.L, self.d, self.c, tuple(self.hidden[:self.n_hidden]), self.act)
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+_VP, _I64, _F, _D, _SZ = C.c_void_p, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_SP = C.POINTER(RnvpShape)
+
+_SIGNATURES = {
+    "rnvp_version": (C.c_int, []),
+    "rnvp_status_string": (C.c_char_p, [C.c_int]),
+    "rnvp_param_count": (_SZ, [_SP]),
+    "rnvp_workspace_bytes": (_SZ, [_SP, C.c_int, _I64]),
+    "rnvp_kernel_path": (C.c_int, [_SP, _VP, C.c_int]),
+    "rnvp_forward_logprob": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "rnvp_inverse": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
+    "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
+    "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
+    "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
+                                  _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load librnvp_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HipLibraryMissing(
+                        "%s not found: build it with `make -C probaforms_amd/csrc` "
+                        "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                        "probaforms_amd has no CPU fallback." % LIB_PATH)
+                L = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(L, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().rnvp_status_string(status)
+        raise RuntimeError("%s failed: %s (status %d)" % (what, msg.decode() if msg else "?", status))
+
+
+def _ptr(t, dtype, what):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on a HIP device (got %s); probaforms_amd has no CPU path"
+                           % (what, getattr(t, "device", type(t))))
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous %s (got %s, contiguous=%s)"
+                           % (what, dtype, t.dtype, t.is_contiguous()))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(ws):
+    return _ptr(ws, torch.uint8, "workspace"), (0 if ws is None else ws.numel())
+
+
+def param_count(shape):
+    return int(lib().rnvp_param_count(C.byref(shape)))
+
+
+def workspace_bytes(shape, op, max_rows):
+    return int(lib().rnvp_workspace_bytes(C.byref(shape), op, int(max_rows)))
+
+
+def kernel_path(shape, host_masks_u8, op):
+    p = None if host_masks_u8 is None else host_masks_u8.ctypes.data
+    return int(lib().rnvp_kernel_path(C.byref(shape), p, op))
+
+
+def forward_logprob(shape, params, masks, x, c, row_index, n_rows, z_out, logdet_out, logp_out, logp_sum, ws):
+    wp, wn = _ws(ws)
+    st = lib().rnvp_forward_logprob(
+        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
+        int(n_rows), _ptr(z_out, torch.float32, "z_out"), _ptr(logdet_out, torch.float32, "logdet_out"),
+        _ptr(logp_out, torch.float32, "logp_out"), _ptr(logp_sum, torch.float32, "logp_sum"), wp, wn)
+    check(st, "rnvp_forward_logprob")
+
+
+def inverse(shape, params, masks, z, c, n_rows, x_out, ws):
+    wp, wn = _ws(ws)
+    st = lib().rnvp_inverse(
+        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(z, torch.float32, "z"), _ptr(c, torch.float32, "c"), int(n_rows),
+        _ptr(x_out, torch.float32, "x_out"), wp, wn)
+    check(st, "rnvp_inverse")
+
+
+def loss_grad(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out, ws):
+    wp, wn = _ws(ws)
+    st = lib().rnvp_loss_grad(
+        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
+        int(n_rows), float(inv_B), _ptr(grad_out, torch.float32, "grad_out"),
+        _ptr(loss_out, torch.float32, "loss_out"), wp, wn)
+    check(st, "rnvp_loss_grad")
+
+
+def adam_step(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step):
+    st = lib().rnvp_adam_step(
+        _stream(), _ptr(params, torch.float32, "params"), _ptr(grad, torch.float32, "grad"),
+        _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), int(n),
+        float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
+    check(st, "rnvp_adam_step")
+
+
+def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out, exp_avg, exp_avg_sq,
+               lr, beta1, beta2, eps, weight_decay, step, ws):
+    wp, wn = _ws(ws)
+    st = lib().rnvp_train_step(
+        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
+        int(n_rows), float(inv_B), _ptr(grad_buf, torch.float32, "grad_buf"),
+        _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
+        _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(eps),
+        float(weight_decay), int(step), wp, wn)
+    check(st, "rnvp_train_step")

@@ -1,0 +1,119 @@
+// rnvp_api.hip -- extern "C" entry points of librnvp_hip.so (declared in include/rnvp_hip.h)
+// and the dispatch between the kernel families.
+#include <cstring>
+
+#include "rnvp_common.h"
+
+using namespace rnvp;
+
+namespace {
+
+bool bad_ptrs(const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c) {
+    return !params || !masks || !x || (k.c > 0 && !c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnvp_version(void) { return 100; }
+
+const char *rnvp_status_string(int status) {
+    switch (status) {
+        case RNVP_OK: return "ok";
+        case RNVP_EINVAL: return "invalid argument (shape, NULL pointer, alignment or size)";
+        case RNVP_EUNSUPPORTED: return "shape too large for the LDS-resident kernels";
+        case RNVP_EWORKSPACE: return "workspace missing or smaller than rnvp_workspace_bytes()";
+        default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
+    }
+}
+
+size_t rnvp_param_count(const rnvp_shape *shape) {
+    KShape k;
+    if (make_kshape(shape, &k) != RNVP_OK) return 0;
+    return (size_t)2 * k.npn * k.L;
+}
+
+int rnvp_kernel_path(const rnvp_shape *shape, const uint8_t *host_masks, int op) {
+    KShape k;
+    if (make_kshape(shape, &k) != RNVP_OK) return RNVP_EINVAL;
+    (void)host_masks; (void)op;
+    return RNVP_PATH_GENERIC;
+}
+
+size_t rnvp_workspace_bytes(const rnvp_shape *shape, int op, int64_t max_rows) {
+    KShape k;
+    if (make_kshape(shape, &k) != RNVP_OK) return 0;
+    return generic_workspace_bytes(k, op, max_rows) + 256;
+}
+
+int rnvp_forward_logprob(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *row_index, int64_t n_rows,
+                         float *z_out, float *logdet_out, float *logp_out, float *logp_sum,
+                         void *workspace, size_t workspace_bytes) {
+    KShape k;
+    int rc = make_kshape(shape, &k);
+    if (rc) return rc;
+    if (n_rows < 0) return RNVP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_rows == 0) {
+        if (logp_sum) RNVP_HIP_TRY(hipMemsetAsync(logp_sum, 0, sizeof(float), st));
+        return RNVP_OK;
+    }
+    if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
+    return generic_forward(st, k, params, masks, x, c, row_index, n_rows, z_out, logdet_out, logp_out,
+                           logp_sum, workspace, workspace_bytes);
+}
+
+int rnvp_inverse(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                 const float *z, const float *c, int64_t n_rows, float *x_out,
+                 void *workspace, size_t workspace_bytes) {
+    KShape k;
+    int rc = make_kshape(shape, &k);
+    if (rc) return rc;
+    if (n_rows < 0) return RNVP_EINVAL;
+    if (n_rows == 0) return RNVP_OK;
+    if (bad_ptrs(k, params, masks, z, c) || !x_out) return RNVP_EINVAL;
+    (void)workspace; (void)workspace_bytes;
+    return generic_inverse(static_cast<hipStream_t>(stream), k, params, masks, z, c, n_rows, x_out);
+}
+
+int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                   const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
+                   float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
+    KShape k;
+    int rc = make_kshape(shape, &k);
+    if (rc) return rc;
+    if (n_rows < 0 || !grad_out) return RNVP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t P = (size_t)2 * k.npn * k.L;
+    if (n_rows == 0) {      // a rank whose shard of a ragged batch is empty contributes zeros
+        RNVP_HIP_TRY(hipMemsetAsync(grad_out, 0, P * sizeof(float), st));
+        if (loss_out) RNVP_HIP_TRY(hipMemsetAsync(loss_out, 0, sizeof(float), st));
+        return RNVP_OK;
+    }
+    if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
+    return generic_loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out,
+                             workspace, workspace_bytes);
+}
+
+int rnvp_adam_step(void *stream, float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   int64_t n_params, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step) {
+    return adam_step(static_cast<hipStream_t>(stream), params, grad, exp_avg, exp_avg_sq, n_params, lr,
+                     beta1, beta2, eps, weight_decay, step);
+}
+
+int rnvp_train_step(void *stream, const rnvp_shape *shape, float *params, const uint8_t *masks,
+                    const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
+                    float *grad_buf, float *loss_out, float *exp_avg, float *exp_avg_sq,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                    void *workspace, size_t workspace_bytes) {
+    int rc = rnvp_loss_grad(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out,
+                            workspace, workspace_bytes);
+    if (rc) return rc;
+    return rnvp_adam_step(stream, params, grad_buf, exp_avg, exp_avg_sq, (int64_t)rnvp_param_count(shape), lr,
+                          beta1, beta2, eps, weight_decay, step);
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""HIP kernels (through the C ABI, include/rnvp_hip.h) against the CPU oracle and the golden
+fixtures produced by the reference.  Runs on the GPU box: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+from cases import CASES, GRAD_STRIDE
+from conftest import load_case, logp_mae_tol
+
+pytestmark = pytest.mark.gpu
+
+ALL = list(CASES)
+
+
+def _dev(a, dtype=torch.float32):
+    return None if a is None else torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda().contiguous()
+
+
+def _setup(name):
+    from probaforms_amd import _hip
+    cs = load_case(name)
+    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
+    assert _hip.param_count(shape) == cs["params"].size
+    return _hip, cs, shape, _dev(cs["params"]), _dev(cs["masks"], torch.uint8)
+
+
+def _ws(_hip, shape, op, n):
+    nb = _hip.workspace_bytes(shape, op, n)
+    return torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_forward_vs_golden_and_oracle(name, oracle32, oracle64):
+    from oracle import Shape
+    _hip, cs, shape, params, masks = _setup(name)
+    n, d = cs["X"].shape
+    x, c = _dev(cs["X"]), _dev(cs["C"])
+    z = torch.empty(n, d, device="cuda"); ld = torch.empty(n, device="cuda")
+    lp = torch.empty(n, device="cuda"); tot = torch.empty(1, device="cuda")
+    _hip.forward_logprob(shape, params, masks, x, c, None, n, z, ld, lp, tot, _ws(_hip, shape, _hip.OP_FORWARD, n))
+    torch.cuda.synchronize()
+    g = cs["gold"]
+    z, ld, lp, tot = z.cpu().numpy(), ld.cpu().numpy(), lp.cpu().numpy(), float(tot.item())
+    # vs the reference's own outputs (golden): same bar as the oracle itself is held to
+    assert np.abs(z - g["G2_z"]).mean() < 2e-6
+    assert np.abs(lp - g["G2_logp"]).mean() < logp_mae_tol(name)
+    assert abs(tot / n - g["G2_mean"]) < logp_mae_tol(name)
+    np.testing.assert_allclose(ld, g["G2_layer_ld"].sum(0), rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ld).max()))
+    # vs the float64 referee: the HIP path must be no further from the truth than the reference is
+    s = Shape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
+    _, lp64, _ = oracle64.log_prob(s, cs["params"], cs["X"], cs["C"], cs["masks"])
+    err_hip = np.abs(lp - lp64).mean(); err_ref = np.abs(g["G2_logp"] - lp64).mean()
+    assert err_hip < max(3 * err_ref, 2e-6), (err_hip, err_ref)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_single_layer_f_and_g(name, oracle32):
+    """L=1 calls are exactly RealNVPLayer.f / .g (realnvp.py:73-129)."""
+    _hip, cs, shape, params, masks = _setup(name)
+    g = cs["gold"]
+    n, d = cs["X"].shape
+    one = _hip.RnvpShape.make(1, cs["d"], cs["c"], cs["hidden"], cs["act"])
+    npl = cs["params"].size // cs["L"]
+    c = _dev(cs["C"])
+    for l in range(cs["L"]):
+        xin = _dev(cs["X"] if l == 0 else g["G2_layer_out"][l - 1])
+        y = torch.empty(n, d, device="cuda"); ld = torch.empty(n, device="cuda")
+        _hip.forward_logprob(one, params[l * npl:(l + 1) * npl], masks[l], xin, c, None, n, y, ld, None, None, None)
+        np.testing.assert_allclose(y.cpu().numpy(), g["G2_layer_out"][l], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ld.cpu().numpy(), g["G2_layer_ld"][l], rtol=2e-6, atol=2e-6)
+    for k, l in enumerate(range(cs["L"] - 1, -1, -1)):
+        zin = _dev(cs["Z"] if k == 0 else g["G3_layer_out"][k - 1])
+        y = torch.empty(n, d, device="cuda")
+        _hip.inverse(one, params[l * npl:(l + 1) * npl], masks[l], zin, c, n, y, None)
+        np.testing.assert_allclose(y.cpu().numpy(), g["G3_layer_out"][k], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_inverse_and_roundtrip(name):
+    _hip, cs, shape, params, masks = _setup(name)
+    n, d = cs["Z"].shape
+    zt, c = _dev(cs["Z"]), _dev(cs["C"])
+    x = torch.empty(n, d, device="cuda")
+    _hip.inverse(shape, params, masks, zt, c, n, x, None)
+    np.testing.assert_allclose(x.cpu().numpy(), cs["gold"]["G3_x"], rtol=1e-5, atol=2e-5)
+    # encode -> decode round trip, in place (x_out may alias z)
+    xx = _dev(cs["X"]); z = torch.empty(n, d, device="cuda")
+    _hip.forward_logprob(shape, params, masks, xx, c, None, n, z, None, None, None, None)
+    _hip.inverse(shape, params, masks, z, c, n, z, None)
+    assert (z - xx).abs().max().item() < max(2e-5, 10 * float(cs["gold"]["G3_roundtrip_maxerr"]))
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("tag,rows", [("G4", None), ("G8", 8)])
+def test_loss_grad(name, tag, rows, oracle32):
+    from oracle import Shape
+    _hip, cs, shape, params, masks = _setup(name)
+    g = cs["gold"]
+    X = cs["X"][:rows]; C = None if cs["C"] is None else cs["C"][:rows]
+    n = X.shape[0]
+    grad = torch.full((cs["params"].size,), float("nan"), device="cuda"); loss = torch.empty(1, device="cuda")
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    _hip.loss_grad(shape, params, masks, _dev(X), _dev(C), None, n, 1.0 / n, grad, loss, ws)
+    grad = grad.cpu().numpy(); loss = float(loss.item())
+    # the loss is ONE float32 number of magnitude |loss|: allow 4 ulp of it on top of the log-prob MAE bar
+    assert abs(loss - g[tag + "_loss"]) < max(logp_mae_tol(name), 5e-7 * abs(loss))
+    if cs["wsrc"] == "torch":
+        ref, got = g[tag + "_grad"], grad
+    else:
+        ref, got = g[tag + "_grad_sub"], grad[::GRAD_STRIDE]
+        l2 = np.sqrt((grad.astype(np.float64) ** 2).sum())
+        assert abs(l2 - g[tag + "_grad_l2"]) < 1e-5 * g[tag + "_grad_l2"]
+    assert np.abs(got - ref).max() < 3e-6 * np.abs(ref).max() + 1e-9
+    # full-vector check against the oracle (fixtures of the large shapes are subsampled)
+    s = Shape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
+    _, gor = oracle32.loss_grad(s, cs["params"], X, C, cs["masks"])
+    assert np.abs(grad - gor).max() < 3e-6 * np.abs(gor).max() + 1e-9
+    assert np.abs(grad[gor == 0]).max(initial=0.0) < 1e-9      # dead (masked) entries stay exactly ~0
+
+
+def test_loss_grad_gather_and_shards(oracle32):
+    """row_index gather + two shards scaled by 1/B_global add up to the full-batch result."""
+    from oracle import Shape
+    _hip, cs, shape, params, masks = _setup("tm")
+    n = cs["X"].shape[0]
+    perm = np.random.default_rng(0).permutation(n).astype(np.int64)
+    x, c, idx = _dev(cs["X"]), _dev(cs["C"]), _dev(perm, torch.int64)
+    P = cs["params"].size
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    full = torch.empty(P + 1, device="cuda")
+    _hip.loss_grad(shape, params, masks, x, c, idx, n, 1.0 / n, full[:P], full[P:], ws)
+    a = torch.empty(P + 1, device="cuda"); b = torch.empty(P + 1, device="cuda")
+    k = 40
+    _hip.loss_grad(shape, params, masks, x, c, idx[:k], k, 1.0 / n, a[:P], a[P:], ws)
+    _hip.loss_grad(shape, params, masks, x, c, idx[k:].contiguous(), n - k, 1.0 / n, b[:P], b[P:], ws)
+    np.testing.assert_allclose((a + b).cpu().numpy(), full.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    s = Shape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
+    lo, go = oracle32.loss_grad(s, cs["params"], cs["X"][perm], cs["C"][perm], cs["masks"])
+    np.testing.assert_allclose(full[:P].cpu().numpy(), go, rtol=1e-4, atol=3e-6 * np.abs(go).max())
+    # empty shard: zeros, no launch
+    z = torch.full((P + 1,), 7.0, device="cuda")
+    _hip.loss_grad(shape, params, masks, x, c, idx[:0], 0, 1.0 / n, z[:P], z[P:], ws)
+    assert float(z.abs().max().item()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["c1_L8", "tm", "d8"])
+@pytest.mark.parametrize("wd", [0.0, 0.2])
+def test_adam_trajectory_vs_reference(name, wd):
+    """3 fused train steps against the reference's own Adam trajectory (G4)."""
+    _hip, cs, shape, params, masks = _setup(name)
+    g = cs["gold"]; k = "G4_adam_wd%g" % wd
+    n = cs["X"].shape[0]; P = cs["params"].size
+    x, c = _dev(cs["X"]), _dev(cs["C"])
+    p = params.clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+    gb = torch.empty(P, device="cuda"); loss = torch.empty(3, device="cuda")
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    for step in range(3):
+        _hip.train_step(shape, p, masks, x, c, None, n, 1.0 / n, gb, loss[step:step + 1], m, v,
+                        0.01, 0.9, 0.999, 1e-8, wd, step + 1, ws)
+        mr, vr, pr = g[k + "_m"][step], g[k + "_v"][step], g[k + "_p"][step]
+        np.testing.assert_allclose(m.cpu().numpy(), mr, rtol=2e-5, atol=3e-6 * np.abs(mr).max())
+        np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=4e-5, atol=6e-6 * np.abs(vr).max())
+        assert np.abs(p.cpu().numpy() - pr).mean() < 2e-6
+    np.testing.assert_allclose(loss.cpu().numpy(), g[k + "_loss"], rtol=5e-5, atol=5e-5)
+
+
+def test_adam_kernel_matches_oracle_bit_exact(oracle32):
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 4, 1001, 76032):
+        p = rng.normal(size=n).astype(np.float32); g = rng.normal(size=n).astype(np.float32) * 1e-2
+        m = rng.normal(size=n).astype(np.float32) * 1e-2; v = (rng.normal(size=n).astype(np.float32) * 1e-2) ** 2
+        pd, gd, md, vd = (torch.from_numpy(a.copy()).cuda() for a in (p, g, m, v))
+        from probaforms_amd import _hip
+        _hip.adam_step(pd, gd, md, vd, n, 1e-3, 0.9, 0.999, 1e-8, 0.2, 7)
+        oracle32.adam(p, g, m, v, 7, lr=1e-3, weight_decay=0.2)
+        # same op order, no FMA contraction, IEEE sqrt/div on both sides: bit-exact
+        assert np.array_equal(md.cpu().numpy(), m)
+        assert np.array_equal(vd.cpu().numpy(), v)
+        assert np.array_equal(pd.cpu().numpy(), p)
+
+
+def test_large_batch_properties():
+    """Size-independent checks at a benchmark-sized batch (C2 shape): round trip and the
+    log-prob identity logp == logdet - 0.5 (d ln 2pi + |z|^2), tiles spanning many blocks."""
+    from probaforms_amd import _hip
+    from cases import numpy_params
+    L, d, c, hidden, act, _ = CASES["c2"]
+    shape = _hip.RnvpShape.make(L, d, c, hidden, act)
+    params = _dev(numpy_params("c2")); masks = _dev(load_case("c2")["masks"], torch.uint8)
+    n = 200_003                                                    # ragged on purpose
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(n, d, device="cuda", generator=gen); cc = torch.randn(n, c, device="cuda", generator=gen)
+    z = torch.empty_like(x); ld = torch.empty(n, device="cuda"); lp = torch.empty(n, device="cuda")
+    tot = torch.empty(1, device="cuda")
+    _hip.forward_logprob(shape, params, masks, x, cc, None, n, z, ld, lp, tot, _ws(_hip, shape, _hip.OP_FORWARD, n))
+    ident = ld - 0.5 * (d * np.log(2 * np.pi) + (z.double() ** 2).sum(1)).float()
+    assert (lp - ident).abs().max().item() < 2e-4
+    assert abs(tot.item() - lp.double().sum().item()) < 1e-5 * abs(lp.double().sum().item())
+    back = torch.empty_like(x)
+    _hip.inverse(shape, params, masks, z, cc, n, back, None)
+    assert (back - x).abs().max().item() < 5e-4 and (back - x).abs().mean().item() < 2e-6
