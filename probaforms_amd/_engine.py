@@ -1,0 +1,315 @@
+"""Host-side engine of the RealNVP hot path: flat parameter storage, workspaces, the
+DataLoader-equivalent shuffle, Adam bookkeeping and data-parallel sharding.
+
+Everything numeric happens in librnvp_hip.so (probaforms_amd/_hip.py); this file only
+decides WHICH rows each call sees and keeps the buffers the kernels read and write.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _hip
+
+
+# ----------------------------------------------------------------------------------------
+# device selection (reference: module-level DEVICE from env var `device`,
+# /root/reference/probaforms/models/realnvp.py:12-15; the build's default is the GPU)
+# ----------------------------------------------------------------------------------------
+def default_device():
+    env = os.environ.get("device")
+    if env:
+        return torch.device(env)
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def require_hip(device):
+    if torch.device(device).type != "cuda":
+        raise RuntimeError(
+            "probaforms_amd runs the RealNVP path on a HIP device only (got device=%r). "
+            "Unset the `device` environment variable or set it to cuda[:i]; there is no CPU fallback."
+            % (device,))
+
+
+# ----------------------------------------------------------------------------------------
+# shuffle: the batch composition of `DataLoader(dataset, batch_size, shuffle=True)`
+# (realnvp.py:237), reproduced by making the same generator calls in the same order.
+# ----------------------------------------------------------------------------------------
+def loader_permutation(n):
+    """Row order of one epoch.  A fresh DataLoader iterator first draws its base seed from the
+    global CPU generator, then RandomSampler draws the seed of a private generator and takes
+    randperm(n) from it (pinned by tests/golden/loader_indices.npz)."""
+    torch.empty((), dtype=torch.int64).random_()                 # _BaseDataLoaderIter base seed
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g)
+
+
+def batch_bounds(n, batch_size):
+    """[(start, stop)] of consecutive slices of the permutation; last one ragged (drop_last=False)."""
+    return [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+
+
+def shard_bounds(start, stop, rank, world):
+    """Contiguous sub-slice of a global batch owned by `rank`; remainder rows go to the low ranks,
+    so a ragged batch may leave high ranks with zero rows (they contribute zero gradients)."""
+    rows = stop - start
+    base, rem = divmod(rows, world)
+    lo = start + rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+# ----------------------------------------------------------------------------------------
+# flat parameter storage
+# ----------------------------------------------------------------------------------------
+def flatten_parameters(params, device):
+    """Move `params` (list of nn.Parameter, reference order) into ONE contiguous float32 device
+    buffer and re-point every parameter at its slice, so state_dict()/load_state_dict() and the
+    kernels see the same memory.  Returns the flat tensor."""
+    total = sum(p.numel() for p in params)
+    pad = (-total) % 4                                   # float4 kernels: keep 16-byte multiples
+    flat = torch.zeros(total + pad, dtype=torch.float32, device=device)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            view = flat[off:off + n].view(p.shape)
+            view.copy_(p.detach().to(device=device, dtype=torch.float32))
+            p.data = view
+            off += n
+    return flat
+
+
+def is_flat(params, flat):
+    """True while every parameter is still the expected slice of `flat` (a later .to()/.float()
+    call re-allocates them)."""
+    if flat is None:
+        return False
+    off = flat.data_ptr()
+    for p in params:
+        if p.data_ptr() != off or p.dtype != torch.float32 or not p.is_contiguous():
+            return False
+        off += p.numel() * 4
+    return True
+
+
+class FlatAdam:
+    """State of `torch.optim.Adam(nf.parameters(), lr, weight_decay)` (realnvp.py:205-207) kept as
+    two flat buffers next to the flat parameters; the update itself is rnvp_adam_step."""
+
+    def __init__(self, n_params, device, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
+                                  amsgrad=False)]
+        self.exp_avg = torch.zeros(n_params, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(n_params, dtype=torch.float32, device=device)
+        self.step_count = 0
+
+    @property
+    def hyper(self):
+        g = self.param_groups[0]
+        return g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]
+
+    def zero_grad(self, set_to_none=True):   # gradients live in the engine's scratch buffer
+        return None
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+
+
+class _Workspace:
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if nbytes <= 0:
+            return None
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class FlowEngine:
+    """Owns the device-side state of one RealNVP flow and issues the HIP calls.
+
+    layers: list of RealNVPLayer with identical (var_size, cond_size, hidden, activation).
+    """
+
+    def __init__(self, layers, device):
+        require_hip(device)
+        self.device = torch.device(device)
+        l0 = layers[0]
+        self.L, self.d, self.c = len(layers), l0.var_size, l0.cond_size
+        self.hidden, self.activation = tuple(l0.hidden), l0.activation
+        for l in layers:
+            if (l.var_size, l.cond_size, tuple(l.hidden), l.activation) != (self.d, self.c, self.hidden, self.activation):
+                raise ValueError("all coupling layers of a flow must share var_size, cond_size, hidden and activation")
+        self.shape = _hip.RnvpShape.make(self.L, self.d, self.c, self.hidden, self.activation)
+        self.layer_shape = _hip.RnvpShape.make(1, self.d, self.c, self.hidden, self.activation)
+        self.param_list = [p for l in layers for p in l.parameters()]
+        self.P = sum(p.numel() for p in self.param_list)
+        if self.P != _hip.param_count(self.shape):
+            raise RuntimeError("parameter count mismatch between the modules (%d) and librnvp_hip (%d)"
+                               % (self.P, _hip.param_count(self.shape)))
+        self.flat = None
+        self.layers = layers
+        self._ws = {op: _Workspace(self.device) for op in (_hip.OP_FORWARD, _hip.OP_INVERSE, _hip.OP_TRAIN)}
+        self._ws_rows = {}
+        self.gbuf = None            # [P + 1]: gradient, then the batch loss (one all-reduce message)
+        self.sync_params()
+
+    # -- storage -------------------------------------------------------------------------
+    def sync_params(self):
+        """(Re)build the flat buffer if the module parameters were moved or replaced."""
+        if not is_flat(self.param_list, self.flat):
+            self.flat = flatten_parameters(self.param_list, self.device)
+        masks = torch.stack([l.mask.detach().to("cpu").to(torch.uint8).reshape(-1) for l in self.layers])
+        self.masks_host = np.ascontiguousarray(masks.numpy())
+        self.masks = masks.to(self.device).contiguous()
+        return self.flat
+
+    @property
+    def params(self):
+        return self.flat[:self.P]
+
+    def workspace(self, op, rows):
+        rows = max(int(rows), 1)
+        key = op
+        if self._ws_rows.get(key, 0) < rows:
+            self._ws_rows[key] = rows
+        return self._ws[op].get(_hip.workspace_bytes(self.shape, op, self._ws_rows[key]))
+
+    def _cond(self, c, n):
+        if self.c == 0:
+            if c is not None:
+                raise RuntimeError("this flow was built without conditions (cond_size=0) but C was given")
+            return None
+        if c is None:
+            # same failure mode as the reference: the first Linear sees d instead of d+c columns
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d): the flow was fit "
+                               "with cond_size=%d, conditions are required" % (n, self.d, self.d + self.c,
+                                                                             self.hidden[0], self.c))
+        if c.shape != (n, self.c):
+            raise RuntimeError("C must have shape (%d, %d), got %s" % (n, self.c, tuple(c.shape)))
+        return c
+
+    def _rows(self, x, rows):
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise RuntimeError("X must have shape (n, %d), got %s" % (self.d, tuple(x.shape)))
+        return x.shape[0] if rows is None else rows.numel()
+
+    # -- hot path --------------------------------------------------------------------------
+    def forward(self, x, c, rows=None, want_z=True, want_logdet=False, want_logp=True, want_sum=False):
+        """-> (z, logdet, logp, logp_sum); unrequested entries are None."""
+        self.sync_params()
+        n = self._rows(x, rows)
+        c = self._cond(c, x.shape[0])
+        dev = self.device
+        z = torch.empty(n, self.d, dtype=torch.float32, device=dev) if want_z else None
+        ld = torch.empty(n, dtype=torch.float32, device=dev) if want_logdet else None
+        lp = torch.empty(n, dtype=torch.float32, device=dev) if want_logp else None
+        tot = torch.zeros(1, dtype=torch.float32, device=dev) if want_sum else None
+        ws = self.workspace(_hip.OP_FORWARD, n)
+        _hip.forward_logprob(self.shape, self.params, self.masks, x, c, rows, n, z, ld, lp, tot, ws)
+        return z, ld, lp, tot
+
+    def inverse(self, z, c, out=None):
+        self.sync_params()
+        n = self._rows(z, None)
+        c = self._cond(c, n)
+        x = torch.empty_like(z) if out is None else out
+        _hip.inverse(self.shape, self.params, self.masks, z, c, n, x, self.workspace(_hip.OP_INVERSE, n))
+        return x
+
+    def ensure_gbuf(self):
+        if self.gbuf is None or self.gbuf.device != self.device:
+            pad = (-(self.P + 1)) % 4
+            self.gbuf = torch.zeros(self.P + 1 + pad, dtype=torch.float32, device=self.device)
+        return self.gbuf
+
+    def loss_grad(self, x, c, rows, n_rows, inv_B):
+        """gbuf[:P] <- d loss / d params for this shard, gbuf[P] <- its share of the batch loss."""
+        g = self.ensure_gbuf()
+        ws = self.workspace(_hip.OP_TRAIN, max(n_rows, 1))
+        _hip.loss_grad(self.shape, self.params, self.masks, x, c, rows, n_rows, inv_B,
+                       g[:self.P], g[self.P:self.P + 1], ws)
+        return g
+
+    def adam(self, opt):
+        lr, b1, b2, eps, wd = opt.hyper
+        opt.step_count += 1
+        g = self.ensure_gbuf()
+        _hip.adam_step(self.params, g[:self.P], opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], self.P,
+                       lr, b1, b2, eps, wd, opt.step_count)
+
+    def train_step(self, opt, x, c, rows, n_rows, inv_B, loss_out):
+        """single-GPU fused step: loss+grad, Adam; the batch loss lands in loss_out[0:1]."""
+        lr, b1, b2, eps, wd = opt.hyper
+        opt.step_count += 1
+        g = self.ensure_gbuf()
+        ws = self.workspace(_hip.OP_TRAIN, max(n_rows, 1))
+        _hip.train_step(self.shape, self.params, self.masks, x, c, rows, n_rows, inv_B, g[:self.P], loss_out,
+                        opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count, ws)
+
+
+# ----------------------------------------------------------------------------------------
+# data-parallel helpers (one process per GPU, torch.distributed; backend "nccl" is RCCL)
+# ----------------------------------------------------------------------------------------
+def dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_reduce_sum(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def broadcast_(t, src=0):
+    import torch.distributed as dist
+    dist.broadcast(t, src=src)
+    return t
+
+
+def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None):
+    """The batch loop of RealNVP.fit (realnvp.py:235-262) on device-resident X [n,d], C [n,c].
+
+    Single GPU: one fused rnvp_train_step per batch.  With torch.distributed initialised every
+    rank walks the SAME permutation, takes its contiguous share of each global batch, and the
+    flat [gradient | loss] buffer is all-reduced (SUM) before an identical Adam step on every
+    rank -- gradients are scaled by 1/B_global inside the kernel, so the sum is the batch mean.
+    Losses stay on the device; one copy per epoch feeds loss_history (one entry per batch, as
+    realnvp.py:254)."""
+    rank, world = dist_info()
+    n = X.shape[0]
+    bounds = batch_bounds(n, batch_size)
+    dev = engine.device
+    for epoch in range(n_epochs):
+        perm = loader_permutation(n).to(dev, non_blocking=False)
+        losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
+        for k, (s, e) in enumerate(bounds):
+            inv_B = 1.0 / (e - s)
+            if world == 1:
+                engine.train_step(opt, X, C, perm[s:e], e - s, inv_B, losses[k:k + 1])
+            else:
+                lo, hi = shard_bounds(s, e, rank, world)
+                g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, inv_B)
+                all_reduce_sum(g[:engine.P + 1])
+                losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
+                engine.adam(opt)
+        host = losses.cpu()
+        loss_history.extend(host[i].clone() for i in range(host.numel()))
+        if epoch_hook is not None:
+            epoch_hook(epoch, float(host[-1]))
+    return loss_history

@@ -108,6 +108,13 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _call(name, args):
+    """arguments are validated (device, dtype, contiguity) BEFORE the stream is looked up, so a CPU
+    tensor is reported as such even on a box without a GPU"""
+    st = getattr(lib(), name)(_stream(), *args)
+    check(st, name)
+
+
 def _ws(ws):
     return _ptr(ws, torch.uint8, "workspace"), (0 if ws is None else ws.numel())
 
@@ -127,49 +134,39 @@ def kernel_path(shape, host_masks_u8, op):
 
 def forward_logprob(shape, params, masks, x, c, row_index, n_rows, z_out, logdet_out, logp_out, logp_sum, ws):
     wp, wn = _ws(ws)
-    st = lib().rnvp_forward_logprob(
-        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+    _call("rnvp_forward_logprob", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
         _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
         int(n_rows), _ptr(z_out, torch.float32, "z_out"), _ptr(logdet_out, torch.float32, "logdet_out"),
-        _ptr(logp_out, torch.float32, "logp_out"), _ptr(logp_sum, torch.float32, "logp_sum"), wp, wn)
-    check(st, "rnvp_forward_logprob")
+        _ptr(logp_out, torch.float32, "logp_out"), _ptr(logp_sum, torch.float32, "logp_sum"), wp, wn))
 
 
 def inverse(shape, params, masks, z, c, n_rows, x_out, ws):
     wp, wn = _ws(ws)
-    st = lib().rnvp_inverse(
-        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+    _call("rnvp_inverse", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
         _ptr(z, torch.float32, "z"), _ptr(c, torch.float32, "c"), int(n_rows),
-        _ptr(x_out, torch.float32, "x_out"), wp, wn)
-    check(st, "rnvp_inverse")
+        _ptr(x_out, torch.float32, "x_out"), wp, wn))
 
 
 def loss_grad(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out, ws):
     wp, wn = _ws(ws)
-    st = lib().rnvp_loss_grad(
-        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+    _call("rnvp_loss_grad", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
         _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
         int(n_rows), float(inv_B), _ptr(grad_out, torch.float32, "grad_out"),
-        _ptr(loss_out, torch.float32, "loss_out"), wp, wn)
-    check(st, "rnvp_loss_grad")
+        _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
 
 
 def adam_step(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step):
-    st = lib().rnvp_adam_step(
-        _stream(), _ptr(params, torch.float32, "params"), _ptr(grad, torch.float32, "grad"),
+    _call("rnvp_adam_step", (_ptr(params, torch.float32, "params"), _ptr(grad, torch.float32, "grad"),
         _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), int(n),
-        float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
-    check(st, "rnvp_adam_step")
+        float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step)))
 
 
 def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out, exp_avg, exp_avg_sq,
                lr, beta1, beta2, eps, weight_decay, step, ws):
     wp, wn = _ws(ws)
-    st = lib().rnvp_train_step(
-        _stream(), C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+    _call("rnvp_train_step", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
         _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
         int(n_rows), float(inv_B), _ptr(grad_buf, torch.float32, "grad_buf"),
         _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
         _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(eps),
-        float(weight_decay), int(step), wp, wn)
-    check(st, "rnvp_train_step")
+        float(weight_decay), int(step), wp, wn))

@@ -1,0 +1,187 @@
+"""Conditional RealNVP, MI355X build.
+
+Mirrors `probaforms.models.realnvp` (/root/reference/probaforms/models/realnvp.py): same
+constructor arguments and defaults, same attributes (`nf`, `opt`, `prior`, `loss_history`, ...),
+same `state_dict` keys and `[out, in]` weight layout, same RNG consumption (parameter init,
+per-epoch shuffle, prior draws) -- but the coupling stack, its backward and Adam run as
+hand-written HIP kernels (probaforms_amd/csrc, C ABI in include/rnvp_hip.h).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from .._engine import (FlatAdam, broadcast_, default_device, dist_info, fit_epochs, flatten_parameters,
+                       is_flat, require_hip)
+from .interfaces import GenModel
+from .nflow import InvertibleLayer, NormalizingFlow, StandardNormalPrior
+
+DEVICE = default_device()
+
+
+def gen_network(n_inputs, n_outputs, hidden=(10,), activation='tanh'):
+    """The s or t net: Linear(n_inputs, hidden[0]), act, ..., Linear(hidden[-1], n_outputs)
+    (realnvp.py:19-43).  Built from stock ``nn.Linear`` modules in the reference's order so the
+    default initialisation consumes the global generator identically; 'tanh' selects Tanh, any
+    other string ReLU."""
+    widths = [n_inputs] + list(hidden)
+    net = nn.Sequential()
+    for w_in, w_out in zip(widths[:-1], widths[1:]):
+        net.append(nn.Linear(w_in, w_out))
+        net.append(nn.Tanh() if activation == 'tanh' else nn.ReLU())
+    net.append(nn.Linear(widths[-1], n_outputs))
+    return net
+
+
+class RealNVPLayer(InvertibleLayer):
+    """One affine coupling layer (realnvp.py:47-129).
+
+    With m = mask, u = [X*m || C]:  T = nn_t(u), S = nn_s(u),
+      f:  X_new = (X*exp(S) + T)*(1-m) + X*m,   log_det = sum_j (1-m_j) S_j
+      g:  X_new = ((X - T)*exp(-S))*(1-m) + X*m
+    `mask` is a {0,1} tensor of length var_size kept as a plain attribute (not in state_dict).
+    `f`/`g` run the HIP kernels on this layer alone; inside a NormalizingFlow the whole stack
+    is fused instead.  The outputs carry no autograd graph: training goes through the fused
+    loss/gradient kernel (RealNVP.fit).
+    """
+
+    def __init__(self, var_size, cond_size, mask, hidden=(10,), activation='tanh'):
+        super().__init__(var_size=var_size)
+        self.cond_size = cond_size
+        self.hidden = tuple(hidden)
+        self.activation = activation
+        self.mask = mask            # stays a host tensor; the kernels take a uint8 copy
+        self.nn_t = gen_network(var_size + cond_size, var_size, hidden, activation)   # order matters:
+        self.nn_s = gen_network(var_size + cond_size, var_size, hidden, activation)   # t first, then s
+        self._flat = None
+
+    def _layer_params(self, device):
+        plist = list(self.parameters())
+        if is_flat(plist, self._flat) and self._flat.device == device:
+            return self._flat
+        # inside a fused flow the parameters already sit contiguously in the flow's buffer
+        first = plist[0]
+        if first.device == device and first.dtype == torch.float32:
+            off, ok = first.data_ptr(), True
+            for p in plist:
+                ok = ok and p.data_ptr() == off and p.is_contiguous() and p.dtype == torch.float32
+                off += p.numel() * 4
+            if ok:
+                n = sum(p.numel() for p in plist)
+                base = first.data.view(-1)
+                return torch.as_strided(base, (n,), (1,))
+        self._flat = flatten_parameters(plist, device)
+        return self._flat
+
+    def _prep(self, X, C):
+        dev = X.device if isinstance(X, torch.Tensor) and X.is_cuda else DEVICE
+        require_hip(dev)
+        X = torch.as_tensor(X, dtype=torch.float32).to(dev).contiguous()
+        if self.cond_size > 0:
+            if C is None:
+                raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: layer built with cond_size=%d needs C"
+                                   % self.cond_size)
+            C = torch.as_tensor(C, dtype=torch.float32).to(dev).contiguous()
+        elif C is not None:
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: layer built with cond_size=0 got C")
+        shape = _hip.RnvpShape.make(1, self.var_size, self.cond_size, self.hidden, self.activation)
+        mask = self.mask.detach().to(dev).to(torch.uint8).contiguous()
+        P = _hip.param_count(shape)
+        return dev, X, C, shape, mask, self._layer_params(dev)[:P]
+
+    def f(self, X, C=None):
+        dev, X, C, shape, mask, params = self._prep(X, C)
+        n = X.shape[0]
+        X_new = torch.empty_like(X)
+        log_det = torch.empty(n, dtype=torch.float32, device=dev)
+        _hip.forward_logprob(shape, params, mask, X, C, None, n, X_new, log_det, None, None, None)
+        return X_new, log_det
+
+    def g(self, X, C=None):
+        dev, X, C, shape, mask, params = self._prep(X, C)
+        X_new = torch.empty_like(X)
+        _hip.inverse(shape, params, mask, X, C, X.shape[0], X_new, None)
+        return X_new
+
+
+class RealNVP(GenModel):
+    """RealNVP normalizing flow with the reference's sklearn-style interface (realnvp.py:133-282).
+
+    Parameters (identical names and defaults to the reference):
+        n_layers=8, hidden=(10,), activation='tanh', batch_size=32, n_epochs=10, lr=1e-4,
+        weight_decay=0, verbose=0
+    ``fit(X, C=None)`` takes numpy arrays [n, d] / [n, c]; ``sample(C)`` takes [n, c] or a python
+    int and returns a float32 numpy array [n, d].  A second ``fit`` continues training (same
+    optimizer state) and keeps appending to ``loss_history`` (one 0-dim CPU tensor per batch).
+    Under ``torch.distributed`` (one process per GPU) ``fit`` is data parallel.
+    """
+
+    def __init__(self, n_layers=8, hidden=(10,), activation='tanh',
+                 batch_size=32, n_epochs=10, lr=0.0001, weight_decay=0, verbose=0):
+        super().__init__()
+        self.n_layers = n_layers
+        self.hidden = hidden
+        self.activation = activation
+        self.batch_size = batch_size
+        self.n_epochs = n_epochs
+        self.lr = lr
+        self.weight_decay = weight_decay
+        self.verbose = verbose
+
+        self.prior = None
+        self.nf = None
+        self.opt = None
+
+        self.loss_history = []
+
+    def _model_init(self, X, C):
+        """Lazy construction on first fit (realnvp.py:180-207): prior, layers with masks
+        (arange(d) + i) % 2, flow, optimizer -- each only if still None (warm start)."""
+        require_hip(DEVICE)
+        var_size = X.shape[1]
+        cond_size = C.shape[1] if C is not None else 0
+
+        if self.prior is None:
+            self.prior = StandardNormalPrior(var_size, DEVICE)
+
+        if self.nf is None:
+            layers = [RealNVPLayer(var_size=var_size, cond_size=cond_size,
+                                   mask=((torch.arange(var_size) + i) % 2),
+                                   hidden=self.hidden, activation=self.activation)
+                      for i in range(self.n_layers)]
+            self.nf = NormalizingFlow(layers=layers, prior=self.prior)
+            eng = self.nf.engine()                 # moves the parameters into one flat HIP buffer
+            _, world = dist_info()
+            if world > 1:
+                broadcast_(eng.flat, src=0)        # identical replicas whatever the local seeds were
+            self.opt = FlatAdam(eng.flat.numel(), eng.device, lr=self.lr, weight_decay=self.weight_decay)
+
+    def fit(self, X, C=None):
+        self._model_init(X, C)
+        eng = self.nf.engine()
+        # numpy (any float dtype) -> float32 on the device, once (realnvp.py:226-228)
+        Xd = torch.tensor(np.asarray(X), dtype=torch.float32, device=eng.device).contiguous()
+        Cd = None if C is None else torch.tensor(np.asarray(C), dtype=torch.float32, device=eng.device).contiguous()
+        if not self.nf._fused_prior():
+            raise NotImplementedError("fit() fuses the N(0, I) prior into the loss kernel; custom priors are "
+                                      "supported for log_prob/sample only")
+        eng._cond(Cd, Xd.shape[0])
+        bar = None
+        if self.verbose >= 1:
+            from tqdm.auto import tqdm
+            bar = tqdm(total=self.n_epochs, unit='epoch')
+
+        def hook(epoch, last_loss):
+            if bar is not None:
+                bar.update(1)
+                bar.set_description("loss: %.4f" % last_loss)
+
+        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook)
+        if bar is not None:
+            bar.close()
+
+    def sample(self, C=100):
+        if type(C) != type(1):
+            C = torch.tensor(np.asarray(C), dtype=torch.float32, device=self.nf.engine().device)
+        X = self.nf.sample(C).cpu().detach().numpy()
+        return X
