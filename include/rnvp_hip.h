@@ -58,6 +58,14 @@ typedef struct rnvp_shape {
     int32_t n_hidden;                 /* len(hidden)               realnvp.py:22        */
     int32_t hidden[RNVP_MAX_HIDDEN];
     int32_t act;                      /* RNVP_ACT_*                                     */
+    int32_t alt_masks;                /* caller's declaration about `masks`:
+                                         0 = arbitrary {0,1} table, read from the masks pointer;
+                                         1 = masks[l][j] == (j + l) % 2, the reference's own
+                                             construction (realnvp.py:199);
+                                         2 = masks[l][j] == (j + l + 1) % 2 (the same pattern seen
+                                             from an odd layer, e.g. one RealNVPLayer on its own).
+                                         1/2 let the library skip the masked-out (dead) columns and
+                                         pick the MFMA path; the masks pointer is then not read.   */
 } rnvp_shape;
 
 /* operations, for rnvp_workspace_bytes */

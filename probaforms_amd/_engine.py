@@ -153,13 +153,13 @@ class FlowEngine:
             if (l.var_size, l.cond_size, tuple(l.hidden), l.activation) != (self.d, self.c, self.hidden, self.activation):
                 raise ValueError("all coupling layers of a flow must share var_size, cond_size, hidden and activation")
         self.shape = _hip.RnvpShape.make(self.L, self.d, self.c, self.hidden, self.activation)
-        self.layer_shape = _hip.RnvpShape.make(1, self.d, self.c, self.hidden, self.activation)
         self.param_list = [p for l in layers for p in l.parameters()]
         self.P = sum(p.numel() for p in self.param_list)
         if self.P != _hip.param_count(self.shape):
             raise RuntimeError("parameter count mismatch between the modules (%d) and librnvp_hip (%d)"
                                % (self.P, _hip.param_count(self.shape)))
         self.flat = None
+        self.masks_host = None
         self.layers = layers
         self._ws = {op: _Workspace(self.device) for op in (_hip.OP_FORWARD, _hip.OP_INVERSE, _hip.OP_TRAIN)}
         self._ws_rows = {}
@@ -172,8 +172,12 @@ class FlowEngine:
         if not is_flat(self.param_list, self.flat):
             self.flat = flatten_parameters(self.param_list, self.device)
         masks = torch.stack([l.mask.detach().to("cpu").to(torch.uint8).reshape(-1) for l in self.layers])
-        self.masks_host = np.ascontiguousarray(masks.numpy())
-        self.masks = masks.to(self.device).contiguous()
+        host = np.ascontiguousarray(masks.numpy())
+        if getattr(self, "masks_host", None) is None or not np.array_equal(host, self.masks_host):
+            self.masks_host = host
+            self.masks = masks.to(self.device).contiguous()
+            # declare the reference's alternating pattern (realnvp.py:199) when that is what we hold
+            self.shape.alt_masks = _hip.RnvpShape.classify_masks(host)
         return self.flat
 
     @property

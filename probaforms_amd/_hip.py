@@ -23,10 +23,10 @@ class RnvpShape(C.Structure):
     """mirror of `rnvp_shape` (include/rnvp_hip.h)"""
     _fields_ = [("L", C.c_int32), ("d", C.c_int32), ("c", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
-                ("act", C.c_int32)]
+                ("act", C.c_int32), ("alt_masks", C.c_int32)]
 
     @classmethod
-    def make(cls, L, d, c, hidden, activation):
+    def make(cls, L, d, c, hidden, activation, alt_masks=0):
         hidden = tuple(int(h) for h in hidden)
         if not 1 <= len(hidden) <= MAX_HIDDEN:
             raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
@@ -35,7 +35,23 @@ class RnvpShape(C.Structure):
         for i, h in enumerate(hidden):
             s.hidden[i] = h
         s.act = 0 if activation == "tanh" else 1     # anything else is ReLU, realnvp.py:32-37
+        s.alt_masks = int(alt_masks)
         return s
+
+    @staticmethod
+    def classify_masks(masks):
+        """0 arbitrary; 1 if masks[l][j] == (j+l)%2 (realnvp.py:199); 2 if == (j+l+1)%2"""
+        import numpy as np
+        m = np.asarray(masks).astype(np.int64)
+        if m.ndim == 1:
+            m = m[None, :]
+        L, d = m.shape
+        base = (np.arange(d)[None, :] + np.arange(L)[:, None]) % 2
+        if np.array_equal(m, base):
+            return 1
+        if np.array_equal(m, 1 - base):
+            return 2
+        return 0
 
     def key(self):
         return (self.L, self.d, self.c, tuple(self.hidden[:self.n_hidden]), self.act)

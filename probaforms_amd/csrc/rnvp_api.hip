@@ -3,13 +3,14 @@
 #include <cstring>
 
 #include "rnvp_common.h"
+#include "rnvp_mfma.h"
 
 using namespace rnvp;
 
 namespace {
 
 bool bad_ptrs(const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c) {
-    return !params || !masks || !x || (k.c > 0 && !c);
+    return !params || (!masks && !k.alt) || !x || (k.c > 0 && !c);
 }
 
 }  // namespace
@@ -37,14 +38,24 @@ size_t rnvp_param_count(const rnvp_shape *shape) {
 int rnvp_kernel_path(const rnvp_shape *shape, const uint8_t *host_masks, int op) {
     KShape k;
     if (make_kshape(shape, &k) != RNVP_OK) return RNVP_EINVAL;
-    (void)host_masks; (void)op;
+    if (host_masks && k.alt) {          // a declared pattern must agree with the table, if one is given
+        for (int l = 0; l < k.L; ++l)
+            for (int j = 0; j < k.d; ++j)
+                if (host_masks[(size_t)l * k.d + j] != (uint8_t)((j + l + k.alt - 1) & 1)) return RNVP_EINVAL;
+    }
+    if (mfma::supported(k) && op != RNVP_OP_TRAIN) return RNVP_PATH_MFMA;
     return RNVP_PATH_GENERIC;
 }
 
 size_t rnvp_workspace_bytes(const rnvp_shape *shape, int op, int64_t max_rows) {
     KShape k;
     if (make_kshape(shape, &k) != RNVP_OK) return 0;
-    return generic_workspace_bytes(k, op, max_rows) + 256;
+    size_t b = generic_workspace_bytes(k, op, max_rows);
+    if (mfma::supported(k)) {
+        const size_t m = mfma::workspace_bytes(k, op, max_rows);
+        if (m > b) b = m;
+    }
+    return b + 256;
 }
 
 int rnvp_forward_logprob(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
@@ -61,6 +72,10 @@ int rnvp_forward_logprob(void *stream, const rnvp_shape *shape, const float *par
         return RNVP_OK;
     }
     if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
+    if (mfma::supported(k))
+        return mfma::forward(st, k, params, x, c, row_index, n_rows, z_out, logdet_out, logp_out, logp_sum,
+                             workspace, workspace_bytes);
+    if (!masks) return RNVP_EINVAL;
     return generic_forward(st, k, params, masks, x, c, row_index, n_rows, z_out, logdet_out, logp_out,
                            logp_sum, workspace, workspace_bytes);
 }
@@ -74,7 +89,10 @@ int rnvp_inverse(void *stream, const rnvp_shape *shape, const float *params, con
     if (n_rows < 0) return RNVP_EINVAL;
     if (n_rows == 0) return RNVP_OK;
     if (bad_ptrs(k, params, masks, z, c) || !x_out) return RNVP_EINVAL;
-    (void)workspace; (void)workspace_bytes;
+    if (mfma::supported(k))
+        return mfma::inverse(static_cast<hipStream_t>(stream), k, params, z, c, n_rows, x_out, workspace,
+                             workspace_bytes);
+    if (!masks) return RNVP_EINVAL;
     return generic_inverse(static_cast<hipStream_t>(stream), k, params, masks, z, c, n_rows, x_out);
 }
 
@@ -92,7 +110,7 @@ int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, c
         if (loss_out) RNVP_HIP_TRY(hipMemsetAsync(loss_out, 0, sizeof(float), st));
         return RNVP_OK;
     }
-    if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
+    if (bad_ptrs(k, params, masks, x, c) || !masks) return RNVP_EINVAL;
     return generic_loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out,
                              workspace, workspace_bytes);
 }

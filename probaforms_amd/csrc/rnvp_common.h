@@ -15,6 +15,7 @@ constexpr float kLog2Pi = 1.8378770664093453f;   // ln(2*pi)
 // (gen_network, /root/reference/probaforms/models/realnvp.py:19-43) precomputed.
 struct KShape {
     int L, d, c, nh, act;
+    int alt;                           // rnvp_shape::alt_masks (0 arbitrary, 1/2 alternating)
     int nin[kMaxLin], nout[kMaxLin];   // Linear k: [nout, nin]
     int woff[kMaxLin], boff[kMaxLin];  // float offsets inside one net's parameter block
     int npn;                           // parameters per net
@@ -28,6 +29,8 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
         return RNVP_EINVAL;
     k->L = s->L; k->d = s->d; k->c = s->c; k->nh = s->n_hidden;
     k->act = (s->act == RNVP_ACT_TANH) ? RNVP_ACT_TANH : RNVP_ACT_RELU;
+    if (s->alt_masks < 0 || s->alt_masks > 2) return RNVP_EINVAL;
+    k->alt = s->alt_masks;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;
     for (int i = 0; i <= s->n_hidden; ++i) {

@@ -1,0 +1,82 @@
+// rnvp_mfma.h -- geometry of the register-chained f32 MFMA path (gfx950, wave64).
+//
+// One wave owns R tiles of 16 rows for the whole L-layer stack.  Every contraction is a
+// v_mfma_f32_16x16x4_f32 computed TRANSPOSED (features on the MFMA M axis, rows on N), so that
+// lane (q = lane >> 4, r = lane & 15) always holds data of row r:
+//   * x:  lane (q, r) keeps features j = q*2NF + e, e in [0, 2NF)  (d = 8*NF; a float4 row load),
+//   * c:  lane (q, r) keeps conditions q*CQ + g, g in [0, CQ)       (cdim = 4*CQ),
+//   * GEMM1  hidden^T[hid x rows] = W1 . in^T : B operand = those registers directly
+//            (k-step kk: k = q <-> conditioning slot kk of lane group q, or condition kk - NF),
+//   * its accumulator (lane (q, r): hid 16*ht + 4q + reg, row r) IS the B operand of
+//     GEMM2  out^T[out x rows] = W2 . h^T  with the k order permuted (k-step reg: k = q),
+//   * GEMM2's accumulator rows are ordered so lane (q, r) receives t and s of exactly the
+//     features it keeps, and the affine update is purely per-lane.
+// Activations therefore never leave registers between the two Linears and across layers; only the
+// weights (pre-packed into these fragment orders by k_pack_weights) stream in from L2.
+//
+// With the reference's alternating masks (realnvp.py:199; rnvp_shape::alt_masks = 1) layer l
+// conditions on features of parity pc = (l + alt_masks) & 1 and transforms the others; masked-out columns of W1 and rows of W2
+// (dead work in the reference's dense form) are never computed.
+#pragma once
+#include "rnvp_common.h"
+
+namespace rnvp {
+namespace mfma {
+
+struct Geo {
+    int NF;     // d / 8: features per parity class per lane
+    int CQ;     // c / 4: conditions per lane
+    int HT;     // h / 16: hidden tiles per net
+    int KS1;    // NF + CQ: k-steps of GEMM1
+    int K4;     // ceil(KS1 / 4): float4 groups of A1 per lane
+    int OTL;    // out tiles fed by one hidden tile: max(1, NF / 4)
+    int NT2;    // out tiles in total: NF >= 4 ? 2 * OTL : 1 (t and s share one tile when NF == 2)
+    int NTI;    // N tiles of the W1 gradient (KS1*4 input columns + 1 ones column for the bias)
+    int MTI;    // M tiles of the input gradient: max(1, NF / 4)
+    // float offsets inside one layer's packed block
+    int oA1, oB1, oA2, oB2, oA2T, oA1T, layer_floats;
+    // packed gradient block of one layer
+    int oG1, oG2, oGb2, glayer_floats;
+};
+
+__host__ __device__ inline Geo make_geo(int d, int c, int h) {
+    Geo g;
+    g.NF = d / 8; g.CQ = c / 4; g.HT = h / 16;
+    g.KS1 = g.NF + g.CQ; g.K4 = (g.KS1 + 3) / 4;
+    g.OTL = g.NF >= 4 ? g.NF / 4 : 1;
+    g.NT2 = g.NF >= 4 ? 2 * g.OTL : 1;
+    g.NTI = (g.KS1 * 4 + 1 + 15) / 16;
+    g.MTI = g.NF >= 4 ? g.NF / 4 : 1;
+    int o = 0;
+    g.oA1 = o; o += 2 * g.HT * g.K4 * 256;          // [tile][k4][lane][4]
+    g.oB1 = o; o += 2 * g.HT * 16;                  // [tile][q][4]
+    g.oA2 = o; o += 2 * g.HT * g.OTL * 256;         // [tile][otl][lane][4 (rho)]
+    g.oB2 = o; o += g.NT2 * 16;                     // [ot][q][4]
+    g.oA2T = o; o += 2 * g.HT * g.OTL * 256;        // [tile][otl][lane][4 (rho)]   (backward: W2^T)
+    g.oA1T = o; o += 2 * g.HT * g.MTI * 256;        // [tile][mt][lane][4 (rho)]    (backward: W1^T)
+    g.layer_floats = o;
+    o = 0;
+    g.oG1 = o; o += 2 * g.HT * g.NTI * 256;         // [tile][nt][lane][4]: dW1 (+ db1 in the ones column)
+    g.oG2 = o; o += 2 * g.HT * g.OTL * 256;         // [tile][otl][lane][4]: dW2
+    g.oGb2 = o; o += g.NT2 * 64;                    // [ot][lane]... db2 kept per lane group, see kernel
+    g.glayer_floats = o;
+    return g;
+}
+
+// feature index of conditioning / transformed slot f of lane group q in a layer of parity pc
+__host__ __device__ inline int feat_cond(int NF, int q, int f, int pc) { return q * 2 * NF + 2 * f + pc; }
+__host__ __device__ inline int feat_trans(int NF, int q, int f, int pc) { return q * 2 * NF + 2 * f + 1 - pc; }
+
+bool supported(const KShape &k);
+size_t workspace_bytes(const KShape &k, int op, int64_t max_rows);
+int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+            const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out,
+            float *logp_sum, void *ws, size_t ws_bytes);
+int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c,
+            int64_t n, float *x_out, void *ws, size_t ws_bytes);
+int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+              const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
+              void *ws, size_t ws_bytes);
+
+}  // namespace mfma
+}  // namespace rnvp

@@ -1,0 +1,388 @@
+// rnvp_mfma.hip -- register-chained f32 MFMA kernels for the RealNVP coupling stack (gfx950).
+// Layout and rationale: rnvp_mfma.h.  Replaces RealNVPLayer.f / .g for every layer and the
+// loops of NormalizingFlow.log_prob / .sample (/root/reference/probaforms/models/realnvp.py:
+// 91-101,120-129; nflow.py:107-117,141-145) for d in {16,32,64}, cdim in {0,4,8,16}, one hidden
+// layer with h % 16 == 0, tanh, and the reference's alternating masks.
+#include "rnvp_mfma.h"
+
+namespace rnvp {
+namespace mfma {
+namespace {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kWaves = 4;                // waves per workgroup (one per SIMD)
+constexpr int kMaxGrid = 2048;
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// tanh(v) = 1 - 2 / (1 + e^{2v}): one v_exp_f32 + one v_rcp_f32 (~1 ulp each); saturates
+// correctly through e = +inf / 0; absolute error ~1e-7, the rounding level of values near 1.
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);   // 2 * log2(e)
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return fmaf(-2.0f, r, 1.0f);
+}
+
+// ---- weight packing ----------------------------------------------------------------------------
+// One thread per float of the packed block; reads the flat reference-order parameters
+// (include/rnvp_hip.h "params").  Runs at the head of every call so the packed copy always
+// reflects the caller's current parameters (76 k .. 450 k floats: a few microseconds).
+__device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const float *__restrict__ params) {
+    const int pc = (l + k.alt) & 1;
+    const int nin = k.d + k.c, h = k.nout[0];
+    const float *pl = params + (size_t)l * 2 * k.npn;
+    if (idx < g.oB1) {                                     // A1 [tile][k4][lane][4]
+        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+        const int k4 = rest % g.K4, tile = rest / g.K4;
+        const int kk = 4 * k4 + e, q = lane >> 4, i = lane & 15;
+        const int net = tile / g.HT, hid = 16 * (tile % g.HT) + i;
+        int col;
+        if (kk < g.NF) col = feat_cond(g.NF, q, kk, pc);
+        else if (kk < g.KS1) col = k.d + q * g.CQ + (kk - g.NF);
+        else return 0.f;
+        return pl[net * k.npn + k.woff[0] + hid * nin + col];
+    }
+    if (idx < g.oA2) {                                     // bias1 [tile][q][4]
+        const int j = idx - g.oB1;
+        const int e = j & 3, q = (j >> 2) & 3, tile = j >> 4;
+        const int net = tile / g.HT;
+        return pl[net * k.npn + k.boff[0] + 16 * (tile % g.HT) + 4 * q + e];
+    }
+    if (idx < g.oB2) {                                     // A2 [tile][otl][lane][4 rho]
+        const int j = idx - g.oA2;
+        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int otl = rest % g.OTL, tile = rest / g.OTL;
+        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
+        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
+        const int qo = i >> 2, ro = i & 3;
+        int f, net_out;
+        if (g.NF >= 4) { f = 4 * otl + ro; net_out = net; }
+        else { f = ro & 1; net_out = ro >> 1; }
+        if (net_out != net) return 0.f;
+        return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, qo, f, pc) * h + hid];
+    }
+    if (idx < g.oA2T) {                                    // bias2 [ot][q][4]
+        const int j = idx - g.oB2;
+        const int ro = j & 3, qo = (j >> 2) & 3, ot = j >> 4;
+        int f, net;
+        if (g.NF >= 4) { net = ot / g.OTL; f = 4 * (ot % g.OTL) + ro; }
+        else { net = ro >> 1; f = ro & 1; }
+        return pl[net * k.npn + k.boff[1] + feat_trans(g.NF, qo, f, pc)];
+    }
+    if (idx < g.oA1T) {                                    // A2T [tile][otl][lane][4 rho]
+        const int j = idx - g.oA2T;
+        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int otl = rest % g.OTL, tile = rest / g.OTL;
+        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
+        const int hid = 16 * (tile % g.HT) + i;
+        int f, net_out;
+        if (g.NF >= 4) { f = 4 * otl + rho; net_out = net; }
+        else { f = rho & 1; net_out = rho >> 1; }
+        if (net_out != net) return 0.f;
+        return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, q, f, pc) * h + hid];
+    }
+    {                                                      // A1T [tile][mt][lane][4 rho]
+        const int j = idx - g.oA1T;
+        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int mt = rest % g.MTI, tile = rest / g.MTI;
+        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
+        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
+        const int qi = i >> 2, ri = i & 3;
+        int f;
+        if (g.NF >= 4) f = 4 * mt + ri;
+        else { if (ri >= 2) return 0.f; f = ri; }
+        return pl[net * k.npn + k.woff[0] + hid * nin + feat_cond(g.NF, qi, f, pc)];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restrict__ packed) {
+    const int per = g.layer_floats;
+    const int64_t total = (int64_t)per * k.L;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(t / per), idx = (int)(t - (int64_t)l * per);
+        packed[t] = pack_value(k, g, l, idx, params);
+    }
+}
+
+__global__ void k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float a = 0.f;
+        for (int i = 0; i < G; ++i) a += part[i];
+        out[0] = a * scale;
+    }
+}
+
+// ---- one coupling layer for the wave's R row tiles -------------------------------------------------
+template <int NF, int CQ, int R, int PC, bool INVERSE>
+__device__ __forceinline__ void layer_apply(const float *__restrict__ W, const Geo &g, int lane,
+                                            float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                            float (&ld)[R]) {
+    constexpr int KS1 = NF + CQ, K4 = (KS1 + 3) / 4;
+    constexpr int OTL = NF >= 4 ? NF / 4 : 1, NT2 = NF >= 4 ? 2 * OTL : 1;
+    const int q = lane >> 4;
+    f4 out[R][NT2];
+#pragma unroll
+    for (int ot = 0; ot < NT2; ++ot) {
+        const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
+    }
+    const int HT = g.HT;
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
+        const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
+        const float *pA2 = W + g.oA2 + ((size_t)net * HT * OTL * 64 + lane) * 4;
+        f4 a1[K4], a2[OTL], b1;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
+        b1 = *reinterpret_cast<const f4 *>(pB1);
+#pragma unroll
+        for (int o = 0; o < OTL; ++o) a2[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
+        for (int ht = 0; ht < HT; ++ht) {
+            // prefetch the next hidden tile's fragments (the last iteration re-reads its own)
+            const int nx = (ht + 1 < HT) ? ht + 1 : ht;
+            f4 na1[K4], na2[OTL], nb1;
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4)
+                na1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)nx * K4 + k4) * 256);
+            nb1 = *reinterpret_cast<const f4 *>(pB1 + nx * 16);
+#pragma unroll
+            for (int o = 0; o < OTL; ++o)
+                na2[o] = *reinterpret_cast<const f4 *>(pA2 + ((size_t)nx * OTL + o) * 256);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                f4 acc = b1;
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk) {
+                    const float bop = (kk < NF) ? xr[rt][2 * (kk < NF ? kk : 0) + PC] : cr[rt][kk >= NF ? kk - NF : 0];
+                    acc = mfma16(a1[kk >> 2][kk & 3], bop, acc);
+                }
+                f4 hv;
+                hv[0] = fast_tanh(acc[0]); hv[1] = fast_tanh(acc[1]);
+                hv[2] = fast_tanh(acc[2]); hv[3] = fast_tanh(acc[3]);
+#pragma unroll
+                for (int o = 0; o < OTL; ++o) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int ot = (NF >= 4) ? net * OTL + o : 0;
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho) out[rt][ot] = mfma16(a2[o][rho], hv[rho], out[rt][ot]);
+                }
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
+            b1 = nb1;
+#pragma unroll
+            for (int o = 0; o < OTL; ++o) a2[o] = na2[o];
+        }
+    }
+    // affine update of the transformed features, all per lane
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float tv, sv;
+            if (NF >= 4) { tv = out[rt][f >> 2][f & 3]; sv = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
+            else { tv = out[rt][0][f & 1]; sv = out[rt][0][2 + (f & 1)]; }
+            const int e = 2 * f + 1 - PC;
+            if (!INVERSE) {
+                xr[rt][e] = fmaf(xr[rt][e], expf(sv), tv);       // x*exp(s) + t   (realnvp.py:99)
+                ld[rt] += sv;                                    // log_det        (realnvp.py:100)
+            } else {
+                xr[rt][e] = (xr[rt][e] - tv) * expf(-sv);        // (x - t)*exp(-s) (realnvp.py:128)
+            }
+        }
+    }
+}
+
+// ---- whole stack: forward (+ log-det + prior) or inverse ---------------------------------------
+template <int NF, int CQ, int R, bool INVERSE>
+__global__ void __launch_bounds__(kWaves * 64)
+k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+            const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n,
+            float *out_x, float *logdet_out, float *logp_out, float *part) {
+    constexpr int D = 8 * NF, CD = 4 * CQ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const float prior_c = 0.5f * (float)D * kLog2Pi;
+    float wave_sum = 0.f;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
+        if (base >= n) continue;                      // whole wave past the end (no barriers here)
+        float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const int64_t row = base + rt * 16 + r;
+            const bool valid = row < n;
+            const int64_t src = valid ? (row_index ? row_index[row] : row) : 0;
+            const float *xp = x + src * D + q * 2 * NF;
+#pragma unroll
+            for (int v = 0; v < 2 * NF; v += 4) {
+                const f4 t = *reinterpret_cast<const f4 *>(xp + v);
+                xr[rt][v] = t[0]; xr[rt][v + 1] = t[1]; xr[rt][v + 2] = t[2]; xr[rt][v + 3] = t[3];
+            }
+            if (CQ > 0) {
+                const float *cp = c + src * CD + q * CQ;
+#pragma unroll
+                for (int v = 0; v < CQ; ++v) cr[rt][v] = cp[v];
+            } else {
+                cr[rt][0] = 0.f;
+            }
+            ld[rt] = 0.f;
+        }
+        for (int lp = 0; lp < L; ++lp) {
+            const int l = INVERSE ? L - 1 - lp : lp;
+            const float *W = wp + (size_t)l * g.layer_floats;
+            if ((l + alt) & 1) layer_apply<NF, CQ, R, 1, INVERSE>(W, g, lane, xr, cr, ld);
+            else layer_apply<NF, CQ, R, 0, INVERSE>(W, g, lane, xr, cr, ld);
+        }
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const int64_t row = base + rt * 16 + r;
+            const bool valid = row < n;
+            if (out_x && valid) {
+                float *op = out_x + row * D + q * 2 * NF;
+#pragma unroll
+                for (int v = 0; v < 2 * NF; v += 4) {
+                    f4 t;
+                    t[0] = xr[rt][v]; t[1] = xr[rt][v + 1]; t[2] = xr[rt][v + 2]; t[3] = xr[rt][v + 3];
+                    *reinterpret_cast<f4 *>(op + v) = t;
+                }
+            }
+            if (!INVERSE) {
+                float ss = 0.f;
+#pragma unroll
+                for (int v = 0; v < 2 * NF; ++v) ss = fmaf(xr[rt][v], xr[rt][v], ss);
+                float l1 = ld[rt];
+                // a row's features are spread over the 4 lane groups: add across q
+                l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
+                ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+                const float lp = l1 + (-0.5f * ss - prior_c);          // nflow.py:115
+                if (valid && q == 0) {
+                    if (logdet_out) logdet_out[row] = l1;
+                    if (logp_out) logp_out[row] = lp;
+                }
+                if (part) {
+                    float v = (valid && q == 0) ? lp : 0.f;
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    wave_sum += v;
+                }
+            }
+        }
+    }
+    if (!INVERSE && part && lane == 0) part[blockIdx.x * kWaves + wave] = wave_sum;
+}
+
+template <int NF, int CQ> struct RowTiles { static constexpr int value = NF == 2 ? 4 : (NF == 4 ? 2 : 1); };
+
+struct Launch {
+    Geo g;
+    int grid;
+    float *packed;
+    float *part;
+};
+
+size_t packed_bytes(const KShape &k) {
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    return align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);
+}
+
+int pack(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed) {
+    const int64_t total = (int64_t)g.layer_floats * k.L;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, st, k, g, params, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+template <int NF, int CQ, bool INVERSE>
+int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
+                const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
+                float *logp_out, float *part, int *grid_out) {
+    constexpr int R = RowTiles<NF, CQ>::value;
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
+    *grid_out = grid;
+    hipLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE>), dim3(grid), dim3(kWaves * 64), 0, st, packed, g, k.L, k.alt, x,
+                       c, row_index, n, out_x, logdet_out, logp_out, part);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+template <bool INVERSE>
+int dispatch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
+                  const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
+                  float *logp_out, float *part, int *grid_out) {
+#define RNVP_CASE(nf, cq)                                                                                   \
+    if (g.NF == nf && g.CQ == cq)                                                                           \
+        return launch_flow<nf, cq, INVERSE>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out, \
+                                            part, grid_out);
+    RNVP_CASE(2, 1) RNVP_CASE(2, 0) RNVP_CASE(4, 2) RNVP_CASE(8, 4)
+#undef RNVP_CASE
+    return RNVP_EUNSUPPORTED;
+}
+
+}  // namespace
+
+bool supported(const KShape &k) {
+    if (!k.alt || k.nh != 1 || k.act != RNVP_ACT_TANH) return false;
+    if (k.nout[0] % 16 != 0 || k.nout[0] < 16) return false;
+    const int NF = k.d / 8, CQ = k.c / 4;
+    if (k.d != 8 * NF || k.c != 4 * CQ) return false;
+    return (NF == 2 && (CQ == 1 || CQ == 0)) || (NF == 4 && CQ == 2) || (NF == 8 && CQ == 4);
+}
+
+size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
+    (void)max_rows;
+    size_t b = packed_bytes(k) + align_up((size_t)kMaxGrid * kWaves * sizeof(float), 256);
+    (void)op;
+    return b;
+}
+
+int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+            const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out,
+            float *logp_sum, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_FORWARD, n)) return RNVP_EWORKSPACE;
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    float *packed = static_cast<float *>(ws);
+    float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + packed_bytes(k));
+    int rc = pack(st, k, g, params, packed);
+    if (rc) return rc;
+    int grid = 0;
+    rc = dispatch_flow<false>(st, k, g, packed, x, c, row_index, n, z_out, logdet_out, logp_out,
+                              logp_sum ? part : nullptr, &grid);
+    if (rc) return rc;
+    if (logp_sum) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, part, grid * kWaves, 1.0f, logp_sum);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
+    return RNVP_OK;
+}
+
+int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c,
+            int64_t n, float *x_out, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    float *packed = static_cast<float *>(ws);
+    int rc = pack(st, k, g, params, packed);
+    if (rc) return rc;
+    int grid = 0;
+    return dispatch_flow<true>(st, k, g, packed, z, c, nullptr, n, x_out, nullptr, nullptr, nullptr, &grid);
+}
+
+int loss_grad(hipStream_t, const KShape &, const float *, const float *, const float *, const int64_t *,
+              int64_t, float, float *, float *, void *, size_t) {
+    return RNVP_EUNSUPPORTED;     // the MFMA backward lands in rnvp_mfma_train.hip
+}
+
+}  // namespace mfma
+}  // namespace rnvp

@@ -84,8 +84,10 @@ class RealNVPLayer(InvertibleLayer):
             C = torch.as_tensor(C, dtype=torch.float32).to(dev).contiguous()
         elif C is not None:
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: layer built with cond_size=0 got C")
-        shape = _hip.RnvpShape.make(1, self.var_size, self.cond_size, self.hidden, self.activation)
-        mask = self.mask.detach().to(dev).to(torch.uint8).contiguous()
+        host_mask = self.mask.detach().to("cpu").to(torch.uint8).reshape(-1)
+        shape = _hip.RnvpShape.make(1, self.var_size, self.cond_size, self.hidden, self.activation,
+                                    alt_masks=_hip.RnvpShape.classify_masks(host_mask.numpy()))
+        mask = host_mask.to(dev).contiguous()
         P = _hip.param_count(shape)
         return dev, X, C, shape, mask, self._layer_params(dev)[:P]
 
@@ -94,14 +96,19 @@ class RealNVPLayer(InvertibleLayer):
         n = X.shape[0]
         X_new = torch.empty_like(X)
         log_det = torch.empty(n, dtype=torch.float32, device=dev)
-        _hip.forward_logprob(shape, params, mask, X, C, None, n, X_new, log_det, None, None, None)
+        _hip.forward_logprob(shape, params, mask, X, C, None, n, X_new, log_det, None, None, self._ws(shape, dev, 0, n))
         return X_new, log_det
 
     def g(self, X, C=None):
         dev, X, C, shape, mask, params = self._prep(X, C)
         X_new = torch.empty_like(X)
-        _hip.inverse(shape, params, mask, X, C, X.shape[0], X_new, None)
+        _hip.inverse(shape, params, mask, X, C, X.shape[0], X_new, self._ws(shape, dev, 1, X.shape[0]))
         return X_new
+
+    @staticmethod
+    def _ws(shape, dev, op, n):
+        nb = _hip.workspace_bytes(shape, op, n)
+        return torch.empty(nb, dtype=torch.uint8, device=dev) if nb > 0 else None
 
 
 class RealNVP(GenModel):

@@ -18,8 +18,9 @@ def _dev(a, dtype=torch.float32):
 def _setup(name):
     from probaforms_amd import _hip
     cs = load_case(name)
-    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
-    assert _hip.param_count(shape) == cs["params"].size
+    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"],
+                                alt_masks=_hip.RnvpShape.classify_masks(cs["masks"]))
+    assert shape.alt_masks == 1 and _hip.param_count(shape) == cs["params"].size
     return _hip, cs, shape, _dev(cs["params"]), _dev(cs["masks"], torch.uint8)
 
 
@@ -58,19 +59,21 @@ def test_single_layer_f_and_g(name, oracle32):
     _hip, cs, shape, params, masks = _setup(name)
     g = cs["gold"]
     n, d = cs["X"].shape
-    one = _hip.RnvpShape.make(1, cs["d"], cs["c"], cs["hidden"], cs["act"])
     npl = cs["params"].size // cs["L"]
     c = _dev(cs["C"])
     for l in range(cs["L"]):
+        one = _hip.RnvpShape.make(1, cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=1 + (l & 1))
         xin = _dev(cs["X"] if l == 0 else g["G2_layer_out"][l - 1])
         y = torch.empty(n, d, device="cuda"); ld = torch.empty(n, device="cuda")
-        _hip.forward_logprob(one, params[l * npl:(l + 1) * npl], masks[l], xin, c, None, n, y, ld, None, None, None)
+        _hip.forward_logprob(one, params[l * npl:(l + 1) * npl], masks[l], xin, c, None, n, y, ld, None, None,
+                             _ws(_hip, one, _hip.OP_FORWARD, n))
         np.testing.assert_allclose(y.cpu().numpy(), g["G2_layer_out"][l], rtol=2e-6, atol=2e-6)
         np.testing.assert_allclose(ld.cpu().numpy(), g["G2_layer_ld"][l], rtol=2e-6, atol=2e-6)
     for k, l in enumerate(range(cs["L"] - 1, -1, -1)):
+        one = _hip.RnvpShape.make(1, cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=1 + (l & 1))
         zin = _dev(cs["Z"] if k == 0 else g["G3_layer_out"][k - 1])
         y = torch.empty(n, d, device="cuda")
-        _hip.inverse(one, params[l * npl:(l + 1) * npl], masks[l], zin, c, n, y, None)
+        _hip.inverse(one, params[l * npl:(l + 1) * npl], masks[l], zin, c, n, y, _ws(_hip, one, _hip.OP_INVERSE, n))
         np.testing.assert_allclose(y.cpu().numpy(), g["G3_layer_out"][k], rtol=2e-6, atol=2e-6)
 
 
@@ -80,12 +83,13 @@ def test_inverse_and_roundtrip(name):
     n, d = cs["Z"].shape
     zt, c = _dev(cs["Z"]), _dev(cs["C"])
     x = torch.empty(n, d, device="cuda")
-    _hip.inverse(shape, params, masks, zt, c, n, x, None)
+    wsi = _ws(_hip, shape, _hip.OP_INVERSE, n)
+    _hip.inverse(shape, params, masks, zt, c, n, x, wsi)
     np.testing.assert_allclose(x.cpu().numpy(), cs["gold"]["G3_x"], rtol=1e-5, atol=2e-5)
     # encode -> decode round trip, in place (x_out may alias z)
     xx = _dev(cs["X"]); z = torch.empty(n, d, device="cuda")
-    _hip.forward_logprob(shape, params, masks, xx, c, None, n, z, None, None, None, None)
-    _hip.inverse(shape, params, masks, z, c, n, z, None)
+    _hip.forward_logprob(shape, params, masks, xx, c, None, n, z, None, None, None, _ws(_hip, shape, _hip.OP_FORWARD, n))
+    _hip.inverse(shape, params, masks, z, c, n, z, wsi)
     assert (z - xx).abs().max().item() < max(2e-5, 10 * float(cs["gold"]["G3_roundtrip_maxerr"]))
 
 
@@ -184,7 +188,7 @@ def test_large_batch_properties():
     from probaforms_amd import _hip
     from cases import numpy_params
     L, d, c, hidden, act, _ = CASES["c2"]
-    shape = _hip.RnvpShape.make(L, d, c, hidden, act)
+    shape = _hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=1)
     params = _dev(numpy_params("c2")); masks = _dev(load_case("c2")["masks"], torch.uint8)
     n = 200_003                                                    # ragged on purpose
     gen = torch.Generator(device="cuda").manual_seed(0)
@@ -196,5 +200,5 @@ def test_large_batch_properties():
     assert (lp - ident).abs().max().item() < 2e-4
     assert abs(tot.item() - lp.double().sum().item()) < 1e-5 * abs(lp.double().sum().item())
     back = torch.empty_like(x)
-    _hip.inverse(shape, params, masks, z, cc, n, back, None)
+    _hip.inverse(shape, params, masks, z, cc, n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
     assert (back - x).abs().max().item() < 5e-4 and (back - x).abs().mean().item() < 2e-6
