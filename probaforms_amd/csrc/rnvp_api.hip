@@ -43,18 +43,15 @@ int rnvp_kernel_path(const rnvp_shape *shape, const uint8_t *host_masks, int op)
             for (int j = 0; j < k.d; ++j)
                 if (host_masks[(size_t)l * k.d + j] != (uint8_t)((j + l + k.alt - 1) & 1)) return RNVP_EINVAL;
     }
-    if (mfma::supported(k) && op != RNVP_OP_TRAIN) return RNVP_PATH_MFMA;
-    return RNVP_PATH_GENERIC;
+    if (op == RNVP_OP_TRAIN) return mfma::train_supported(k) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
+    return mfma::supported(k) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
 }
 
 size_t rnvp_workspace_bytes(const rnvp_shape *shape, int op, int64_t max_rows) {
     KShape k;
     if (make_kshape(shape, &k) != RNVP_OK) return 0;
-    size_t b = generic_workspace_bytes(k, op, max_rows);
-    if (mfma::supported(k)) {
-        const size_t m = mfma::workspace_bytes(k, op, max_rows);
-        if (m > b) b = m;
-    }
+    const bool use_mfma = (op == RNVP_OP_TRAIN) ? mfma::train_supported(k) : mfma::supported(k);
+    const size_t b = use_mfma ? mfma::workspace_bytes(k, op, max_rows) : generic_workspace_bytes(k, op, max_rows);
     return b + 256;
 }
 
@@ -110,7 +107,11 @@ int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, c
         if (loss_out) RNVP_HIP_TRY(hipMemsetAsync(loss_out, 0, sizeof(float), st));
         return RNVP_OK;
     }
-    if (bad_ptrs(k, params, masks, x, c) || !masks) return RNVP_EINVAL;
+    if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
+    if (mfma::train_supported(k))
+        return mfma::loss_grad(st, k, params, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
+                               workspace_bytes);
+    if (!masks) return RNVP_EINVAL;
     return generic_loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out,
                              workspace, workspace_bytes);
 }

@@ -67,7 +67,10 @@ __host__ __device__ inline Geo make_geo(int d, int c, int h) {
 __host__ __device__ inline int feat_cond(int NF, int q, int f, int pc) { return q * 2 * NF + 2 * f + pc; }
 __host__ __device__ inline int feat_trans(int NF, int q, int f, int pc) { return q * 2 * NF + 2 * f + 1 - pc; }
 
-bool supported(const KShape &k);
+bool supported(const KShape &k);            // forward / inverse
+bool train_supported(const KShape &k);      // fused forward + backward
+size_t train_workspace_bytes(const KShape &k, int64_t max_rows);
+int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed);
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows);
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
             const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out,

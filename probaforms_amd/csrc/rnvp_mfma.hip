@@ -294,14 +294,6 @@ size_t packed_bytes(const KShape &k) {
     return align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);
 }
 
-int pack(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed) {
-    const int64_t total = (int64_t)g.layer_floats * k.L;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, st, k, g, params, packed);
-    RNVP_HIP_TRY(hipGetLastError());
-    return RNVP_OK;
-}
 
 template <int NF, int CQ, bool INVERSE>
 int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
@@ -333,6 +325,15 @@ int dispatch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pa
 
 }  // namespace
 
+int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed) {
+    const int64_t total = (int64_t)g.layer_floats * k.L;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, st, k, g, params, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
 bool supported(const KShape &k) {
     if (!k.alt || k.nh != 1 || k.act != RNVP_ACT_TANH) return false;
     if (k.nout[0] % 16 != 0 || k.nout[0] < 16) return false;
@@ -342,10 +343,8 @@ bool supported(const KShape &k) {
 }
 
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
-    (void)max_rows;
-    size_t b = packed_bytes(k) + align_up((size_t)kMaxGrid * kWaves * sizeof(float), 256);
-    (void)op;
-    return b;
+    if (op == RNVP_OP_TRAIN) return train_workspace_bytes(k, max_rows);
+    return packed_bytes(k) + align_up((size_t)kMaxGrid * kWaves * sizeof(float), 256);
 }
 
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
@@ -355,7 +354,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     float *packed = static_cast<float *>(ws);
     float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + packed_bytes(k));
-    int rc = pack(st, k, g, params, packed);
+    int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
     int grid = 0;
     rc = dispatch_flow<false>(st, k, g, packed, x, c, row_index, n, z_out, logdet_out, logp_out,
@@ -373,15 +372,10 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const float *z
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     float *packed = static_cast<float *>(ws);
-    int rc = pack(st, k, g, params, packed);
+    int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
     int grid = 0;
     return dispatch_flow<true>(st, k, g, packed, z, c, nullptr, n, x_out, nullptr, nullptr, nullptr, &grid);
-}
-
-int loss_grad(hipStream_t, const KShape &, const float *, const float *, const float *, const int64_t *,
-              int64_t, float, float *, float *, void *, size_t) {
-    return RNVP_EUNSUPPORTED;     // the MFMA backward lands in rnvp_mfma_train.hip
 }
 
 }  // namespace mfma

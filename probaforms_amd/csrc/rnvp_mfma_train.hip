@@ -1,0 +1,629 @@
+// rnvp_mfma_train.hip -- fused forward + backward of the RealNVP coupling stack on f32 MFMA
+// (gfx950).  Replaces `loss = -nf.log_prob(X, C); loss.backward()`
+// (/root/reference/probaforms/models/realnvp.py:246-250; the backward the reference gets from
+// autograd is hand-derived in SURVEY.md 3.3).  Geometry: rnvp_mfma.h.
+//
+// Per wave: R tiles of 16 rows stay in registers for the whole step.
+//   forward  : as rnvp_mfma.hip, additionally spilling, per layer, the pre-transform value of the
+//              transformed features and exp(s) to a wave-private scratch (2*NF floats per lane).
+//   backward : per layer, per hidden tile (16 units of one net):
+//       GEMM1 recompute -> h = tanh(.)                       [hid x rows]   (accumulator layout)
+//       g_h   = W2^T . g_out          (B operand = g_out registers, k order permuted)
+//       g_pre = g_h * (1 - h^2)
+//       g_in += W1^T . g_pre          (accumulates over all hidden tiles; lands on the lanes that
+//                                      keep the conditioning features)
+//       dW2  += h . g_out^T,  dW1|db1 += g_pre . [in | 1]^T   (contraction over ROWS: h and g_pre
+//                                      are transposed through a wave-private LDS tile; the ones
+//                                      column makes db1 a by-product of the same MFMA)
+//     The weight-gradient accumulators live in registers across the wave's R row tiles, are then
+//     added into one of two LDS slots (waves 0,1 -> slot 0; waves 2,3 -> slot 1: two adds onto
+//     zero commute, so the result is order independent), and after each (layer, net) the
+//     workgroup stores slot0 + slot1 into its private partial in global memory.  A second kernel
+//     sums the partials over workgroups in a fixed order and scatters them into the reference's
+//     flat parameter order.  No float atomics reach global memory: results are deterministic.
+#include <atomic>
+
+#include "rnvp_mfma.h"
+
+namespace rnvp {
+namespace mfma {
+namespace {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kWaves = 4;
+constexpr int kMaxGridTrain = 512;
+constexpr int kTS = 20;                  // row stride (floats) of a 16-wide transposition tile
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return fmaf(-2.0f, r, 1.0f);
+}
+
+// LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, so only the
+// compiler has to be kept from reordering the accesses.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// accumulator-layout tile (lane (q, r): features 4q..4q+3 of row r)  ->  k-step operands for a
+// contraction over rows (lane (qk, j): feature j of rows 4*ks + qk, ks = 0..3)
+__device__ __forceinline__ void transpose16(float *buf, f4 v, int lane, float (&o)[4]) {
+    const int q = lane >> 4, r = lane & 15;
+    wave_lds_fence();
+    *reinterpret_cast<f4 *>(buf + r * kTS + 4 * q) = v;
+    wave_lds_fence();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o[ks] = buf[(4 * ks + q) * kTS + r];
+}
+
+template <int NF, int CQ> struct Dims {
+    static constexpr int KS1 = NF + CQ;
+    static constexpr int K4 = (KS1 + 3) / 4;
+    static constexpr int OTL = NF >= 4 ? NF / 4 : 1;
+    static constexpr int NT2 = NF >= 4 ? 2 * OTL : 1;
+    static constexpr int KP4 = (KS1 + 1 + 3) / 4;     // f4 groups of [inputs | 1 | pad] per lane
+    static constexpr int NTI = KP4;                   // N tiles of the W1 gradient
+    static constexpr int MTI = OTL;                   // M tiles of the input gradient
+    static constexpr int KSP = 4 * KP4;               // input columns per lane group
+    static constexpr int SIN = 16 * NTI + 4;          // row stride of the input transposition tile
+    static constexpr int TB = NT2 * 16 * kTS + 16 * SIN + 2 * 16 * kTS;   // floats of LDS scratch per wave
+};
+
+// B operand of GEMM1 for k-step kk (compile-time kk)
+template <int NF, int CQ, int PC, int R>
+__device__ __forceinline__ float in_op(const float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                       int rt, int kk) {
+    return (kk < NF) ? xr[rt][2 * (kk < NF ? kk : 0) + PC] : cr[rt][kk >= NF ? kk - NF : 0];
+}
+
+// ---- forward of one layer, saving what the backward needs ---------------------------------------
+template <int NF, int CQ, int R, int PC>
+__device__ __forceinline__ void layer_fwd_save(const float *__restrict__ W, const Geo &g, int lane,
+                                               float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                               float (&ld)[R], float *__restrict__ scr) {
+    using D = Dims<NF, CQ>;
+    constexpr int KS1 = D::KS1, K4 = D::K4, OTL = D::OTL, NT2 = D::NT2;
+    const int q = lane >> 4;
+    f4 out[R][NT2];
+#pragma unroll
+    for (int ot = 0; ot < NT2; ++ot) {
+        const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
+    }
+    const int HT = g.HT;
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
+        const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
+        const float *pA2 = W + g.oA2 + ((size_t)net * HT * OTL * 64 + lane) * 4;
+        f4 a1[K4], a2[OTL], b1;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
+        b1 = *reinterpret_cast<const f4 *>(pB1);
+#pragma unroll
+        for (int o = 0; o < OTL; ++o) a2[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
+        for (int ht = 0; ht < HT; ++ht) {
+            const int nx = (ht + 1 < HT) ? ht + 1 : ht;
+            f4 na1[K4], na2[OTL], nb1;
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4)
+                na1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)nx * K4 + k4) * 256);
+            nb1 = *reinterpret_cast<const f4 *>(pB1 + nx * 16);
+#pragma unroll
+            for (int o = 0; o < OTL; ++o)
+                na2[o] = *reinterpret_cast<const f4 *>(pA2 + ((size_t)nx * OTL + o) * 256);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                f4 acc = b1;
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk)
+                    acc = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc);
+                f4 hv;
+                hv[0] = fast_tanh(acc[0]); hv[1] = fast_tanh(acc[1]);
+                hv[2] = fast_tanh(acc[2]); hv[3] = fast_tanh(acc[3]);
+#pragma unroll
+                for (int o = 0; o < OTL; ++o) {
+                    const int ot = (NF >= 4) ? net * OTL + o : 0;
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho) out[rt][ot] = mfma16(a2[o][rho], hv[rho], out[rt][ot]);
+                }
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
+            b1 = nb1;
+#pragma unroll
+            for (int o = 0; o < OTL; ++o) a2[o] = na2[o];
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float tv, sv;
+            if (NF >= 4) { tv = out[rt][f >> 2][f & 3]; sv = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
+            else { tv = out[rt][0][f & 1]; sv = out[rt][0][2 + (f & 1)]; }
+            const int e = 2 * f + 1 - PC;
+            const float es = expf(sv), xv = xr[rt][e];
+            scr[((rt * 2 * NF) + f) * 64 + lane] = xv;             // layer input (transformed features)
+            scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;        // exp(s)
+            xr[rt][e] = fmaf(xv, es, tv);
+            ld[rt] += sv;
+        }
+    }
+}
+
+// ---- backward of one layer ---------------------------------------------------------------------------
+template <int NF, int CQ, int R, int PC>
+__device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
+                                          float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                          float (&gy)[R][2 * NF], const float (&gld)[R],
+                                          const float *__restrict__ scr, float *lds, float *tb,
+                                          float *gp_layer, bool first) {
+    using D = Dims<NF, CQ>;
+    constexpr int KS1 = D::KS1, K4 = D::K4, OTL = D::OTL, NT2 = D::NT2, KP4 = D::KP4, NTI = D::NTI,
+                  MTI = D::MTI, KSP = D::KSP, SIN = D::SIN;
+    const int q = lane >> 4, r = lane & 15, tid = wave * 64 + lane;
+    const int HT = g.HT;
+    const int netblock = HT * (NTI + OTL) * 256;          // floats of one net's gradient block
+    const int slot_floats = netblock + NT2 * 16;
+    float *slot = lds + (wave >> 1) * slot_floats;
+    float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging)
+    float *bufI = tb + NT2 * 16 * kTS;                    // 16 x SIN
+    float *bufH = bufI + 16 * SIN;                        // 16 x kTS
+    float *bufP = bufH + 16 * kTS;                        // 16 x kTS
+
+    // 1. restore the layer input, form g_out = [g_t | g_s] and the gradient of the pass-through part
+    f4 go[R][NT2];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float sx = scr[((rt * 2 * NF) + f) * 64 + lane];
+            const float se = scr[((rt * 2 * NF) + NF + f) * 64 + lane];
+            const int e = 2 * f + 1 - PC;
+            const float gyv = gy[rt][e];
+            const float gt = gyv;                                  // (1-m) * gy
+            const float gs = fmaf(gyv * sx, se, gld[rt]);          // (1-m) * (gy * x * e^s + gld)
+            gy[rt][e] = gyv * se;                                  // gy * (1-m) * e^s
+            xr[rt][e] = sx;
+            if (NF >= 4) { go[rt][f >> 2][f & 3] = gt; go[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3] = gs; }
+            else { go[rt][0][f & 1] = gt; go[rt][0][2 + (f & 1)] = gs; }
+        }
+    }
+    f4 gb2[NT2];
+#pragma unroll
+    for (int ot = 0; ot < NT2; ++ot) {
+        gb2[ot] = go[0][ot];
+#pragma unroll
+        for (int rt = 1; rt < R; ++rt) gb2[ot] += go[rt][ot];
+    }
+    // 2. row-contraction operands: g_out^T and [in | 1]^T through the wave's LDS tiles
+    float goT[R][NT2][4], inT[R][NTI][4];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int ot = 0; ot < NT2; ++ot) transpose16(bufG + ot * 16 * kTS, go[rt][ot], lane, goT[rt][ot]);
+        wave_lds_fence();
+#pragma unroll
+        for (int k4 = 0; k4 < KP4; ++k4) {
+            f4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = 4 * k4 + u;
+                v[u] = (kk < KS1) ? in_op<NF, CQ, PC, R>(xr, cr, rt, kk < KS1 ? kk : 0)
+                                  : (kk == KS1 ? (q == 0 ? 1.0f : 0.0f) : 0.0f);
+            }
+            *reinterpret_cast<f4 *>(bufI + r * SIN + q * KSP + 4 * k4) = v;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int nt = 0; nt < NTI; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) inT[rt][nt][ks] = bufI[(4 * ks + q) * SIN + 16 * nt + r];
+    }
+    f4 gin[R][MTI];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt) gin[rt][mt] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // 3. the two nets, hidden tile by hidden tile
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
+        const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
+        const float *pA2T = W + g.oA2T + ((size_t)net * HT * OTL * 64 + lane) * 4;
+        const float *pA1T = W + g.oA1T + ((size_t)net * HT * MTI * 64 + lane) * 4;
+        f4 a1[K4], a2t[OTL], a1t[MTI], b1;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
+        b1 = *reinterpret_cast<const f4 *>(pB1);
+#pragma unroll
+        for (int o = 0; o < OTL; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + o * 256);
+#pragma unroll
+        for (int m = 0; m < MTI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + m * 256);
+        for (int ht = 0; ht < HT; ++ht) {
+            const int nx = (ht + 1 < HT) ? ht + 1 : ht;
+            f4 na1[K4], na2t[OTL], na1t[MTI], nb1;
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4)
+                na1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)nx * K4 + k4) * 256);
+            nb1 = *reinterpret_cast<const f4 *>(pB1 + nx * 16);
+#pragma unroll
+            for (int o = 0; o < OTL; ++o)
+                na2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)nx * OTL + o) * 256);
+#pragma unroll
+            for (int m = 0; m < MTI; ++m)
+                na1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)nx * MTI + m) * 256);
+
+            f4 gW2[OTL], gW1[NTI];
+#pragma unroll
+            for (int o = 0; o < OTL; ++o) gW2[o] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) gW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                f4 acc = b1;
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk)
+                    acc = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc);
+                f4 hv;
+                hv[0] = fast_tanh(acc[0]); hv[1] = fast_tanh(acc[1]);
+                hv[2] = fast_tanh(acc[2]); hv[3] = fast_tanh(acc[3]);
+                f4 gh = f4{0.f, 0.f, 0.f, 0.f};
+                if (NF >= 4) {
+#pragma unroll
+                    for (int o = 0; o < OTL; ++o)
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho)
+                            gh = mfma16(a2t[o][rho], go[rt][(NF >= 4 ? net * OTL : 0) + o][rho], gh);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) gh = mfma16(a2t[0][2 * net + u], go[rt][0][2 * net + u], gh);
+                }
+                f4 gpv;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gpv[u] = gh[u] * fmaf(-hv[u], hv[u], 1.0f);     // tanh'
+#pragma unroll
+                for (int m = 0; m < MTI; ++m)
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho) gin[rt][m] = mfma16(a1t[m][rho], gpv[rho], gin[rt][m]);
+                float hT[4], pT[4];
+                transpose16(bufH, hv, lane, hT);
+                transpose16(bufP, gpv, lane, pT);
+#pragma unroll
+                for (int o = 0; o < OTL; ++o) {
+                    const int ot = (NF >= 4) ? net * OTL + o : 0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) gW2[o] = mfma16(hT[ks], goT[rt][ot][ks], gW2[o]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTI; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) gW1[nt] = mfma16(pT[ks], inT[rt][nt][ks], gW1[nt]);
+            }
+            // this wave's share of dW1|db1 and dW2 for hidden tile ht -> LDS slot
+            float *sb = slot + (size_t)ht * (NTI + OTL) * 256 + lane * 4;
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) atomicAdd(sb + nt * 256 + u, gW1[nt][u]);
+#pragma unroll
+            for (int o = 0; o < OTL; ++o)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) atomicAdd(sb + (NTI + o) * 256 + u, gW2[o][u]);
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
+            b1 = nb1;
+#pragma unroll
+            for (int o = 0; o < OTL; ++o) a2t[o] = na2t[o];
+#pragma unroll
+            for (int m = 0; m < MTI; ++m) a1t[m] = na1t[m];
+        }
+        if (net == 1) {
+            // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 then hold (q, reg) sums
+#pragma unroll
+            for (int ot = 0; ot < NT2; ++ot)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v = gb2[ot][u];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    if (r == 0) atomicAdd(slot + netblock + (ot * 4 + q) * 4 + u, v);
+                }
+        }
+        __syncthreads();
+        {   // slot0 + slot1 -> the workgroup's partial in global memory; clear the slots
+            const int nfl = netblock + (net == 1 ? NT2 * 16 : 0);
+            float *dst = gp_layer + (size_t)net * netblock;
+            for (int i = tid; i < nfl; i += kWaves * 64) {
+                const float v = lds[i] + lds[slot_floats + i];
+                float *p = (i < netblock) ? dst + i : gp_layer + 2 * (size_t)netblock + (i - netblock);
+                *p = first ? v : *p + v;
+                lds[i] = 0.f; lds[slot_floats + i] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    // 4. gradient reaching the conditioning features through the nets
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float gi = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
+            gy[rt][2 * f + PC] += gi;
+        }
+}
+
+template <int NF, int CQ, int R>
+__global__ void __launch_bounds__(kWaves * 64)
+k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
+             float *gpart, float *losspart, float *scratch, int glayer_floats) {
+    using DM = Dims<NF, CQ>;
+    constexpr int D = 8 * NF, CD = 4 * CQ;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
+    const int slot_floats = netblock + DM::NT2 * 16;
+    float *tb = lds + 2 * slot_floats + wave * DM::TB;
+    for (int i = threadIdx.x; i < 2 * slot_floats; i += kWaves * 64) lds[i] = 0.f;
+    __syncthreads();
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const float prior_c = 0.5f * (float)D * kLog2Pi;
+    float *gp = gpart + (size_t)blockIdx.x * glayer_floats * L;
+    float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + wave) * L * R * 2 * NF * 64;
+    float wave_sum = 0.f;
+    bool first = true;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
+        float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R], gy[R][2 * NF], gld[R];
+        bool valid[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const int64_t row = base + rt * 16 + r;
+            valid[rt] = row < n;
+            const int64_t src = valid[rt] ? (row_index ? row_index[row] : row) : 0;
+            const float *xp = x + src * D + q * 2 * NF;
+#pragma unroll
+            for (int v = 0; v < 2 * NF; v += 4) {
+                const f4 t = *reinterpret_cast<const f4 *>(xp + v);
+                xr[rt][v] = t[0]; xr[rt][v + 1] = t[1]; xr[rt][v + 2] = t[2]; xr[rt][v + 3] = t[3];
+            }
+            if (CQ > 0) {
+                const float *cp = c + src * CD + q * CQ;
+#pragma unroll
+                for (int v = 0; v < CQ; ++v) cr[rt][v] = cp[v];
+            } else {
+                cr[rt][0] = 0.f;
+            }
+            ld[rt] = 0.f;
+        }
+        for (int l = 0; l < L; ++l) {
+            const float *W = wp + (size_t)l * g.layer_floats;
+            float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
+            if ((l + alt) & 1) layer_fwd_save<NF, CQ, R, 1>(W, g, lane, xr, cr, ld, scr);
+            else layer_fwd_save<NF, CQ, R, 0>(W, g, lane, xr, cr, ld, scr);
+        }
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            float ss = 0.f;
+#pragma unroll
+            for (int v = 0; v < 2 * NF; ++v) ss = fmaf(xr[rt][v], xr[rt][v], ss);
+            float l1 = ld[rt];
+            l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+            const float lp = l1 + (-0.5f * ss - prior_c);
+            float v = (valid[rt] && q == 0) ? lp : 0.f;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            wave_sum += v;
+            // seed of the backward: d(-mean logp)/dz = z / B; padding rows contribute nothing
+            const float sc = valid[rt] ? inv_B : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
+            gld[rt] = -sc;
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            const float *W = wp + (size_t)l * g.layer_floats;
+            const float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
+            float *gpl = gp + (size_t)l * glayer_floats;
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first);
+            else layer_bwd<NF, CQ, R, 0>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first);
+        }
+        first = false;
+    }
+    if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
+}
+
+// ---- partial sums over workgroups -> flat reference-order gradient ----------------------------------
+// One thread per flat parameter; finds where the packed gradient keeps it (or that the masks make
+// it dead: exactly zero, as in the reference) and sums the workgroup partials in index order.
+__global__ void __launch_bounds__(256)
+k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restrict__ gpart,
+              const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss) {
+    const size_t P = (size_t)2 * k.npn * k.L;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == P) {
+        if (loss) {
+            float a = 0.f;
+            for (int i = 0; i < G * kWaves; ++i) a += losspart[i];
+            loss[0] = -a * inv_B;
+        }
+        return;
+    }
+    if (p > P) return;
+    const int l = (int)(p / (2 * (size_t)k.npn));
+    int idx = (int)(p - (size_t)l * 2 * k.npn);
+    const int net = idx >= k.npn;
+    idx -= net * k.npn;
+    const int pc = (l + k.alt) & 1;
+    const int NF = g.NF, CQ = g.CQ, HT = g.HT, OTL = g.OTL, h = k.nout[0], nin = k.d + k.c;
+    const int KSP = 4 * NTI;
+    const int netblock = HT * (NTI + OTL) * 256;
+    int loc = -1;
+    if (idx < k.boff[0]) {                                     // W1 [h][d + c]
+        const int hid = idx / nin, col = idx - hid * nin;
+        int jn = -1;
+        if (col < k.d) {
+            const int qq = col / (2 * NF), e = col % (2 * NF);
+            if ((e & 1) == pc) jn = qq * KSP + (e >> 1);
+        } else {
+            const int ci = col - k.d;
+            jn = (ci / CQ) * KSP + NF + (ci % CQ);
+        }
+        if (jn >= 0) {
+            const int i = hid & 15;
+            loc = net * netblock + ((hid >> 4) * (NTI + OTL) + (jn >> 4)) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
+        }
+    } else if (idx < k.woff[1]) {                              // b1 [h]: the ones column
+        const int hid = idx - k.boff[0], i = hid & 15, jn = NF + CQ;
+        loc = net * netblock + ((hid >> 4) * (NTI + OTL) + (jn >> 4)) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
+    } else if (idx < k.boff[1]) {                              // W2 [d][h]
+        const int j = (idx - k.woff[1]) / h, hid = (idx - k.woff[1]) - j * h;
+        const int qo = j / (2 * NF), e = j % (2 * NF);
+        if ((e & 1) == 1 - pc) {
+            const int f = e >> 1;
+            int otl, io;
+            if (NF >= 4) { otl = f >> 2; io = 4 * qo + (f & 3); }
+            else { otl = 0; io = 4 * qo + 2 * net + f; }
+            const int i = hid & 15;
+            loc = net * netblock + ((hid >> 4) * (NTI + OTL) + NTI + otl) * 256 + (16 * (i >> 2) + io) * 4 + (i & 3);
+        }
+    } else {                                                   // b2 [d]
+        const int j = idx - k.boff[1];
+        const int qo = j / (2 * NF), e = j % (2 * NF);
+        if ((e & 1) == 1 - pc) {
+            const int f = e >> 1;
+            int ot, reg;
+            if (NF >= 4) { ot = net * OTL + (f >> 2); reg = f & 3; }
+            else { ot = 0; reg = 2 * net + f; }
+            loc = 2 * netblock + (ot * 4 + qo) * 4 + reg;
+        }
+    }
+    float a = 0.f;
+    if (loc >= 0) {
+        const float *src = gpart + (size_t)l * glayer_floats + loc;
+        const size_t stride = (size_t)glayer_floats * k.L;
+        for (int b = 0; b < G; ++b) a += src[(size_t)b * stride];
+    }
+    grad[p] = a;
+}
+
+template <int NF, int CQ> struct TrainRows { static constexpr int value = NF == 2 ? 4 : (NF == 4 ? 2 : 1); };
+
+struct TrainPlan {
+    int glayer_floats;      // per layer: 2 net blocks + db2
+    size_t lds_bytes;
+    int R;
+    size_t scratch_per_wave;   // floats
+};
+
+template <int NF, int CQ>
+TrainPlan make_plan(const Geo &g, int L) {
+    using DM = Dims<NF, CQ>;
+    TrainPlan p;
+    const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
+    p.glayer_floats = 2 * netblock + DM::NT2 * 16;
+    p.lds_bytes = ((size_t)2 * (netblock + DM::NT2 * 16) + (size_t)kWaves * DM::TB) * sizeof(float);
+    p.R = TrainRows<NF, CQ>::value;
+    p.scratch_per_wave = (size_t)L * p.R * 2 * NF * 64;
+    return p;
+}
+
+bool plan_for(const Geo &g, int L, TrainPlan *p) {
+    if (g.NF == 2 && g.CQ == 1) { *p = make_plan<2, 1>(g, L); return true; }
+    if (g.NF == 2 && g.CQ == 0) { *p = make_plan<2, 0>(g, L); return true; }
+    if (g.NF == 4 && g.CQ == 2) { *p = make_plan<4, 2>(g, L); return true; }
+    if (g.NF == 8 && g.CQ == 4) { *p = make_plan<8, 4>(g, L); return true; }
+    return false;
+}
+
+std::atomic<int> g_lds_ok{0};
+
+template <int NF, int CQ>
+int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+                 const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
+                 float *losspart, float *scratch, int grid) {
+    constexpr int R = TrainRows<NF, CQ>::value;
+    auto kern = k_mfma_train<NF, CQ, R>;
+    static std::atomic<int> attr_done{0};
+    if (!attr_done.load(std::memory_order_relaxed)) {
+        RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.store(1, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), pl.lds_bytes, st, packed, g, k.L, k.alt, x, c, row_index,
+                       n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+}  // namespace
+
+bool train_supported(const KShape &k) {
+    if (!supported(k)) return false;
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    TrainPlan pl;
+    if (!plan_for(g, k.L, &pl)) return false;
+    return pl.lds_bytes <= 160 * 1024;
+}
+
+size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
+    (void)max_rows;
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    TrainPlan pl;
+    if (!plan_for(g, k.L, &pl)) return 0;
+    size_t b = align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);                    // packed weights
+    b += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);          // partials
+    b += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);                          // loss partials
+    b += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);    // saved activations
+    return b;
+}
+
+int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+              const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
+              void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    TrainPlan pl;
+    if (!plan_for(g, k.L, &pl)) return RNVP_EUNSUPPORTED;
+    char *w = static_cast<char *>(ws);
+    float *packed = reinterpret_cast<float *>(w);
+    w += align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);
+    float *gpart = reinterpret_cast<float *>(w);
+    w += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);
+    float *losspart = reinterpret_cast<float *>(w);
+    w += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);
+    float *scratch = reinterpret_cast<float *>(w);
+    int rc = pack_weights(st, k, g, params, packed);
+    if (rc) return rc;
+    const int64_t rows_per_wg = (int64_t)kWaves * pl.R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
+    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
+    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
+    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
+    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
+    else return RNVP_EUNSUPPORTED;
+    if (rc) return rc;
+    const size_t P = (size_t)2 * k.npn * k.L;
+    const unsigned blocks = (unsigned)((P + 1 + 255) / 256);
+    int NTI = (g.KS1 + 1 + 3) / 4;
+    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, gpart, losspart,
+                       grid, inv_B, grad_out, loss_out);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+}  // namespace mfma
+}  // namespace rnvp
