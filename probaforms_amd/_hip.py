@@ -16,7 +16,9 @@ OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PATH_GENERIC, PATH_MFMA = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librnvp_hip.so")
+# RNVP_HIP_LIB lets a developer A/B an experimental build of the same C ABI (still a HIP library:
+# there is no non-HIP implementation to point it at).
+LIB_PATH = os.environ.get("RNVP_HIP_LIB") or os.path.join(_HERE, "csrc", "librnvp_hip.so")
 
 
 class RnvpShape(C.Structure):

@@ -202,7 +202,7 @@ __device__ __forceinline__ void layer_apply(const float *__restrict__ W, const G
 
 // ---- whole stack: forward (+ log-det + prior) or inverse ---------------------------------------
 template <int NF, int CQ, int R, bool INVERSE>
-__global__ void __launch_bounds__(kWaves * 64)
+__global__ void __launch_bounds__(kWaves * 64, 2)
 k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n,
             float *out_x, float *logdet_out, float *logp_out, float *part) {

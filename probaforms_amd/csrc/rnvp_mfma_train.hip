@@ -16,11 +16,11 @@
 //                                      are transposed through a wave-private LDS tile; the ones
 //                                      column makes db1 a by-product of the same MFMA)
 //     The weight-gradient accumulators live in registers across the wave's R row tiles, are then
-//     added into one of two LDS slots (waves 0,1 -> slot 0; waves 2,3 -> slot 1: two adds onto
-//     zero commute, so the result is order independent), and after each (layer, net) the
-//     workgroup stores slot0 + slot1 into its private partial in global memory.  A second kernel
-//     sums the partials over workgroups in a fixed order and scatters them into the reference's
-//     flat parameter order.  No float atomics reach global memory: results are deterministic.
+//     stored (plain ds_write_b128; LDS float atomics measured ~1 lane/clk on gfx950) into the
+//     wave's own LDS slot, and every FT hidden tiles the workgroup adds the four slots in wave
+//     order into its private partial in global memory.  A second pass sums the partials over
+//     workgroups in a fixed order and scatters them into the reference's flat parameter order.
+//     No float atomics anywhere: results are bitwise reproducible.
 #include <atomic>
 
 #include "rnvp_mfma.h"
@@ -31,6 +31,14 @@ namespace {
 
 using f4 = __attribute__((ext_vector_type(4))) float;
 
+// RNVP_ABLATE: developer-only timing experiments (results are WRONG when set); never defined in the
+// product build.  bit0 no LDS transposes, bit1 no LDS accumulation, bit2 no barrier/global flush,
+// bit3 cheap activation, bit4 forward only, bit5 no weight-gradient MFMAs.
+#ifndef RNVP_ABLATE
+#define RNVP_ABLATE 0
+#endif
+constexpr int kAblate = RNVP_ABLATE;
+
 constexpr int kWaves = 4;
 constexpr int kMaxGridTrain = 512;
 constexpr int kTS = 20;                  // row stride (floats) of a 16-wide transposition tile
@@ -40,6 +48,7 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 }
 
 __device__ __forceinline__ float fast_tanh(float v) {
+    if (kAblate & 8) return v * 0.5f;
     const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
     const float r = __builtin_amdgcn_rcpf(1.0f + e);
     return fmaf(-2.0f, r, 1.0f);
@@ -56,6 +65,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // accumulator-layout tile (lane (q, r): features 4q..4q+3 of row r)  ->  k-step operands for a
 // contraction over rows (lane (qk, j): feature j of rows 4*ks + qk, ks = 0..3)
 __device__ __forceinline__ void transpose16(float *buf, f4 v, int lane, float (&o)[4]) {
+    if (kAblate & 1) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; return; }
     const int q = lane >> 4, r = lane & 15;
     wave_lds_fence();
     *reinterpret_cast<f4 *>(buf + r * kTS + 4 * q) = v;
@@ -75,6 +85,8 @@ template <int NF, int CQ> struct Dims {
     static constexpr int KSP = 4 * KP4;               // input columns per lane group
     static constexpr int SIN = 16 * NTI + 4;          // row stride of the input transposition tile
     static constexpr int TB = NT2 * 16 * kTS + 16 * SIN + 2 * 16 * kTS;   // floats of LDS scratch per wave
+    static constexpr int FT = NF == 8 ? 4 : 8;        // hidden tiles accumulated in LDS between two flushes
+    static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
 };
 
 // B operand of GEMM1 for k-step kk (compile-time kk)
@@ -173,9 +185,9 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                   MTI = D::MTI, KSP = D::KSP, SIN = D::SIN;
     const int q = lane >> 4, r = lane & 15, tid = wave * 64 + lane;
     const int HT = g.HT;
-    const int netblock = HT * (NTI + OTL) * 256;          // floats of one net's gradient block
-    const int slot_floats = netblock + NT2 * 16;
-    float *slot = lds + (wave >> 1) * slot_floats;
+    constexpr int FT = D::FT, SLOT = D::SLOT, TBLK = (NTI + OTL) * 256;
+    const int netblock = HT * TBLK;                       // floats of one net's gradient block
+    float *slot = lds + wave * SLOT;
     float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging)
     float *bufI = tb + NT2 * 16 * kTS;                    // 16 x SIN
     float *bufH = bufI + 16 * SIN;                        // 16 x kTS
@@ -300,6 +312,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 float hT[4], pT[4];
                 transpose16(bufH, hv, lane, hT);
                 transpose16(bufP, gpv, lane, pT);
+                if (!(kAblate & 32)) {
 #pragma unroll
                 for (int o = 0; o < OTL; ++o) {
                     const int ot = (NF >= 4) ? net * OTL + o : 0;
@@ -310,17 +323,56 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 for (int nt = 0; nt < NTI; ++nt)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) gW1[nt] = mfma16(pT[ks], inT[rt][nt][ks], gW1[nt]);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[ks]; gW1[0][ks] += pT[ks]; }
+                }
             }
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> LDS slot
-            float *sb = slot + (size_t)ht * (NTI + OTL) * 256 + lane * 4;
+            // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
+            if (!(kAblate & 2)) {
+                float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
 #pragma unroll
-            for (int nt = 0; nt < NTI; ++nt)
+                for (int nt = 0; nt < NTI; ++nt) *reinterpret_cast<f4 *>(sb + nt * 256) = gW1[nt];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) atomicAdd(sb + nt * 256 + u, gW1[nt][u]);
+                for (int o = 0; o < OTL; ++o) *reinterpret_cast<f4 *>(sb + (NTI + o) * 256) = gW2[o];
+            } else {
 #pragma unroll
-            for (int o = 0; o < OTL; ++o)
+                for (int nt = 0; nt < NTI; ++nt) asm volatile("" ::"v"(gW1[nt]));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) atomicAdd(sb + (NTI + o) * 256 + u, gW2[o][u]);
+                for (int o = 0; o < OTL; ++o) asm volatile("" ::"v"(gW2[o]));
+            }
+            const bool last_tile = (ht + 1 == HT);
+            if (((ht + 1) % FT == 0 || last_tile) && !(kAblate & 4)) {
+                if (last_tile && net == 1) {
+                    // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
+#pragma unroll
+                    for (int ot = 0; ot < NT2; ++ot)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            float v = gb2[ot][u];
+                            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                            if (r == 0) slot[FT * TBLK + (ot * 4 + q) * 4 + u] = v;
+                        }
+                }
+                __syncthreads();
+                {   // slot0 + slot1 + slot2 + slot3 (wave order) -> the workgroup's partial in global memory
+                    const int t0 = (ht / FT) * FT, ntile = ht + 1 - t0;
+                    const int nfl = ntile * TBLK;
+                    float *dst = gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK;
+                    for (int i = tid; i < nfl; i += kWaves * 64) {
+                        const float v = ((lds[i] + lds[SLOT + i]) + lds[2 * SLOT + i]) + lds[3 * SLOT + i];
+                        dst[i] = first ? v : dst[i] + v;
+                    }
+                    if (last_tile && net == 1 && tid < NT2 * 16) {
+                        const int i = FT * TBLK + tid;
+                        const float v = ((lds[i] + lds[SLOT + i]) + lds[2 * SLOT + i]) + lds[3 * SLOT + i];
+                        float *p = gp_layer + 2 * (size_t)netblock + tid;
+                        *p = first ? v : *p + v;
+                    }
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
             b1 = nb1;
@@ -329,29 +381,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
             for (int m = 0; m < MTI; ++m) a1t[m] = na1t[m];
         }
-        if (net == 1) {
-            // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 then hold (q, reg) sums
-#pragma unroll
-            for (int ot = 0; ot < NT2; ++ot)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float v = gb2[ot][u];
-                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                    if (r == 0) atomicAdd(slot + netblock + (ot * 4 + q) * 4 + u, v);
-                }
-        }
-        __syncthreads();
-        {   // slot0 + slot1 -> the workgroup's partial in global memory; clear the slots
-            const int nfl = netblock + (net == 1 ? NT2 * 16 : 0);
-            float *dst = gp_layer + (size_t)net * netblock;
-            for (int i = tid; i < nfl; i += kWaves * 64) {
-                const float v = lds[i] + lds[slot_floats + i];
-                float *p = (i < netblock) ? dst + i : gp_layer + 2 * (size_t)netblock + (i - netblock);
-                *p = first ? v : *p + v;
-                lds[i] = 0.f; lds[slot_floats + i] = 0.f;
-            }
-        }
-        __syncthreads();
     }
     // 4. gradient reaching the conditioning features through the nets
 #pragma unroll
@@ -364,7 +393,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 }
 
 template <int NF, int CQ, int R>
-__global__ void __launch_bounds__(kWaves * 64)
+__global__ void __launch_bounds__(kWaves * 64, 2)
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats) {
@@ -373,11 +402,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, r = lane & 15;
-    const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
-    const int slot_floats = netblock + DM::NT2 * 16;
-    float *tb = lds + 2 * slot_floats + wave * DM::TB;
-    for (int i = threadIdx.x; i < 2 * slot_floats; i += kWaves * 64) lds[i] = 0.f;
-    __syncthreads();
+    float *tb = lds + kWaves * DM::SLOT + wave * DM::TB;
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)D * kLog2Pi;
@@ -433,7 +458,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
             gld[rt] = -sc;
         }
-        for (int l = L - 1; l >= 0; --l) {
+        for (int l = L - 1; l >= 0 && !(kAblate & 16); --l) {
             const float *W = wp + (size_t)l * g.layer_floats;
             const float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             float *gpl = gp + (size_t)l * glayer_floats;
@@ -445,7 +470,20 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
 }
 
-// ---- partial sums over workgroups -> flat reference-order gradient ----------------------------------
+// ---- partial sums over workgroups, stage 1: coalesced, float4, G partials -> kSeg segment sums -------
+constexpr int kSeg = 16;
+
+__global__ void __launch_bounds__(256)
+k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restrict__ seg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sgi = blockIdx.y;
+    if (i >= n4) return;
+    f4 a = f4{0.f, 0.f, 0.f, 0.f};
+    for (int b = sgi; b < G; b += kSeg) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
+    reinterpret_cast<f4 *>(seg)[(size_t)sgi * n4 + i] = a;
+}
+
+// ---- stage 2: segment sums -> flat reference-order gradient -----------------------------------------
 // One thread per flat parameter; finds where the packed gradient keeps it (or that the masks make
 // it dead: exactly zero, as in the reference) and sums the workgroup partials in index order.
 __global__ void __launch_bounds__(256)
@@ -514,7 +552,8 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
     if (loc >= 0) {
         const float *src = gpart + (size_t)l * glayer_floats + loc;
         const size_t stride = (size_t)glayer_floats * k.L;
-        for (int b = 0; b < G; ++b) a += src[(size_t)b * stride];
+        const int S = G < kSeg ? G : kSeg;
+        for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];
     }
     grad[p] = a;
 }
@@ -534,7 +573,7 @@ TrainPlan make_plan(const Geo &g, int L) {
     TrainPlan p;
     const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
     p.glayer_floats = 2 * netblock + DM::NT2 * 16;
-    p.lds_bytes = ((size_t)2 * (netblock + DM::NT2 * 16) + (size_t)kWaves * DM::TB) * sizeof(float);
+    p.lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::TB) * sizeof(float);
     p.R = TrainRows<NF, CQ>::value;
     p.scratch_per_wave = (size_t)L * p.R * 2 * NF * 64;
     return p;
@@ -585,6 +624,7 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
     if (!plan_for(g, k.L, &pl)) return 0;
     size_t b = align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);                    // packed weights
     b += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);          // partials
+    b += align_up((size_t)kSeg * pl.glayer_floats * k.L * sizeof(float), 256);                   // segment sums
     b += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);                          // loss partials
     b += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);    // saved activations
     return b;
@@ -602,6 +642,8 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const float 
     w += align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);
     float *gpart = reinterpret_cast<float *>(w);
     w += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);
+    float *seg = reinterpret_cast<float *>(w);
+    w += align_up((size_t)kSeg * pl.glayer_floats * k.L * sizeof(float), 256);
     float *losspart = reinterpret_cast<float *>(w);
     w += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);
     float *scratch = reinterpret_cast<float *>(w);
@@ -619,7 +661,10 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const float 
     const size_t P = (size_t)2 * k.npn * k.L;
     const unsigned blocks = (unsigned)((P + 1 + 255) / 256);
     int NTI = (g.KS1 + 1 + 3) / 4;
-    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, gpart, losspart,
+    const size_t n4 = (size_t)pl.glayer_floats * k.L / 4;
+    hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), kSeg), dim3(256), 0, st, gpart, grid, n4, seg);
+    RNVP_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, seg, losspart,
                        grid, inv_B, grad_out, loss_out);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
