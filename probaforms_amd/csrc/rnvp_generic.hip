@@ -138,12 +138,14 @@ k_generic_forward(KShape s, const float *__restrict__ params, const uint8_t *__r
     if (part && t == 0) part[blockIdx.x] = block_sum;
 }
 
-__global__ void k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f;
-        for (int i = 0; i < G; ++i) a += part[i];
-        out[0] = a * scale;
-    }
+__global__ void __launch_bounds__(64)
+k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
+    // one wave: lane i adds part[i], part[i + 64], ... in order, then a fixed butterfly: deterministic
+    const int lane = threadIdx.x;
+    float a = 0.f;
+    for (int i = lane; i < G; i += 64) a += part[i];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) out[0] = a * scale;
 }
 
 // ---- inverse (realnvp.py:120-129, nflow.py:142-143) ---------------------------------------
@@ -361,10 +363,6 @@ k_reduce_grad(const float *__restrict__ gpart, const float *__restrict__ losspar
         float a = 0.f;
         for (int b = 0; b < G; ++b) a += gpart[(size_t)b * P + p];
         grad[p] = a;
-    } else if (p == P && loss) {
-        float a = 0.f;
-        for (int b = 0; b < G; ++b) a += losspart[b];
-        loss[0] = -a * inv_B;
     }
 }
 
@@ -486,6 +484,10 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
     hipLaunchKernelGGL(k_reduce_grad, dim3(blocks), dim3(rb), 0, st, gpart, losspart, G, P, inv_B, grad_out,
                        loss_out);
     RNVP_HIP_TRY(hipGetLastError());
+    if (loss_out) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, losspart, G, -inv_B, loss_out);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
     return RNVP_OK;
 }
 

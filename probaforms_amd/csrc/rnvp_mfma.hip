@@ -109,12 +109,14 @@ k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restr
     }
 }
 
-__global__ void k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f;
-        for (int i = 0; i < G; ++i) a += part[i];
-        out[0] = a * scale;
-    }
+__global__ void __launch_bounds__(64)
+k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
+    // one wave: lane i adds part[i], part[i + 64], ... in order, then a fixed butterfly: deterministic
+    const int lane = threadIdx.x;
+    float a = 0.f;
+    for (int i = lane; i < G; i += 64) a += part[i];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) out[0] = a * scale;
 }
 
 // ---- one coupling layer for the wave's R row tiles -------------------------------------------------

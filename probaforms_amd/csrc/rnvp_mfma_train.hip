@@ -479,7 +479,7 @@ k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restr
     const int sgi = blockIdx.y;
     if (i >= n4) return;
     f4 a = f4{0.f, 0.f, 0.f, 0.f};
-    for (int b = sgi; b < G; b += kSeg) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
+    for (int b = sgi; b < G; b += gridDim.y) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
     reinterpret_cast<f4 *>(seg)[(size_t)sgi * n4 + i] = a;
 }
 
@@ -491,15 +491,17 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
               const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss) {
     const size_t P = (size_t)2 * k.npn * k.L;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == P) {
-        if (loss) {
+    if (p >= P) {
+        // the last block's first wave reduces the per-wave loss partials (fixed order: deterministic)
+        if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
+            const int lane = threadIdx.x - 192;
             float a = 0.f;
-            for (int i = 0; i < G * kWaves; ++i) a += losspart[i];
-            loss[0] = -a * inv_B;
+            for (int i = lane; i < G * kWaves; i += 64) a += losspart[i];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            if (lane == 0) loss[0] = -a * inv_B;
         }
         return;
     }
-    if (p > P) return;
     const int l = (int)(p / (2 * (size_t)k.npn));
     int idx = (int)(p - (size_t)l * 2 * k.npn);
     const int net = idx >= k.npn;
@@ -552,8 +554,8 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
     if (loc >= 0) {
         const float *src = gpart + (size_t)l * glayer_floats + loc;
         const size_t stride = (size_t)glayer_floats * k.L;
-        const int S = G < kSeg ? G : kSeg;
-        for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];
+        a = src[0];                                  // already summed over workgroups
+        (void)stride;
     }
     grad[p] = a;
 }
@@ -659,12 +661,18 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const float 
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
     const size_t P = (size_t)2 * k.npn * k.L;
-    const unsigned blocks = (unsigned)((P + 1 + 255) / 256);
+    const unsigned blocks = (unsigned)(P / 256 + 2);     // last block's last wave is always past P: it sums the loss
     int NTI = (g.KS1 + 1 + 3) / 4;
     const size_t n4 = (size_t)pl.glayer_floats * k.L / 4;
     hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), kSeg), dim3(256), 0, st, gpart, grid, n4, seg);
     RNVP_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, seg, losspart,
+    RNVP_HIP_TRY(hipGetLastError());
+    // second level: the kSeg segment sums -> one packed gradient (kept in segment 0's place is not
+    // possible in place, so it lands behind the segments' first row: reuse gpart's head, now dead)
+    const int S = grid < kSeg ? grid : kSeg;
+    hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, st, seg, S, n4, gpart);
+    RNVP_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, gpart, losspart,
                        grid, inv_B, grad_out, loss_out);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
