@@ -3,28 +3,21 @@
 // loops of NormalizingFlow.log_prob / .sample (/root/reference/probaforms/models/realnvp.py:
 // 91-101,120-129; nflow.py:107-117,141-145) for d in {16,32,64}, cdim in {0,4,8,16}, one hidden
 // layer with h % 16 == 0, tanh, and the reference's alternating masks.
-#include "rnvp_mfma.h"
+#include "rnvp_mfma_layer.h"
+
+// occupancy the scheduler is told to aim for: exactly RNVP_WPE waves per SIMD, so that it spends
+// the rest of the 512/RNVP_WPE register budget on instruction-level parallelism instead of
+// serialising the tanh / MFMA chains to save registers (measured: see DESIGN.md).
+#ifndef RNVP_WPE
+#define RNVP_WPE 2
+#endif
 
 namespace rnvp {
 namespace mfma {
 namespace {
 
-using f4 = __attribute__((ext_vector_type(4))) float;
-
 constexpr int kWaves = 4;                // waves per workgroup (one per SIMD)
 constexpr int kMaxGrid = 2048;
-
-__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// tanh(v) = 1 - 2 / (1 + e^{2v}): one v_exp_f32 + one v_rcp_f32 (~1 ulp each); saturates
-// correctly through e = +inf / 0; absolute error ~1e-7, the rounding level of values near 1.
-__device__ __forceinline__ float fast_tanh(float v) {
-    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);   // 2 * log2(e)
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    return fmaf(-2.0f, r, 1.0f);
-}
 
 // ---- weight packing ----------------------------------------------------------------------------
 // One thread per float of the packed block; reads the flat reference-order parameters
@@ -119,92 +112,9 @@ k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
     if (lane == 0) out[0] = a * scale;
 }
 
-// ---- one coupling layer for the wave's R row tiles -------------------------------------------------
-template <int NF, int CQ, int R, int PC, bool INVERSE>
-__device__ __forceinline__ void layer_apply(const float *__restrict__ W, const Geo &g, int lane,
-                                            float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
-                                            float (&ld)[R]) {
-    constexpr int KS1 = NF + CQ, K4 = (KS1 + 3) / 4;
-    constexpr int OTL = NF >= 4 ? NF / 4 : 1, NT2 = NF >= 4 ? 2 * OTL : 1;
-    const int q = lane >> 4;
-    f4 out[R][NT2];
-#pragma unroll
-    for (int ot = 0; ot < NT2; ++ot) {
-        const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
-    }
-    const int HT = g.HT;
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
-        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
-        const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
-        const float *pA2 = W + g.oA2 + ((size_t)net * HT * OTL * 64 + lane) * 4;
-        f4 a1[K4], a2[OTL], b1;
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
-        b1 = *reinterpret_cast<const f4 *>(pB1);
-#pragma unroll
-        for (int o = 0; o < OTL; ++o) a2[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
-        for (int ht = 0; ht < HT; ++ht) {
-            // prefetch the next hidden tile's fragments (the last iteration re-reads its own)
-            const int nx = (ht + 1 < HT) ? ht + 1 : ht;
-            f4 na1[K4], na2[OTL], nb1;
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4)
-                na1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)nx * K4 + k4) * 256);
-            nb1 = *reinterpret_cast<const f4 *>(pB1 + nx * 16);
-#pragma unroll
-            for (int o = 0; o < OTL; ++o)
-                na2[o] = *reinterpret_cast<const f4 *>(pA2 + ((size_t)nx * OTL + o) * 256);
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) {
-                f4 acc = b1;
-#pragma unroll
-                for (int kk = 0; kk < KS1; ++kk) {
-                    const float bop = (kk < NF) ? xr[rt][2 * (kk < NF ? kk : 0) + PC] : cr[rt][kk >= NF ? kk - NF : 0];
-                    acc = mfma16(a1[kk >> 2][kk & 3], bop, acc);
-                }
-                f4 hv;
-                hv[0] = fast_tanh(acc[0]); hv[1] = fast_tanh(acc[1]);
-                hv[2] = fast_tanh(acc[2]); hv[3] = fast_tanh(acc[3]);
-#pragma unroll
-                for (int o = 0; o < OTL; ++o) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int ot = (NF >= 4) ? net * OTL + o : 0;
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho) out[rt][ot] = mfma16(a2[o][rho], hv[rho], out[rt][ot]);
-                }
-            }
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
-            b1 = nb1;
-#pragma unroll
-            for (int o = 0; o < OTL; ++o) a2[o] = na2[o];
-        }
-    }
-    // affine update of the transformed features, all per lane
-#pragma unroll
-    for (int rt = 0; rt < R; ++rt) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            float tv, sv;
-            if (NF >= 4) { tv = out[rt][f >> 2][f & 3]; sv = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
-            else { tv = out[rt][0][f & 1]; sv = out[rt][0][2 + (f & 1)]; }
-            const int e = 2 * f + 1 - PC;
-            if (!INVERSE) {
-                xr[rt][e] = fmaf(xr[rt][e], expf(sv), tv);       // x*exp(s) + t   (realnvp.py:99)
-                ld[rt] += sv;                                    // log_det        (realnvp.py:100)
-            } else {
-                xr[rt][e] = (xr[rt][e] - tv) * expf(-sv);        // (x - t)*exp(-s) (realnvp.py:128)
-            }
-        }
-    }
-}
-
 // ---- whole stack: forward (+ log-det + prior) or inverse ---------------------------------------
 template <int NF, int CQ, int R, bool INVERSE>
-__global__ void __launch_bounds__(kWaves * 64, 2)
+__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n,
             float *out_x, float *logdet_out, float *logp_out, float *part) {
@@ -242,8 +152,8 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__
         for (int lp = 0; lp < L; ++lp) {
             const int l = INVERSE ? L - 1 - lp : lp;
             const float *W = wp + (size_t)l * g.layer_floats;
-            if ((l + alt) & 1) layer_apply<NF, CQ, R, 1, INVERSE>(W, g, lane, xr, cr, ld);
-            else layer_apply<NF, CQ, R, 0, INVERSE>(W, g, lane, xr, cr, ld);
+            if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, INVERSE ? 1 : 0>(W, g, lane, xr, cr, ld, nullptr);
+            else layer_forward<NF, CQ, R, 0, INVERSE ? 1 : 0>(W, g, lane, xr, cr, ld, nullptr);
         }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {

@@ -1,0 +1,206 @@
+// rnvp_mfma_layer.h -- one coupling layer of the register-chained MFMA path, forward direction
+// (shared by the forward / inverse kernels and by the forward phase of the training kernel).
+//
+// The hidden-tile loop is software-pipelined BY HAND, because hipcc (ROCm 7.2) otherwise
+// serialises it: left to itself it computes each tanh just in time for the MFMA that consumes it
+// (exp -> add -> rcp -> fma -> mfma on ONE register, ~45 dependent cycles per MFMA) and re-loads
+// the weight fragments at the top of every iteration behind an s_waitcnt vmcnt(0).  Structure of
+// one iteration for hidden tile t (R row tiles per wave):
+//     top    : issue the fragment loads for tile t+2 (GEMM1) and t+1 (GEMM2); their addresses are
+//              made opaque so the optimiser cannot sink the loads into the next iteration
+//     phase A: for each row tile: 3..12 GEMM1 MFMAs of tile t+1  ||  the 4 tanh of tile t (VALU)
+//     phase B: for each row tile: the GEMM2 MFMAs of tile t
+// __builtin_amdgcn_sched_barrier(0) between the blocks pins that order; inside a block the MFMAs
+// issue first and the VALU work runs in their shadow.
+#pragma once
+#include "rnvp_mfma.h"
+
+namespace rnvp {
+namespace mfma {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#ifndef RNVP_ABLATE
+#define RNVP_ABLATE 0
+#endif
+
+// tanh(v) = 1 - 2 / (1 + e^{2v}): one v_exp_f32 + one v_rcp_f32 (~1 ulp each); saturates
+// correctly through e = +inf / 0; absolute error ~1e-7, the rounding level of values near 1.
+__device__ __forceinline__ float fast_tanh(float v) {
+    if (RNVP_ABLATE & 8) return v * 0.5f;
+    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);   // 2 * log2(e)
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return fmaf(-2.0f, r, 1.0f);
+}
+
+__device__ __forceinline__ f4 tanh4(f4 a) {
+    f4 h;
+    h[0] = fast_tanh(a[0]); h[1] = fast_tanh(a[1]); h[2] = fast_tanh(a[2]); h[3] = fast_tanh(a[3]);
+    return h;
+}
+
+// hide a fragment address from the optimiser (it would otherwise prove that next iteration's
+// "current" fragment equals this iteration's prefetch and replace the prefetch by a late re-load)
+typedef const __attribute__((address_space(1))) f4 *gf4_ptr;      // keeps the loads global_load (not flat)
+__device__ __forceinline__ gf4_ptr opaque(const float *p) {
+    asm volatile("" : "+v"(p));
+    return (gf4_ptr)p;
+}
+
+template <int NF, int CQ> struct FwdDims {
+    static constexpr int KS1 = NF + CQ;
+    static constexpr int K4 = (KS1 + 3) / 4;
+    static constexpr int OTL = NF >= 4 ? NF / 4 : 1;
+    static constexpr int NT2 = NF >= 4 ? 2 * OTL : 1;
+};
+
+// B operand of GEMM1 for k-step kk (kk is a compile-time constant after unrolling)
+template <int NF, int CQ, int PC, int R>
+__device__ __forceinline__ float in_op(const float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                       int rt, int kk) {
+    return (kk < NF) ? xr[rt][2 * (kk < NF ? kk : 0) + PC] : cr[rt][kk >= NF ? kk - NF : 0];
+}
+
+template <int NF, int CQ, int PC, int R>
+__device__ __forceinline__ f4 gemm1(const f4 (&a1)[FwdDims<NF, CQ>::K4], f4 b1, const float (&xr)[R][2 * NF],
+                                    const float (&cr)[R][CQ > 0 ? CQ : 1], int rt) {
+    f4 acc = b1;
+#pragma unroll
+    for (int kk = 0; kk < NF + CQ; ++kk)
+        acc = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc);
+    return acc;
+}
+
+// Tiles [tile0, tile0 + ntiles) of the packed layer feed out tiles OT0 .. OT0 + OTL - 1.
+template <int NF, int CQ, int R, int PC, int OT0>
+__device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo &g, int lane, int tile0,
+                                          int ntiles, const float (&xr)[R][2 * NF],
+                                          const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                          f4 (&out)[R][FwdDims<NF, CQ>::NT2]) {
+    using D = FwdDims<NF, CQ>;
+    constexpr int K4 = D::K4, OTL = D::OTL;
+    const int q = lane >> 4;
+    const float *pA1 = W + g.oA1 + ((size_t)tile0 * K4 * 64 + lane) * 4;
+    const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
+    const float *pA2 = W + g.oA2 + ((size_t)tile0 * OTL * 64 + lane) * 4;
+    const int last = ntiles - 1;
+    f4 a1n[K4], b1n, a2c[OTL], acc[R];
+    {   // prologue: GEMM1 of the first tile; fragments of the second
+        f4 a1c[K4], b1c;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1c[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
+        b1c = *reinterpret_cast<const f4 *>(pB1);
+#pragma unroll
+        for (int o = 0; o < OTL; ++o) a2c[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
+        const int t1 = last < 1 ? last : 1;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
+        b1n = *opaque(pB1 + t1 * 16);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
+    }
+    for (int t = 0; t < last; ++t) {
+        // fragments for the NEXT iteration: GEMM1 of tile t+2, GEMM2 of tile t+1
+        const int t2 = (t + 2 < last) ? t + 2 : last;
+        f4 a1f[K4], b1f, a2f[OTL];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1f[k4] = *opaque(pA1 + ((size_t)t2 * K4 + k4) * 256);
+        b1f = *opaque(pB1 + t2 * 16);
+#pragma unroll
+        for (int o = 0; o < OTL; ++o) a2f[o] = *opaque(pA2 + ((size_t)(t + 1) * OTL + o) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        f4 accn[R], hv[R];
+        constexpr int RB = (R % 2 == 0) ? 2 : 1;       // row tiles per phase-A block (two chains interleave)
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += RB) {           // phase A
+#pragma unroll
+            for (int u = 0; u < RB; ++u) accn[r0 + u] = b1n;
+#pragma unroll
+            for (int kk = 0; kk < NF + CQ; ++kk)
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    accn[r0 + u] = mfma16(a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), accn[r0 + u]);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) hv[r0 + u] = tanh4(acc[r0 + u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int o = 0; o < OTL; ++o)                  // phase B: independent accumulators back to back
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) out[rt][OT0 + o] = mfma16(a2c[o][rho], hv[rt][rho], out[rt][OT0 + o]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) acc[rt] = accn[rt];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = a1f[k4];
+        b1n = b1f;
+#pragma unroll
+        for (int o = 0; o < OTL; ++o) a2c[o] = a2f[o];
+    }
+    {   // epilogue: the last tile has no successor to overlap with
+        f4 hv[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) hv[rt] = tanh4(acc[rt]);
+#pragma unroll
+        for (int o = 0; o < OTL; ++o)
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) out[rt][OT0 + o] = mfma16(a2c[o][rho], hv[rt][rho], out[rt][OT0 + o]);
+    }
+}
+
+// MODE 0: forward (x*exp(s)+t, log-det)   realnvp.py:99-100
+// MODE 1: inverse ((x-t)*exp(-s))          realnvp.py:128
+// MODE 2: forward, also writing the layer input of the transformed features and exp(s) to scr
+template <int NF, int CQ, int R, int PC, int MODE>
+__device__ __forceinline__ void layer_forward(const float *__restrict__ W, const Geo &g, int lane,
+                                              float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                              float (&ld)[R], float *__restrict__ scr) {
+    using D = FwdDims<NF, CQ>;
+    constexpr int OTL = D::OTL, NT2 = D::NT2;
+    const int q = lane >> 4;
+    f4 out[R][NT2];
+#pragma unroll
+    for (int ot = 0; ot < NT2; ++ot) {
+        const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
+    }
+    if (NF >= 4) {      // each net feeds its own out tiles
+        run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
+        run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
+    } else {            // t and s share one out tile: one pipelined pass over all 2*HT tiles
+        run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, 2 * g.HT, xr, cr, out);
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float tv, sv;
+            if (NF >= 4) { tv = out[rt][f >> 2][f & 3]; sv = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
+            else { tv = out[rt][0][f & 1]; sv = out[rt][0][2 + (f & 1)]; }
+            const int e = 2 * f + 1 - PC;
+            if (MODE == 1) {
+                xr[rt][e] = (xr[rt][e] - tv) * expf(-sv);
+            } else {
+                const float es = expf(sv), xv = xr[rt][e];
+                if (MODE == 2) {
+                    scr[((rt * 2 * NF) + f) * 64 + lane] = xv;
+                    scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;
+                }
+                xr[rt][e] = fmaf(xv, es, tv);
+                ld[rt] += sv;
+            }
+        }
+    }
+}
+
+}  // namespace mfma
+}  // namespace rnvp

@@ -23,36 +23,37 @@
 //     No float atomics anywhere: results are bitwise reproducible.
 #include <atomic>
 
-#include "rnvp_mfma.h"
+#include "rnvp_mfma_layer.h"
+
+// occupancy the scheduler is told to aim for: exactly RNVP_WPE waves per SIMD, so that it spends
+// the rest of the 512/RNVP_WPE register budget on instruction-level parallelism instead of
+// serialising the tanh / MFMA chains to save registers (measured: see DESIGN.md).
+#ifndef RNVP_WPE
+#define RNVP_WPE 2
+#endif
 
 namespace rnvp {
 namespace mfma {
 namespace {
 
-using f4 = __attribute__((ext_vector_type(4))) float;
-
 // RNVP_ABLATE: developer-only timing experiments (results are WRONG when set); never defined in the
 // product build.  bit0 no LDS transposes, bit1 no LDS accumulation, bit2 no barrier/global flush,
 // bit3 cheap activation, bit4 forward only, bit5 no weight-gradient MFMAs.
-#ifndef RNVP_ABLATE
-#define RNVP_ABLATE 0
-#endif
 constexpr int kAblate = RNVP_ABLATE;
+// RNVP_STAMP: diagnostic build that accumulates s_memtime deltas per phase and printf()s them for
+// workgroup 0 (read the SHARES, not the absolute time: the stamps serialise the wave).
+#ifdef RNVP_STAMP
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_ADD(acc, t0) do { unsigned long long t1__; STAMP(t1__); acc += t1__ - t0; t0 = t1__; } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#define STAMP_ADD(acc, t0) do { } while (0)
+#endif
+struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld; };
 
 constexpr int kWaves = 4;
 constexpr int kMaxGridTrain = 512;
 constexpr int kTS = 20;                  // row stride (floats) of a 16-wide transposition tile
-
-__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float fast_tanh(float v) {
-    if (kAblate & 8) return v * 0.5f;
-    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    return fmaf(-2.0f, r, 1.0f);
-}
 
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering the accesses.
@@ -89,97 +90,15 @@ template <int NF, int CQ> struct Dims {
     static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
 };
 
-// B operand of GEMM1 for k-step kk (compile-time kk)
-template <int NF, int CQ, int PC, int R>
-__device__ __forceinline__ float in_op(const float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
-                                       int rt, int kk) {
-    return (kk < NF) ? xr[rt][2 * (kk < NF ? kk : 0) + PC] : cr[rt][kk >= NF ? kk - NF : 0];
-}
-
-// ---- forward of one layer, saving what the backward needs ---------------------------------------
-template <int NF, int CQ, int R, int PC>
-__device__ __forceinline__ void layer_fwd_save(const float *__restrict__ W, const Geo &g, int lane,
-                                               float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
-                                               float (&ld)[R], float *__restrict__ scr) {
-    using D = Dims<NF, CQ>;
-    constexpr int KS1 = D::KS1, K4 = D::K4, OTL = D::OTL, NT2 = D::NT2;
-    const int q = lane >> 4;
-    f4 out[R][NT2];
-#pragma unroll
-    for (int ot = 0; ot < NT2; ++ot) {
-        const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
-    }
-    const int HT = g.HT;
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
-        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
-        const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
-        const float *pA2 = W + g.oA2 + ((size_t)net * HT * OTL * 64 + lane) * 4;
-        f4 a1[K4], a2[OTL], b1;
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
-        b1 = *reinterpret_cast<const f4 *>(pB1);
-#pragma unroll
-        for (int o = 0; o < OTL; ++o) a2[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
-        for (int ht = 0; ht < HT; ++ht) {
-            const int nx = (ht + 1 < HT) ? ht + 1 : ht;
-            f4 na1[K4], na2[OTL], nb1;
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4)
-                na1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)nx * K4 + k4) * 256);
-            nb1 = *reinterpret_cast<const f4 *>(pB1 + nx * 16);
-#pragma unroll
-            for (int o = 0; o < OTL; ++o)
-                na2[o] = *reinterpret_cast<const f4 *>(pA2 + ((size_t)nx * OTL + o) * 256);
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) {
-                f4 acc = b1;
-#pragma unroll
-                for (int kk = 0; kk < KS1; ++kk)
-                    acc = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc);
-                f4 hv;
-                hv[0] = fast_tanh(acc[0]); hv[1] = fast_tanh(acc[1]);
-                hv[2] = fast_tanh(acc[2]); hv[3] = fast_tanh(acc[3]);
-#pragma unroll
-                for (int o = 0; o < OTL; ++o) {
-                    const int ot = (NF >= 4) ? net * OTL + o : 0;
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho) out[rt][ot] = mfma16(a2[o][rho], hv[rho], out[rt][ot]);
-                }
-            }
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
-            b1 = nb1;
-#pragma unroll
-            for (int o = 0; o < OTL; ++o) a2[o] = na2[o];
-        }
-    }
-#pragma unroll
-    for (int rt = 0; rt < R; ++rt) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            float tv, sv;
-            if (NF >= 4) { tv = out[rt][f >> 2][f & 3]; sv = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
-            else { tv = out[rt][0][f & 1]; sv = out[rt][0][2 + (f & 1)]; }
-            const int e = 2 * f + 1 - PC;
-            const float es = expf(sv), xv = xr[rt][e];
-            scr[((rt * 2 * NF) + f) * 64 + lane] = xv;             // layer input (transformed features)
-            scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;        // exp(s)
-            xr[rt][e] = fmaf(xv, es, tv);
-            ld[rt] += sv;
-        }
-    }
-}
-
 // ---- backward of one layer ---------------------------------------------------------------------------
 template <int NF, int CQ, int R, int PC>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
                                           const float *__restrict__ scr, float *lds, float *tb,
-                                          float *gp_layer, bool first) {
+                                          float *gp_layer, bool first, Stamps &stp) {
+    unsigned long long t0 = 0; (void)t0;
+    STAMP(t0);
     using D = Dims<NF, CQ>;
     constexpr int KS1 = D::KS1, K4 = D::K4, OTL = D::OTL, NT2 = D::NT2, KP4 = D::KP4, NTI = D::NTI,
                   MTI = D::MTI, KSP = D::KSP, SIN = D::SIN;
@@ -247,6 +166,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt) gin[rt][mt] = f4{0.f, 0.f, 0.f, 0.f};
+    STAMP_ADD(stp.bsetup, t0);
 
     // 3. the two nets, hidden tile by hidden tile
 #pragma unroll
@@ -264,7 +184,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
         for (int m = 0; m < MTI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + m * 256);
         for (int ht = 0; ht < HT; ++ht) {
-            const int nx = (ht + 1 < HT) ? ht + 1 : ht;
+            const int nx = (kAblate & 64) ? 0 : ((ht + 1 < HT) ? ht + 1 : ht);
             f4 na1[K4], na2t[OTL], na1t[MTI], nb1;
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4)
@@ -343,6 +263,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 for (int o = 0; o < OTL; ++o) asm volatile("" ::"v"(gW2[o]));
             }
             const bool last_tile = (ht + 1 == HT);
+            STAMP_ADD(stp.bloop, t0);
             if (((ht + 1) % FT == 0 || last_tile) && !(kAblate & 4)) {
                 if (last_tile && net == 1) {
                     // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
@@ -372,6 +293,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     }
                 }
                 __syncthreads();
+                STAMP_ADD(stp.bflush, t0);
             }
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
@@ -390,10 +312,11 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             const float gi = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
             gy[rt][2 * f + PC] += gi;
         }
+    STAMP_ADD(stp.btail, t0);
 }
 
 template <int NF, int CQ, int R>
-__global__ void __launch_bounds__(kWaves * 64, 2)
+__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats) {
@@ -410,7 +333,11 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + wave) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
     bool first = true;
+    Stamps stp = {0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = 0, tk0 = 0; (void)t0; (void)tk0;
+    STAMP(tk0);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        STAMP(t0);
         const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
         float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R], gy[R][2 * NF], gld[R];
         bool valid[R];
@@ -434,11 +361,12 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             }
             ld[rt] = 0.f;
         }
+        STAMP_ADD(stp.ld, t0);
         for (int l = 0; l < L; ++l) {
             const float *W = wp + (size_t)l * g.layer_floats;
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
-            if ((l + alt) & 1) layer_fwd_save<NF, CQ, R, 1>(W, g, lane, xr, cr, ld, scr);
-            else layer_fwd_save<NF, CQ, R, 0>(W, g, lane, xr, cr, ld, scr);
+            if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2>(W, g, lane, xr, cr, ld, scr);
+            else layer_forward<NF, CQ, R, 0, 2>(W, g, lane, xr, cr, ld, scr);
         }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
@@ -458,16 +386,25 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
             gld[rt] = -sc;
         }
+        STAMP_ADD(stp.fwd, t0);
         for (int l = L - 1; l >= 0 && !(kAblate & 16); --l) {
             const float *W = wp + (size_t)l * g.layer_floats;
             const float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             float *gpl = gp + (size_t)l * glayer_floats;
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first);
-            else layer_bwd<NF, CQ, R, 0>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first);
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp);
+            else layer_bwd<NF, CQ, R, 0>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp);
         }
         first = false;
     }
     if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
+#ifdef RNVP_STAMP
+    {
+        unsigned long long tk1; STAMP(tk1);
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+            printf("STAMP wg %d wave %d total %llu load %llu fwd %llu bsetup %llu bloop %llu bflush %llu btail %llu\n",
+                   (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.bloop, stp.bflush, stp.btail);
+    }
+#endif
 }
 
 // ---- partial sums over workgroups, stage 1: coalesced, float4, G partials -> kSeg segment sums -------
