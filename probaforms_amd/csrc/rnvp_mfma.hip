@@ -36,13 +36,13 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         if (kk < g.NF) col = feat_cond(g.NF, q, kk, pc);
         else if (kk < g.KS1) col = k.d + q * g.CQ + (kk - g.NF);
         else return 0.f;
-        return pl[net * k.npn + k.woff[0] + hid * nin + col];
+        return kTanhScale * pl[net * k.npn + k.woff[0] + hid * nin + col];      // pre-scaled: see tanh4
     }
     if (idx < g.oA2) {                                     // bias1 [tile][q][4]
         const int j = idx - g.oB1;
         const int e = j & 3, q = (j >> 2) & 3, tile = j >> 4;
         const int net = tile / g.HT;
-        return pl[net * k.npn + k.boff[0] + 16 * (tile % g.HT) + 4 * q + e];
+        return kTanhScale * pl[net * k.npn + k.boff[0] + 16 * (tile % g.HT) + 4 * q + e];
     }
     if (idx < g.oB2) {                                     // A2 [tile][otl][lane][4 rho]
         const int j = idx - g.oA2;

@@ -28,19 +28,27 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 #define RNVP_ABLATE 0
 #endif
 
-// tanh(v) = 1 - 2 / (1 + e^{2v}): one v_exp_f32 + one v_rcp_f32 (~1 ulp each); saturates
-// correctly through e = +inf / 0; absolute error ~1e-7, the rounding level of values near 1.
-__device__ __forceinline__ float fast_tanh(float v) {
-    if (RNVP_ABLATE & 8) return v * 0.5f;
-    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);   // 2 * log2(e)
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    return fmaf(-2.0f, r, 1.0f);
-}
+// tanh(v) = 1 - 2 / (1 + e^{2v}) with u = 2*log2(e)*v arriving PRE-SCALED: k_pack_weights folds
+// kTanhScale into the packed W1 and b1, so GEMM1's accumulator already is u.  Per value: one
+// v_exp_f32 + one v_rcp_f32 (~1 ulp each) and half a v_pk_add_f32 / v_pk_fma_f32.  f32 MFMA and
+// VALU do not overlap on a SIMD (measured: MFMA busy + VALU busy = 99 % of the forward kernel),
+// so every VALU instruction saved here is wall time.  Saturates correctly through e = +inf / 0;
+// absolute error ~1e-7, the rounding level of values near 1.
+constexpr float kTanhScale = 2.8853900817779268f;          // 2 * log2(e)
+using f2 = __attribute__((ext_vector_type(2))) float;
 
-__device__ __forceinline__ f4 tanh4(f4 a) {
-    f4 h;
-    h[0] = fast_tanh(a[0]); h[1] = fast_tanh(a[1]); h[2] = fast_tanh(a[2]); h[3] = fast_tanh(a[3]);
-    return h;
+__device__ __forceinline__ f4 tanh4(f4 u) {
+    if (RNVP_ABLATE & 8) return u * 0.5f;
+    f2 e0, e1;
+    e0[0] = __builtin_amdgcn_exp2f(u[0]); e0[1] = __builtin_amdgcn_exp2f(u[1]);
+    e1[0] = __builtin_amdgcn_exp2f(u[2]); e1[1] = __builtin_amdgcn_exp2f(u[3]);
+    e0 = e0 + 1.0f; e1 = e1 + 1.0f;                                           // v_pk_add_f32
+    f2 r0, r1;
+    r0[0] = __builtin_amdgcn_rcpf(e0[0]); r0[1] = __builtin_amdgcn_rcpf(e0[1]);
+    r1[0] = __builtin_amdgcn_rcpf(e1[0]); r1[1] = __builtin_amdgcn_rcpf(e1[1]);
+    r0 = __builtin_elementwise_fma(r0, f2{-2.0f, -2.0f}, f2{1.0f, 1.0f});     // v_pk_fma_f32
+    r1 = __builtin_elementwise_fma(r1, f2{-2.0f, -2.0f}, f2{1.0f, 1.0f});
+    return f4{r0[0], r0[1], r1[0], r1[1]};
 }
 
 // hide a fragment address from the optimiser (it would otherwise prove that next iteration's

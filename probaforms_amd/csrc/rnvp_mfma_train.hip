@@ -85,7 +85,8 @@ template <int NF, int CQ> struct Dims {
     static constexpr int MTI = OTL;                   // M tiles of the input gradient
     static constexpr int KSP = 4 * KP4;               // input columns per lane group
     static constexpr int SIN = 16 * NTI + 4;          // row stride of the input transposition tile
-    static constexpr int TB = NT2 * 16 * kTS + 16 * SIN + 2 * 16 * kTS;   // floats of LDS scratch per wave
+    // LDS scratch per wave: g_out^T staging (NT2 tiles), [in|1]^T staging, and 2 tiles (h, g_pre) per row tile
+    template <int R> static constexpr int tb() { return NT2 * 16 * kTS + 16 * SIN + 2 * R * 16 * kTS; }
     static constexpr int FT = NF == 8 ? 4 : 8;        // hidden tiles accumulated in LDS between two flushes
     static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
 };
@@ -109,8 +110,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     float *slot = lds + wave * SLOT;
     float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging)
     float *bufI = tb + NT2 * 16 * kTS;                    // 16 x SIN
-    float *bufH = bufI + 16 * SIN;                        // 16 x kTS
-    float *bufP = bufH + 16 * kTS;                        // 16 x kTS
+    float *bufH = bufI + 16 * SIN;                        // 2R tiles of 16 x kTS: (h, g_pre) per row tile
 
     // 1. restore the layer input, form g_out = [g_t | g_s] and the gradient of the pass-through part
     f4 go[R][NT2];
@@ -168,7 +168,10 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         for (int mt = 0; mt < MTI; ++mt) gin[rt][mt] = f4{0.f, 0.f, 0.f, 0.f};
     STAMP_ADD(stp.bsetup, t0);
 
-    // 3. the two nets, hidden tile by hidden tile
+    // 3. the two nets, hidden tile by hidden tile.  Hand-scheduled like the forward layer
+    //    (rnvp_mfma_layer.h): every phase runs over all R row tiles so that dependent MFMA chains
+    //    interleave, LDS round trips are covered by the input-gradient MFMAs, and the weight
+    //    fragments of the next tile are in flight for a whole iteration.
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
@@ -187,68 +190,103 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < HT) ? ht + 1 : ht);
             f4 na1[K4], na2t[OTL], na1t[MTI], nb1;
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4)
-                na1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)nx * K4 + k4) * 256);
-            nb1 = *reinterpret_cast<const f4 *>(pB1 + nx * 16);
+            for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
+            nb1 = *opaque(pB1 + nx * 16);
 #pragma unroll
-            for (int o = 0; o < OTL; ++o)
-                na2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)nx * OTL + o) * 256);
+            for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
+#pragma unroll
+            for (int m = 0; m < MTI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * MTI + m) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // phase 1 (MFMA): GEMM1 recompute and g_h = W2^T g_out, chains interleaved over row tiles
+            f4 acc[R], gh[R];
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) { acc[rt] = b1; gh[rt] = f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk)
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt)
+                    acc[rt] = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc[rt]);
+            if (NF >= 4) {
+#pragma unroll
+                for (int o = 0; o < OTL; ++o)
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                        for (int rt = 0; rt < R; ++rt)
+                            gh[rt] = mfma16(a2t[o][rho], go[rt][(NF >= 4 ? net * OTL : 0) + o][rho], gh[rt]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt)
+                        gh[rt] = mfma16(a2t[0][2 * net + u], go[rt][0][2 * net + u], gh[rt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            // phase 2 (VALU + LDS writes): h = tanh, g_pre = g_h * (1 - h^2); both go to this wave's
+            // per-row-tile transposition tiles
+            f4 gpv[R];
+            wave_lds_fence();
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                const f4 hv = tanh4(acc[rt]);
+                gpv[rt] = gh[rt] * (1.0f - hv * hv);                                   // tanh'
+                if (!(kAblate & 1)) {
+                    *reinterpret_cast<f4 *>(bufH + (2 * rt) * 16 * kTS + r * kTS + 4 * q) = hv;
+                    *reinterpret_cast<f4 *>(bufH + (2 * rt + 1) * 16 * kTS + r * kTS + 4 * q) = gpv[rt];
+                } else {
+                    asm volatile("" ::"v"(hv));
+                }
+            }
+            wave_lds_fence();
+            __builtin_amdgcn_sched_barrier(0);
+
+            // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
 #pragma unroll
             for (int m = 0; m < MTI; ++m)
-                na1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)nx * MTI + m) * 256);
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) gin[rt][m] = mfma16(a1t[m][rho], gpv[rt][rho], gin[rt][m]);
+            float hT[R][4], pT[R][4];
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (!(kAblate & 1)) {
+                        hT[rt][ks] = bufH[(2 * rt) * 16 * kTS + (4 * ks + q) * kTS + r];
+                        pT[rt][ks] = bufH[(2 * rt + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
+                    } else {
+                        hT[rt][ks] = gpv[rt][ks]; pT[rt][ks] = gpv[rt][ks];
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
 
+            // phase 4 (MFMA): dW2 += h g_out^T, dW1|db1 += g_pre [in|1]^T; two+ independent chains
             f4 gW2[OTL], gW1[NTI];
 #pragma unroll
             for (int o = 0; o < OTL; ++o) gW2[o] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < NTI; ++nt) gW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(kAblate & 32)) {
 #pragma unroll
-            for (int rt = 0; rt < R; ++rt) {
-                f4 acc = b1;
+                for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-                for (int kk = 0; kk < KS1; ++kk)
-                    acc = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc);
-                f4 hv;
-                hv[0] = fast_tanh(acc[0]); hv[1] = fast_tanh(acc[1]);
-                hv[2] = fast_tanh(acc[2]); hv[3] = fast_tanh(acc[3]);
-                f4 gh = f4{0.f, 0.f, 0.f, 0.f};
-                if (NF >= 4) {
+                    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                    for (int o = 0; o < OTL; ++o)
+                        for (int o = 0; o < OTL; ++o)
+                            gW2[o] = mfma16(hT[rt][ks], goT[rt][(NF >= 4 ? net * OTL : 0) + o][ks], gW2[o]);
 #pragma unroll
-                        for (int rho = 0; rho < 4; ++rho)
-                            gh = mfma16(a2t[o][rho], go[rt][(NF >= 4 ? net * OTL : 0) + o][rho], gh);
-                } else {
+                        for (int nt = 0; nt < NTI; ++nt) gW1[nt] = mfma16(pT[rt][ks], inT[rt][nt][ks], gW1[nt]);
+                    }
+            } else {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) gh = mfma16(a2t[0][2 * net + u], go[rt][0][2 * net + u], gh);
-                }
-                f4 gpv;
+                for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) gpv[u] = gh[u] * fmaf(-hv[u], hv[u], 1.0f);     // tanh'
-#pragma unroll
-                for (int m = 0; m < MTI; ++m)
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho) gin[rt][m] = mfma16(a1t[m][rho], gpv[rho], gin[rt][m]);
-                float hT[4], pT[4];
-                transpose16(bufH, hv, lane, hT);
-                transpose16(bufP, gpv, lane, pT);
-                if (!(kAblate & 32)) {
-#pragma unroll
-                for (int o = 0; o < OTL; ++o) {
-                    const int ot = (NF >= 4) ? net * OTL + o : 0;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) gW2[o] = mfma16(hT[ks], goT[rt][ot][ks], gW2[o]);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NTI; ++nt)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) gW1[nt] = mfma16(pT[ks], inT[rt][nt][ks], gW1[nt]);
-                } else {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[ks]; gW1[0][ks] += pT[ks]; }
-                }
+                    for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[rt][ks]; gW1[0][ks] += pT[rt][ks]; }
             }
-            // this wave's share of dW1|db1 and dW2 for hidden tile ht -> LDS slot
+            __builtin_amdgcn_sched_barrier(0);
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
             if (!(kAblate & 2)) {
                 float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
@@ -279,10 +317,11 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 __syncthreads();
                 {   // slot0 + slot1 + slot2 + slot3 (wave order) -> the workgroup's partial in global memory
                     const int t0 = (ht / FT) * FT, ntile = ht + 1 - t0;
-                    const int nfl = ntile * TBLK;
-                    float *dst = gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK;
-                    for (int i = tid; i < nfl; i += kWaves * 64) {
-                        const float v = ((lds[i] + lds[SLOT + i]) + lds[2 * SLOT + i]) + lds[3 * SLOT + i];
+                    const int nfl4 = ntile * TBLK / 4;
+                    f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK);
+                    const f4 *s0 = reinterpret_cast<const f4 *>(lds);
+                    for (int i = tid; i < nfl4; i += kWaves * 64) {
+                        const f4 v = ((s0[i] + s0[SLOT / 4 + i]) + s0[2 * (SLOT / 4) + i]) + s0[3 * (SLOT / 4) + i];
                         dst[i] = first ? v : dst[i] + v;
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
@@ -325,7 +364,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, r = lane & 15;
-    float *tb = lds + kWaves * DM::SLOT + wave * DM::TB;
+    float *tb = lds + kWaves * DM::SLOT + wave * DM::template tb<R>();
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)D * kLog2Pi;
@@ -512,8 +551,8 @@ TrainPlan make_plan(const Geo &g, int L) {
     TrainPlan p;
     const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
     p.glayer_floats = 2 * netblock + DM::NT2 * 16;
-    p.lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::TB) * sizeof(float);
     p.R = TrainRows<NF, CQ>::value;
+    p.lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::template tb<TrainRows<NF, CQ>::value>()) * sizeof(float);
     p.scratch_per_wave = (size_t)L * p.R * 2 * NF * 64;
     return p;
 }
