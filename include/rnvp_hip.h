@@ -152,6 +152,17 @@ int rnvp_train_step(void *stream, const rnvp_shape *shape,
                     double weight_decay, int64_t step,
                     void *workspace, size_t workspace_bytes);
 
+/*
+ * Measurement aid (bench.py): while enabled, the DOMINANT kernel of each rnvp_loss_grad /
+ * rnvp_train_step call (the fused forward+backward kernel) is bracketed by a pair of HIP events
+ * recorded on the caller's stream.  rnvp_profile_read synchronises on them and returns the
+ * number of bracketed launches and their summed duration in milliseconds, then resets.
+ * At most `capacity` launches are bracketed between two reads (later ones run un-timed).
+ * Not thread-safe; has no equivalent in the reference.
+ */
+int rnvp_profile_enable(int capacity);          /* capacity <= 0 disables and frees the events */
+int rnvp_profile_read(int *n_launches, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

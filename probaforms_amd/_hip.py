@@ -81,6 +81,8 @@ _SIGNATURES = {
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "rnvp_profile_enable": (C.c_int, [C.c_int]),
+    "rnvp_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -135,6 +137,17 @@ def _call(name, args):
 
 def _ws(ws):
     return _ptr(ws, torch.uint8, "workspace"), (0 if ws is None else ws.numel())
+
+
+def profile_enable(capacity):
+    check(lib().rnvp_profile_enable(int(capacity)), "rnvp_profile_enable")
+
+
+def profile_read():
+    """-> (launches, total_ms) of the dominant kernel since the last read"""
+    n, ms = C.c_int(0), C.c_float(0.0)
+    check(lib().rnvp_profile_read(C.byref(n), C.byref(ms)), "rnvp_profile_read")
+    return n.value, ms.value
 
 
 def param_count(shape):

@@ -1,6 +1,7 @@
 // rnvp_api.hip -- extern "C" entry points of librnvp_hip.so (declared in include/rnvp_hip.h)
 // and the dispatch between the kernel families.
 #include <cstring>
+#include <vector>
 
 #include "rnvp_common.h"
 #include "rnvp_mfma.h"
@@ -15,7 +16,53 @@ bool bad_ptrs(const KShape &k, const float *params, const uint8_t *masks, const 
 
 }  // namespace
 
+// ---- rnvp_profile_*: event pairs around the dominant kernel ------------------------------------
+namespace rnvp {
+namespace {
+std::vector<hipEvent_t> g_ev;      // start0, stop0, start1, stop1, ...
+int g_ev_used = 0;                 // pairs recorded since the last read
+}  // namespace
+
+KernelTimer::KernelTimer(hipStream_t s) : st(s), on(false) {
+    if (!g_ev.empty() && (size_t)(2 * g_ev_used + 1) < g_ev.size()) {
+        on = hipEventRecord(g_ev[2 * g_ev_used], st) == hipSuccess;
+    }
+}
+KernelTimer::~KernelTimer() {
+    if (on) {
+        (void)hipEventRecord(g_ev[2 * g_ev_used + 1], st);
+        ++g_ev_used;
+    }
+}
+}  // namespace rnvp
+
 extern "C" {
+
+int rnvp_profile_enable(int capacity) {
+    for (hipEvent_t e : rnvp::g_ev) (void)hipEventDestroy(e);
+    rnvp::g_ev.clear();
+    rnvp::g_ev_used = 0;
+    for (int i = 0; i < 2 * capacity; ++i) {
+        hipEvent_t e;
+        RNVP_HIP_TRY(hipEventCreate(&e));
+        rnvp::g_ev.push_back(e);
+    }
+    return RNVP_OK;
+}
+
+int rnvp_profile_read(int *n_launches, float *total_ms) {
+    float tot = 0.f;
+    for (int i = 0; i < rnvp::g_ev_used; ++i) {
+        RNVP_HIP_TRY(hipEventSynchronize(rnvp::g_ev[2 * i + 1]));
+        float ms = 0.f;
+        RNVP_HIP_TRY(hipEventElapsedTime(&ms, rnvp::g_ev[2 * i], rnvp::g_ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (n_launches) *n_launches = rnvp::g_ev_used;
+    if (total_ms) *total_ms = tot;
+    rnvp::g_ev_used = 0;
+    return RNVP_OK;
+}
 
 int rnvp_version(void) { return 100; }
 

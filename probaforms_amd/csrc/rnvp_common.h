@@ -69,6 +69,14 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
 int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
               double lr, double beta1, double beta2, double eps, double wd, int64_t step);
 
+// ---- optional event bracket around the dominant kernel (rnvp_profile_*, rnvp_api.hip) ------------
+struct KernelTimer {
+    hipStream_t st;
+    bool on;
+    explicit KernelTimer(hipStream_t s);   // records the start event if profiling is enabled
+    ~KernelTimer();                        // records the stop event
+};
+
 #define RNVP_HIP_TRY(expr)                         \
     do {                                           \
         hipError_t e__ = (expr);                   \

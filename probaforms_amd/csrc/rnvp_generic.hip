@@ -476,8 +476,11 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
     float *xsave = reinterpret_cast<float *>(w);
     int rc = allow_lds(k_generic_train, tl.lds, g_lds_train);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_generic_train, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,
-                       row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP);
+    {
+        KernelTimer timer(st);      // rnvp_profile_*: brackets exactly this launch when enabled
+        hipLaunchKernelGGL(k_generic_train, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,
+                           row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP);
+    }
     RNVP_HIP_TRY(hipGetLastError());
     const int rb = 256;
     const unsigned blocks = (unsigned)((P + 1 + rb - 1) / rb);

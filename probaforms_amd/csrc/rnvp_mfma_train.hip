@@ -579,8 +579,11 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.store(1, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), pl.lds_bytes, st, packed, g, k.L, k.alt, x, c, row_index,
-                       n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
+    {
+        KernelTimer timer(st);      // rnvp_profile_*: brackets exactly this launch when enabled
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), pl.lds_bytes, st, packed, g, k.L, k.alt, x, c,
+                           row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
+    }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }

@@ -1,0 +1,122 @@
+"""Data-parallel fit over torch.distributed (gloo, world_size 2) on CPU.
+
+The product computes on HIP only, so here the C-ABI calls are replaced -- in the TEST process,
+by monkeypatching probaforms_amd._hip -- with the CPU oracle as a compute stand-in.  What is
+under test is the host logic of SURVEY.md 8(e): identical permutation on every rank, contiguous
+shards of each global batch (ragged last batch, possibly empty shards), gradients scaled by
+1/B_global, ONE all-reduce(SUM) of the flat [grad | loss] buffer per step, identical Adam on every
+rank.  Two ranks must reproduce the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _install_oracle_backend():
+    """swap the HIP entry points for oracle-backed CPU stand-ins (test process only)"""
+    os.environ["device"] = "cpu"
+    sys.path.insert(0, ROOT)
+    from oracle import Oracle, Shape
+    from probaforms_amd import _engine, _hip
+    import probaforms_amd.models.nflow as nflow
+    import probaforms_amd.models.realnvp as realnvp
+    o = Oracle(32)
+
+    def oshape(s):
+        return Shape.make(s.L, s.d, s.c, tuple(s.hidden[:s.n_hidden]), "tanh" if s.act == 0 else "relu")
+
+    def loss_grad(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out, ws):
+        if n_rows == 0:
+            grad_out.zero_(); loss_out.zero_(); return
+        rows = row_index.numpy() if row_index is not None else np.arange(n_rows)
+        X = x.numpy()[rows]; Cc = None if c is None else c.numpy()[rows]
+        loss, g = o.loss_grad(oshape(shape), params.numpy(), X, Cc, masks.numpy(), inv_B=inv_B)
+        grad_out.copy_(torch.from_numpy(g)); loss_out[0] = float(loss)
+
+    def adam_step(params, grad, m, v, n, lr, b1, b2, eps, wd, step):
+        o.adam(params.numpy(), grad.numpy(), m.numpy(), v.numpy(), step, lr=lr, betas=(b1, b2), eps=eps,
+               weight_decay=wd)
+
+    def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out, m, v,
+                   lr, b1, b2, eps, wd, step, ws):
+        loss_grad(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out, ws)
+        adam_step(params, grad_buf, m, v, params.numel(), lr, b1, b2, eps, wd, step)
+
+    def inverse(shape, params, masks, z, c, n_rows, x_out, ws):
+        x_out.copy_(torch.from_numpy(o.sample(oshape(shape), params.numpy(), z.numpy(),
+                                              None if c is None else c.numpy(), masks.numpy())))
+
+    _hip.loss_grad, _hip.adam_step, _hip.train_step, _hip.inverse = loss_grad, adam_step, train_step, inverse
+    _hip.workspace_bytes = lambda shape, op, rows: 16
+    for mod in (_engine, nflow, realnvp):
+        mod.require_hip = lambda device: None
+    return realnvp
+
+
+def _data():
+    rng = np.random.default_rng(3)
+    return rng.normal(size=(75, 4)), rng.normal(size=(75, 2))        # 75 rows, bs 32 -> 32, 32, 11
+
+
+def _fit(world_rank=None):
+    realnvp = _install_oracle_backend()
+    X, C = _data()
+    torch.manual_seed(0)
+    m = realnvp.RealNVP(n_layers=3, hidden=(6,), batch_size=32, n_epochs=2, lr=0.01, weight_decay=0.1)
+    m.fit(X, C)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.nf.parameters()]).numpy().copy()
+    hist = np.array([float(v) for v in m.loss_history])
+    return flat, hist
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat, hist = _fit(rank)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), flat=flat, hist=hist)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_match_single_process(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    # every rank applies the identical update: replicas stay bit-identical
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["hist"], r1["hist"])
+    assert r0["hist"].shape == (6,)                                   # 3 batches x 2 epochs
+    # reference run in a fresh single process (world size 1 path: fused train_step)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single, args=(q,)); p.start(); flat1, hist1 = q.get(timeout=240); p.join()
+    # only the summation order of the two shards differs from the single-process gradient
+    np.testing.assert_allclose(r0["hist"], hist1, rtol=2e-5, atol=2e-5)
+    assert np.abs(r0["flat"] - flat1).max() < 5e-4 and np.abs(r0["flat"] - flat1).mean() < 2e-5
+
+
+def _single(q):
+    q.put(_fit(None))
+
+
+def test_three_way_shards_cover_ragged_batch():
+    from probaforms_amd._engine import batch_bounds, shard_bounds
+    n, bs, world = 75, 32, 3
+    seen = []
+    for s, e in batch_bounds(n, bs):
+        for r in range(world):
+            lo, hi = shard_bounds(s, e, r, world)
+            seen.extend(range(lo, hi))
+    assert seen == list(range(n))
