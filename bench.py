@@ -67,6 +67,21 @@ def useful_flops_per_row(d, c, hidden, L, passes):
     return 4 * hidden[0] * (d + c) * L * passes
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
+    command (scripts/gpu_traffic.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md).  bench.py cannot collect counters itself; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    for k, v in d.items():
+        if k.startswith(kernel_prefix):
+            return float(v["hbm_bytes_per_launch"])
+    return None
+
+
 def cpu_baseline(X, C, params, rows=32768):
     """oracle (scalar C port, 1 core) on a bounded sample: one training step on `rows` rows
     + sampling `rows` rows -- the same mix as one GPU step."""
@@ -186,7 +201,8 @@ def main():
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic("k_mfma_train" if path == _hip.PATH_MFMA else "k_generic_train"),
                          "kernel": "k_mfma_train / k_generic_train (fused forward+backward), %.3f ms avg over %d launches, "
                                    "%d useful flop/row x %d rows" % (kern_ms, args.steps,
                                                                      useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 3), BATCH)},

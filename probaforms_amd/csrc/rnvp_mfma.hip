@@ -192,7 +192,10 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__
     if (!INVERSE && part && lane == 0) part[blockIdx.x * kWaves + wave] = wave_sum;
 }
 
-template <int NF, int CQ> struct RowTiles { static constexpr int value = NF == 2 ? 4 : (NF == 4 ? 2 : 1); };
+#ifndef RNVP_FLOW_R2
+#define RNVP_FLOW_R2 4
+#endif
+template <int NF, int CQ> struct RowTiles { static constexpr int value = NF == 2 ? RNVP_FLOW_R2 : (NF == 4 ? 2 : 1); };
 
 struct Launch {
     Geo g;

@@ -49,9 +49,12 @@ constexpr int kAblate = RNVP_ABLATE;
 #define STAMP(var) do { } while (0)
 #define STAMP_ADD(acc, t0) do { } while (0)
 #endif
-struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld; };
+struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2, p3, p4, p5; };
 
-constexpr int kWaves = 4;
+#ifndef RNVP_TRAIN_WAVES
+#define RNVP_TRAIN_WAVES 4
+#endif
+constexpr int kWaves = RNVP_TRAIN_WAVES;    // waves per workgroup
 constexpr int kMaxGridTrain = 512;
 constexpr int kTS = 20;                  // row stride (floats) of a 16-wide transposition tile
 
@@ -87,7 +90,11 @@ template <int NF, int CQ> struct Dims {
     static constexpr int SIN = 16 * NTI + 4;          // row stride of the input transposition tile
     // LDS scratch per wave: g_out^T staging (NT2 tiles), [in|1]^T staging, and 2 tiles (h, g_pre) per row tile
     template <int R> static constexpr int tb() { return NT2 * 16 * kTS + 16 * SIN + 2 * R * 16 * kTS; }
+#ifdef RNVP_TRAIN_FT
+    static constexpr int FT = RNVP_TRAIN_FT;
+#else
     static constexpr int FT = NF == 8 ? 4 : 8;        // hidden tiles accumulated in LDS between two flushes
+#endif
     static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
 };
 
@@ -224,6 +231,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             }
             __builtin_amdgcn_sched_barrier(0);
 
+            STAMP_ADD(stp.p1, t0);
             // phase 2 (VALU + LDS writes): h = tanh, g_pre = g_h * (1 - h^2); both go to this wave's
             // per-row-tile transposition tiles
             f4 gpv[R];
@@ -242,6 +250,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             wave_lds_fence();
             __builtin_amdgcn_sched_barrier(0);
 
+            STAMP_ADD(stp.p2, t0);
             // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
 #pragma unroll
             for (int m = 0; m < MTI; ++m)
@@ -263,6 +272,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 }
             __builtin_amdgcn_sched_barrier(0);
 
+            STAMP_ADD(stp.p3, t0);
             // phase 4 (MFMA): dW2 += h g_out^T, dW1|db1 += g_pre [in|1]^T; two+ independent chains
             f4 gW2[OTL], gW1[NTI];
 #pragma unroll
@@ -287,6 +297,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[rt][ks]; gW1[0][ks] += pT[rt][ks]; }
             }
             __builtin_amdgcn_sched_barrier(0);
+            STAMP_ADD(stp.p4, t0);
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
             if (!(kAblate & 2)) {
                 float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
@@ -301,7 +312,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 for (int o = 0; o < OTL; ++o) asm volatile("" ::"v"(gW2[o]));
             }
             const bool last_tile = (ht + 1 == HT);
-            STAMP_ADD(stp.bloop, t0);
+            STAMP_ADD(stp.p5, t0);
             if (((ht + 1) % FT == 0 || last_tile) && !(kAblate & 4)) {
                 if (last_tile && net == 1) {
                     // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
@@ -321,12 +332,16 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds);
                     for (int i = tid; i < nfl4; i += kWaves * 64) {
-                        const f4 v = ((s0[i] + s0[SLOT / 4 + i]) + s0[2 * (SLOT / 4) + i]) + s0[3 * (SLOT / 4) + i];
+                        f4 v = s0[i];
+#pragma unroll
+                        for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
                         dst[i] = first ? v : dst[i] + v;
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
                         const int i = FT * TBLK + tid;
-                        const float v = ((lds[i] + lds[SLOT + i]) + lds[2 * SLOT + i]) + lds[3 * SLOT + i];
+                        float v = lds[i];
+#pragma unroll
+                        for (int w = 1; w < kWaves; ++w) v += lds[w * SLOT + i];
                         float *p = gp_layer + 2 * (size_t)netblock + tid;
                         *p = first ? v : *p + v;
                     }
@@ -372,7 +387,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + wave) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
     bool first = true;
-    Stamps stp = {0, 0, 0, 0, 0, 0};
+    Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0, tk0 = 0; (void)t0; (void)tk0;
     STAMP(tk0);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -440,8 +455,8 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     {
         unsigned long long tk1; STAMP(tk1);
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-            printf("STAMP wg %d wave %d total %llu load %llu fwd %llu bsetup %llu bloop %llu bflush %llu btail %llu\n",
-                   (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.bloop, stp.bflush, stp.btail);
+            printf("STAMP wg %d wave %d total %llu load %llu fwd %llu bsetup %llu p1 %llu p2 %llu p3 %llu p4 %llu p5 %llu bflush %llu btail %llu\n",
+                   (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.p1, stp.p2, stp.p3, stp.p4, stp.p5, stp.bflush, stp.btail);
     }
 #endif
 }
@@ -536,7 +551,10 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
     grad[p] = a;
 }
 
-template <int NF, int CQ> struct TrainRows { static constexpr int value = NF == 2 ? 4 : (NF == 4 ? 2 : 1); };
+#ifndef RNVP_TRAIN_R2
+#define RNVP_TRAIN_R2 4
+#endif
+template <int NF, int CQ> struct TrainRows { static constexpr int value = NF == 2 ? RNVP_TRAIN_R2 : (NF == 4 ? 2 : 1); };
 
 struct TrainPlan {
     int glayer_floats;      // per layer: 2 net blocks + db2
