@@ -1,0 +1,55 @@
+/*
+ * cvae_hip.h -- C ABI of the conditional-VAE entry points of librnvp_hip.so (SURVEY.md 8(f) rank 1,
+ * BASELINE.json configs[4]).  Same conventions as rnvp_hip.h (device pointers, caller-owned
+ * workspace, caller's stream, int status).  Replaces the arithmetic of
+ * /root/reference/probaforms/models/cvae.py: Encoder.forward (39-64), Decoder.forward (92-113),
+ * CVAE.sample_z / custom_loss / compute_loss (186-203) and the autograd backward of
+ * `loss.backward()` (243-246).  The optimizer step is rnvp_adam_step (rnvp_hip.h).
+ *
+ * params: flat float32: encoder hidden Linears (weight [out,in], bias) in order; then the two heads
+ *   stored as ONE Linear: mu.weight, log_sigma.weight, mu.bias, log_sigma.bias; then the decoder's
+ *   Linears (weight, bias) in order.  (Each tensor is a contiguous [out,in] block, so the
+ *   reference's state_dict tensors can simply be views into this buffer.)
+ * x [n,d], c [n,cdim] (NULL iff cdim == 0), eps [n_rows, lat] (the N(0,1) draws of sample_z,
+ *   cvae.py:187, in BATCH order), z [n, lat]; all float32 row-major.
+ */
+#ifndef CVAE_HIP_H
+#define CVAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cvae_shape {
+    int32_t d;            /* var_size                                   cvae.py:170-173 */
+    int32_t c;            /* cond_size, 0 for C=None                    cvae.py:159-162 */
+    int32_t lat;          /* latent_dim                                 cvae.py:145     */
+    int32_t n_hidden;     /* len(hidden)                                              */
+    int32_t hidden[8];
+    int32_t act;          /* 0 tanh, 1 relu                             cvae.py:26-32   */
+} cvae_shape;
+
+size_t cvae_param_count(const cvae_shape *shape);
+size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows);
+
+/* loss = KL_weight * (1/B) sum_b KL_b + (1/(B d)) sum_{b,j} (x - x_rec)^2 with 1/B = inv_B, and its
+ * gradient wrt every parameter (grad_out [P]; NULL = loss only, the per-epoch evaluation of
+ * cvae.py:254-259).  row_index (nullable) gathers x/c rows; eps is already in batch order. */
+int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params,
+                   const float *x, const float *c, const int64_t *row_index, const float *eps,
+                   int64_t n_rows, float inv_B, float kl_weight,
+                   float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes);
+
+/* x_out [n,d] = Decoder([z || c])                                       cvae.py:108-113, 284-290 */
+int cvae_decode(void *stream, const cvae_shape *shape, const float *params,
+                const float *z, const float *c, int64_t n_rows, float *x_out);
+
+/* mu [n,lat], log_sigma [n,lat] = Encoder([x || c])                     cvae.py:57-64 */
+int cvae_encode(void *stream, const cvae_shape *shape, const float *params,
+                const float *x, const float *c, int64_t n_rows, float *mu_out, float *log_sigma_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -38,8 +38,8 @@ class Shape(C.Structure):
 def build(force=False):
     """Compile the oracle with gcc (make -C oracle). Building the checker is not using it."""
     libs = [os.path.join(_BUILD, "librnvp_oracle%d.so" % b) for b in (32, 64)]
-    src = os.path.join(_HERE, "rnvp_oracle.c")
-    stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src)
+    srcs = [os.path.join(_HERE, f) for f in ("rnvp_oracle.c", "cvae_oracle.c")]
+    stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(f) for f in srcs)
                          for p in libs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -157,3 +157,74 @@ class Oracle:
         self.lib.rnvp_oracle_adam(self._p(p), self._p(g), self._p(m), self._p(v), C.c_int64(p.size),
                                   C.c_double(lr), C.c_double(betas[0]), C.c_double(betas[1]),
                                   C.c_double(eps), C.c_double(weight_decay), C.c_int64(step))
+
+
+# ---------------------------------------------------------------------------------------------
+# CVAE (oracle/cvae_oracle.c; /root/reference/probaforms/models/cvae.py)
+# ---------------------------------------------------------------------------------------------
+class CvaeShape(C.Structure):
+    _fields_ = [("d", C.c_int32), ("c", C.c_int32), ("lat", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * MAX_HIDDEN), ("act", C.c_int32)]
+
+    @classmethod
+    def make(cls, d, c, lat, hidden=(10,), activation="tanh"):
+        s = cls()
+        s.d, s.c, s.lat, s.n_hidden = int(d), int(c), int(lat), len(hidden)
+        for i, h in enumerate(hidden):
+            s.hidden[i] = int(h)
+        s.act = 0 if activation == "tanh" else 1
+        return s
+
+
+def cvae_flat_from_state(enc_sd, dec_sd, n_hidden):
+    """reference state_dicts of Encoder / Decoder -> the oracle's flat order (heads as one Linear)"""
+    g = lambda sd, k: np.asarray(sd[k], dtype=np.float64).ravel()
+    parts = []
+    for k in range(n_hidden):
+        parts += [g(enc_sd, "model.%d.weight" % (2 * k)), g(enc_sd, "model.%d.bias" % (2 * k))]
+    parts += [g(enc_sd, "mu.weight"), g(enc_sd, "log_sigma.weight"), g(enc_sd, "mu.bias"), g(enc_sd, "log_sigma.bias")]
+    for k in range(n_hidden + 1):
+        parts += [g(dec_sd, "model.%d.weight" % (2 * k)), g(dec_sd, "model.%d.bias" % (2 * k))]
+    return np.concatenate(parts)
+
+
+class CvaeOracle:
+    def __init__(self, precision=32):
+        build()
+        self.lib = C.CDLL(os.path.join(_BUILD, "librnvp_oracle%d.so" % precision))
+        self.dtype = np.float32 if precision == 32 else np.float64
+        self.lib.cvae_oracle_param_count.restype = C.c_size_t
+
+    def _a(self, x):
+        return None if x is None else np.ascontiguousarray(x, dtype=self.dtype)
+
+    @staticmethod
+    def _p(a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    def param_count(self, s):
+        return int(self.lib.cvae_oracle_param_count(C.byref(s)))
+
+    def loss_grad(self, s, params, x, c, eps, kl_weight, inv_B=None, want_grad=True):
+        B = x.shape[0]
+        x, c, eps, p = self._a(x), self._a(c), self._a(eps), self._a(params)
+        g = np.empty_like(p) if want_grad else None
+        loss = np.zeros(1, self.dtype)
+        self.lib.cvae_oracle_loss_grad(C.byref(s), self._p(p), self._p(x), self._p(c), self._p(eps), C.c_int64(B),
+                                       C.c_double(1.0 / B if inv_B is None else inv_B), C.c_double(kl_weight),
+                                       self._p(g), self._p(loss))
+        return loss[0], g
+
+    def decode(self, s, params, z, c):
+        n = z.shape[0]
+        z, c, p = self._a(z), self._a(c), self._a(params)
+        x = np.empty((n, s.d), self.dtype)
+        self.lib.cvae_oracle_decode(C.byref(s), self._p(p), self._p(z), self._p(c), C.c_int64(n), self._p(x))
+        return x
+
+    def encode(self, s, params, x, c):
+        n = x.shape[0]
+        x, c, p = self._a(x), self._a(c), self._a(params)
+        mu = np.empty((n, s.lat), self.dtype); ls = np.empty((n, s.lat), self.dtype)
+        self.lib.cvae_oracle_encode(C.byref(s), self._p(p), self._p(x), self._p(c), C.c_int64(n), self._p(mu), self._p(ls))
+        return mu, ls

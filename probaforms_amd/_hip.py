@@ -59,6 +59,24 @@ class RnvpShape(C.Structure):
         return (self.L, self.d, self.c, tuple(self.hidden[:self.n_hidden]), self.act)
 
 
+class CvaeShape(C.Structure):
+    """mirror of `cvae_shape` (include/cvae_hip.h)"""
+    _fields_ = [("d", C.c_int32), ("c", C.c_int32), ("lat", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * MAX_HIDDEN), ("act", C.c_int32)]
+
+    @classmethod
+    def make(cls, d, c, lat, hidden, activation):
+        hidden = tuple(int(h) for h in hidden)
+        if not 1 <= len(hidden) <= MAX_HIDDEN:
+            raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
+        s = cls()
+        s.d, s.c, s.lat, s.n_hidden = int(d), int(c), int(lat), len(hidden)
+        for i, h in enumerate(hidden):
+            s.hidden[i] = h
+        s.act = 0 if activation == "tanh" else 1       # cvae.py:26-32
+        return s
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -81,6 +99,11 @@ _SIGNATURES = {
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
+    "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
+    "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
+    "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP]),
+    "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP]),
     "rnvp_profile_enable": (C.c_int, [C.c_int]),
     "rnvp_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
@@ -201,3 +224,31 @@ def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, l
         _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
         _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(eps),
         float(weight_decay), int(step), wp, wn))
+
+
+# ---- CVAE (include/cvae_hip.h) ----------------------------------------------------------------
+def cvae_param_count(shape):
+    return int(lib().cvae_param_count(C.byref(shape)))
+
+
+def cvae_workspace_bytes(shape, max_rows):
+    return int(lib().cvae_workspace_bytes(C.byref(shape), int(max_rows)))
+
+
+def cvae_loss_grad(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out, ws):
+    wp, wn = _ws(ws)
+    _call("cvae_loss_grad", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(x, torch.float32, "x"),
+          _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"), _ptr(eps, torch.float32, "eps"),
+          int(n_rows), float(inv_B), float(kl_weight), _ptr(grad_out, torch.float32, "grad_out"),
+          _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
+
+
+def cvae_decode(shape, params, z, c, n_rows, x_out):
+    _call("cvae_decode", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(z, torch.float32, "z"),
+          _ptr(c, torch.float32, "c"), int(n_rows), _ptr(x_out, torch.float32, "x_out")))
+
+
+def cvae_encode(shape, params, x, c, n_rows, mu_out, ls_out):
+    _call("cvae_encode", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(x, torch.float32, "x"),
+          _ptr(c, torch.float32, "c"), int(n_rows), _ptr(mu_out, torch.float32, "mu_out"),
+          _ptr(ls_out, torch.float32, "log_sigma_out")))

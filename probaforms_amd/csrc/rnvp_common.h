@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <cstring>
 
 #include "../../include/rnvp_hip.h"
 
@@ -64,6 +65,9 @@ int generic_inverse(hipStream_t st, const KShape &k, const float *params, const 
 int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *row_index, int64_t n,
                       float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes);
+
+int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
+                            float loss_scale, float *grad_out, float *loss_out);
 
 // ---- optimizer: rnvp_adam.hip -----------------------------------------------------------
 int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,

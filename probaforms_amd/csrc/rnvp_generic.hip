@@ -16,6 +16,7 @@
 #include <atomic>
 
 #include "rnvp_common.h"
+#include "rnvp_generic_net.h"
 
 namespace rnvp {
 namespace {
@@ -31,51 +32,6 @@ struct Tiling {
     int threads;   // blockDim.x
     size_t lds;    // dynamic LDS bytes
 };
-
-__device__ __forceinline__ float act_fwd(float v, int act) {
-    return act == RNVP_ACT_TANH ? tanhf(v) : fmaxf(v, 0.f);
-}
-
-// One s/t net (Linear, act, ..., Linear) for row t of the block; buffers are LDS [feature][TBP].
-// KEEP: every hidden activation vector is kept, consecutively, in buf0 (for the backward).
-// Otherwise buf0/buf1 ping-pong.
-template <bool KEEP>
-__device__ void net_forward(const float *__restrict__ p, const KShape &s, const float *in,
-                            float *buf0, float *buf1, float *out, int TBP, int t) {
-    const float *cur = in;
-    float *dst = buf0;
-    for (int k = 0; k <= s.nh; ++k) {
-        const int nin = s.nin[k], nout = s.nout[k];
-        const float *__restrict__ W = p + s.woff[k];
-        const float *__restrict__ b = p + s.boff[k];
-        float *ob = (k < s.nh) ? dst : out;
-        for (int o = 0; o < nout; o += 4) {
-            const int o1 = min(o + 1, nout - 1), o2 = min(o + 2, nout - 1), o3 = min(o + 3, nout - 1);
-            const float *w0 = W + o * nin, *w1 = W + o1 * nin, *w2 = W + o2 * nin, *w3 = W + o3 * nin;
-            float a0 = b[o], a1 = b[o1], a2 = b[o2], a3 = b[o3];
-            for (int i = 0; i < nin; ++i) {
-                const float v = cur[i * TBP + t];
-                a0 = fmaf(v, w0[i], a0);
-                a1 = fmaf(v, w1[i], a1);
-                a2 = fmaf(v, w2[i], a2);
-                a3 = fmaf(v, w3[i], a3);
-            }
-            if (k < s.nh) {
-                a0 = act_fwd(a0, s.act); a1 = act_fwd(a1, s.act);
-                a2 = act_fwd(a2, s.act); a3 = act_fwd(a3, s.act);
-            }
-            ob[o * TBP + t] = a0;
-            if (o + 1 < nout) ob[(o + 1) * TBP + t] = a1;
-            if (o + 2 < nout) ob[(o + 2) * TBP + t] = a2;
-            if (o + 3 < nout) ob[(o + 3) * TBP + t] = a3;
-        }
-        cur = ob;
-        if (k < s.nh) {
-            if (KEEP) dst += nout * TBP;
-            else dst = (dst == buf0) ? buf1 : buf0;
-        }
-    }
-}
 
 // ---- forward + log-det + prior (realnvp.py:91-101, nflow.py:107-117) ---------------------
 __global__ void __launch_bounds__(256)
@@ -179,76 +135,6 @@ k_generic_inverse(KShape s, const float *__restrict__ params, const uint8_t *__r
         }
         for (int j = 0; j < d; ++j) x_out[row * d + j] = xcur[j * TBP + t];
     }
-}
-
-// ---- backward of one net for the block's tile ----------------------------------------------
-// gA holds d(loss)/d(net output) [d][TBP] on entry.  Weight/bias gradients are summed over the
-// tile's rows by a "thread = parameter" sweep and stored (first tile) or added into the
-// block-private partial gp (same layout as one net's parameters).  d(loss)/d(net input) for
-// the x part is ADDED into gin [d][TBP].  Uniform control flow: contains barriers.
-__device__ void net_backward(const float *__restrict__ p, float *gp, const KShape &s,
-                             const float *uin, const float *acts, float *gA, float *gB, float *gin,
-                             int TB, int TBP, int t, int nthreads, bool first) {
-    float *gcur = gA, *gprev = gB;
-    int aoff = s.hs;   // running offset (in features) of Linear k's own activation block
-    for (int k = s.nh; k >= 0; --k) {
-        const int nin = s.nin[k], nout = s.nout[k];
-        if (k < s.nh) aoff -= nout;
-        const float *ak = acts + aoff * TBP;                               // act output of Linear k
-        const float *inp = (k == 0) ? uin : acts + (aoff - s.nin[k]) * TBP;  // its input
-        if (k < s.nh && t < TB) {
-            for (int q = 0; q < nout; ++q) {
-                const float a = ak[q * TBP + t];
-                const float g = gcur[q * TBP + t];
-                gcur[q * TBP + t] = (s.act == RNVP_ACT_TANH) ? g * (1.f - a * a) : (a > 0.f ? g : 0.f);
-            }
-        }
-        __syncthreads();
-        // weight gradient: thread = (q, i)
-        float *gW = gp + s.woff[k], *gb = gp + s.boff[k];
-        for (int idx = t; idx < nout * nin; idx += nthreads) {
-            const int q = idx / nin, i = idx - q * nin;
-            const float *gq = gcur + q * TBP, *xi = inp + i * TBP;
-            float a = 0.f;
-            for (int r = 0; r < TB; ++r) a = fmaf(gq[r], xi[r], a);
-            gW[idx] = first ? a : gW[idx] + a;
-        }
-        for (int q = t; q < nout; q += nthreads) {
-            const float *gq = gcur + q * TBP;
-            float a = 0.f;
-            for (int r = 0; r < TB; ++r) a += gq[r];
-            gb[q] = first ? a : gb[q] + a;
-        }
-        // input gradient: thread = row.  For Linear 0 only the x part is needed (C gets none).
-        if (t < TB) {
-            const float *__restrict__ W = p + s.woff[k];
-            const int ni = (k == 0) ? s.d : nin;
-            float *dst = (k == 0) ? gin : gprev;
-            for (int i = 0; i < ni; i += 4) {
-                const int i1 = min(i + 1, ni - 1), i2 = min(i + 2, ni - 1), i3 = min(i + 3, ni - 1);
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int q = 0; q < nout; ++q) {
-                    const float g = gcur[q * TBP + t];
-                    const float *w = W + q * nin;
-                    a0 = fmaf(g, w[i], a0); a1 = fmaf(g, w[i1], a1);
-                    a2 = fmaf(g, w[i2], a2); a3 = fmaf(g, w[i3], a3);
-                }
-                if (k == 0) {
-                    dst[i * TBP + t] += a0;
-                    if (i + 1 < ni) dst[(i + 1) * TBP + t] += a1;
-                    if (i + 2 < ni) dst[(i + 2) * TBP + t] += a2;
-                    if (i + 3 < ni) dst[(i + 3) * TBP + t] += a3;
-                } else {
-                    dst[i * TBP + t] = a0;
-                    if (i + 1 < ni) dst[(i + 1) * TBP + t] = a1;
-                    if (i + 2 < ni) dst[(i + 2) * TBP + t] = a2;
-                    if (i + 3 < ni) dst[(i + 3) * TBP + t] = a3;
-                }
-            }
-        }
-        float *tmp = gcur; gcur = gprev; gprev = tmp;
-    }
-    __syncthreads();
 }
 
 // ---- loss + gradient (realnvp.py:246-250; backward derived in SURVEY.md 3.3) ---------------
@@ -407,6 +293,22 @@ int grid_for(int64_t n, int TB, int cap) {
 }
 
 }  // namespace
+
+// grad_out[p] = sum_b gpart[b][p] (skipped when gpart is NULL); loss_out = loss_scale * sum_b losspart[b]
+int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
+                            float loss_scale, float *grad_out, float *loss_out) {
+    if (gpart && grad_out) {
+        const int rb = 256;
+        hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((P + rb - 1) / rb)), dim3(rb), 0, st, gpart, losspart, G, P,
+                           loss_scale, grad_out, loss_out);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
+    if (loss_out) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, losspart, G, loss_scale, loss_out);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
+    return RNVP_OK;
+}
 
 size_t generic_workspace_bytes(const KShape &k, int op, int64_t max_rows) {
     Tiling tl;

@@ -1,0 +1,204 @@
+"""Conditional VAE, MI355X build (BASELINE.json configs[4]).
+
+Mirrors `probaforms.models.cvae` (/root/reference/probaforms/models/cvae.py): `Encoder`, `Decoder`
+and `CVAE(GenModel)` with the reference's constructor defaults, `state_dict` keys
+(`model.{2k}.weight`, `mu.weight`, `log_sigma.weight`, ...), RNG consumption (networks are RE-BUILT
+on every fit, cvae.py:164-184; eps for sample_z and the latent draws of `sample` come from the
+global CPU generator, cvae.py:187,285) and return values (`fit` returns self; `loss_history` holds
+one full-data loss per epoch).  The encoder, the reparameterisation, the decoder, the KL + MSE loss,
+their backward and Adam run in librnvp_hip.so (include/cvae_hip.h, include/rnvp_hip.h).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from .._engine import (FlatAdam, all_reduce_sum, batch_bounds, broadcast_, default_device, dist_info,
+                       flatten_parameters, is_flat, loader_permutation, require_hip, shard_bounds)
+from .interfaces import GenModel
+
+DEVICE = default_device()
+
+
+def _trunk(n_inputs, hidden, activation):
+    widths = [n_inputs] + list(hidden)
+    net = nn.Sequential()
+    for w_in, w_out in zip(widths[:-1], widths[1:]):
+        net.append(nn.Linear(w_in, w_out))
+        net.append(nn.Tanh() if activation == 'tanh' else nn.ReLU())
+    return net
+
+
+class _CvaeCore:
+    """flat storage shared by an Encoder/Decoder pair, in the order include/cvae_hip.h expects"""
+
+    def __init__(self, encoder, decoder, d, c, lat, hidden, activation, device):
+        require_hip(device)
+        self.device = torch.device(device)
+        self.shape = _hip.CvaeShape.make(d, c, lat, hidden, activation)
+        e, dd = encoder, decoder
+        trunk = [p for m in e.model if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
+        heads = [e.mu.weight, e.log_sigma.weight, e.mu.bias, e.log_sigma.bias]        # ONE Linear of 2*lat outputs
+        dec = [p for m in dd.model if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
+        self.plist = trunk + heads + dec
+        self.P = sum(p.numel() for p in self.plist)
+        assert self.P == _hip.cvae_param_count(self.shape)
+        self.flat = None
+        self.ws = None
+        self.gbuf = None
+        self.sync()
+
+    def sync(self):
+        if not is_flat(self.plist, self.flat):
+            self.flat = flatten_parameters(self.plist, self.device)
+        return self.flat[:self.P]
+
+    def workspace(self, rows):
+        nb = _hip.cvae_workspace_bytes(self.shape, rows)
+        if self.ws is None or self.ws.numel() < nb:
+            self.ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    def grads(self):
+        if self.gbuf is None:
+            self.gbuf = torch.zeros(self.P + 1 + (-(self.P + 1)) % 4, dtype=torch.float32, device=self.device)
+        return self.gbuf
+
+
+def _dev(t, device):
+    return None if t is None else torch.as_tensor(t, dtype=torch.float32).to(device).contiguous()
+
+
+class Encoder(nn.Module):
+    """[X || C] -> hidden MLP -> (mu, log_sigma)   (cvae.py:14-64)"""
+
+    def __init__(self, n_inputs, lat_size, hidden=(10,), activation='tanh'):
+        super().__init__()
+        self.model = _trunk(n_inputs, hidden, activation)
+        self.mu = nn.Linear(hidden[-1], lat_size)              # creation order = RNG order: trunk, mu, log_sigma
+        self.log_sigma = nn.Linear(hidden[-1], lat_size)
+        self._core = None
+
+    def forward(self, X, C=None):
+        core = self._core
+        if core is None:
+            raise RuntimeError("Encoder must belong to a CVAE (its weights live in the CVAE's flat HIP buffer)")
+        X, C = _dev(X, core.device), _dev(C, core.device)
+        n = X.shape[0]
+        mu = torch.empty(n, core.shape.lat, device=core.device); ls = torch.empty_like(mu)
+        _hip.cvae_encode(core.shape, core.sync(), X, C, n, mu, ls)
+        return mu, ls
+
+
+class Decoder(nn.Module):
+    """[Z || C] -> hidden MLP -> X_rec   (cvae.py:68-113)"""
+
+    def __init__(self, n_inputs, n_outputs, hidden=(10,), activation='tanh'):
+        super().__init__()
+        self.model = _trunk(n_inputs, hidden, activation)
+        self.model.append(nn.Linear(hidden[-1], n_outputs))
+        self._core = None
+
+    def forward(self, X, C=None):
+        core = self._core
+        if core is None:
+            raise RuntimeError("Decoder must belong to a CVAE (its weights live in the CVAE's flat HIP buffer)")
+        Z, C = _dev(X, core.device), _dev(C, core.device)
+        out = torch.empty(Z.shape[0], core.shape.d, device=core.device)
+        _hip.cvae_decode(core.shape, core.sync(), Z, C, Z.shape[0], out)
+        return out
+
+
+class CVAE(GenModel):
+    """Conditional VAE with the reference's interface (cvae.py:116-291).
+
+    CVAE(latent_dim=2, hidden=(10,), activation='tanh', batch_size=32, n_epochs=10, lr=1e-4,
+         weight_decay=0, KL_weight=0.001, verbose=0); fit(X, C=None) -> self; sample(C=10)."""
+
+    def __init__(self, latent_dim=2, hidden=(10,), activation='tanh', batch_size=32, n_epochs=10, lr=0.0001,
+                 weight_decay=0, KL_weight=0.001, verbose=0):
+        super().__init__()
+        self.lat_size = latent_dim
+        self.hidden = hidden
+        self.activation = activation
+        self.batch_size = batch_size
+        self.n_epochs = n_epochs
+        self.latent_dim = latent_dim
+        self.lr = lr
+        self.weight_decay = weight_decay
+        self.KL_weight = KL_weight
+        self.verbose = verbose
+        self.opt = None
+        self._core = None
+
+    def _model_init(self, X, C=None):
+        """fresh networks and optimizer on EVERY fit, as the reference (cvae.py:157-184)"""
+        require_hip(DEVICE)
+        c_len = 0 if C is None else C.shape[1]
+        self.encoder = Encoder(X.shape[1] + c_len, self.lat_size, self.hidden, self.activation)
+        self.decoder = Decoder(self.lat_size + c_len, X.shape[1], self.hidden, self.activation)
+        core = _CvaeCore(self.encoder, self.decoder, X.shape[1], c_len, self.lat_size, self.hidden,
+                         self.activation, DEVICE)
+        self.encoder._core = self.decoder._core = self._core = core
+        _, world = dist_info()
+        if world > 1:
+            broadcast_(core.flat, 0)
+        self.opt = FlatAdam(core.flat.numel(), core.device, lr=self.lr, weight_decay=self.weight_decay)
+
+    def compute_loss(self, x_batch, cond_batch):
+        """KL_weight * KL + MSE on one batch with freshly drawn eps (cvae.py:195-203); no autograd graph"""
+        core = self._core
+        x, c = _dev(x_batch, core.device), _dev(cond_batch, core.device)
+        n = x.shape[0]
+        eps = torch.randn(n, self.lat_size).to(core.device)                       # cvae.py:187 (CPU generator)
+        loss = torch.zeros(1, device=core.device)
+        _hip.cvae_loss_grad(core.shape, core.sync(), x, c, None, eps, n, 1.0 / n, self.KL_weight, None, loss,
+                            core.workspace(n))
+        return loss.reshape(())
+
+    def fit(self, X, C=None):
+        self._model_init(X, C)
+        core = self._core
+        dev = core.device
+        Xd = torch.tensor(np.asarray(X), dtype=torch.float, device=dev).contiguous()
+        Cd = None if C is None else torch.tensor(np.asarray(C), dtype=torch.float, device=dev).contiguous()
+        n = Xd.shape[0]
+        rank, world = dist_info()
+        self.loss_history = []
+        bounds = batch_bounds(n, self.batch_size)
+        lr, b1, b2, eps_adam, wd = self.opt.hyper
+        bar = None
+        if self.verbose >= 1:
+            from tqdm.auto import tqdm
+            bar = tqdm(total=self.n_epochs, unit='epoch')
+        for epoch in range(self.n_epochs):
+            perm = loader_permutation(n).to(dev)                                   # DataLoader(shuffle=True), cvae.py:235
+            for (s, e) in bounds:
+                B = e - s
+                eps = torch.randn(B, self.lat_size).to(dev)                        # sample_z, cvae.py:187
+                g = core.grads()
+                lo, hi = (s, e) if world == 1 else shard_bounds(s, e, rank, world)
+                _hip.cvae_loss_grad(core.shape, core.sync(), Xd, Cd, perm[lo:hi], eps[lo - s:hi - s], hi - lo,
+                                    1.0 / B, self.KL_weight, g[:core.P], g[core.P:core.P + 1], core.workspace(B))
+                if world > 1:
+                    all_reduce_sum(g[:core.P + 1])
+                self.opt.step_count += 1
+                _hip.adam_step(core.sync(), g[:core.P], self.opt.exp_avg[:core.P], self.opt.exp_avg_sq[:core.P],
+                               core.P, lr, b1, b2, eps_adam, wd, self.opt.step_count)
+            loss_epoch = self.compute_loss(Xd, Cd)                                 # cvae.py:254-259
+            self.loss_history.append(loss_epoch.detach().cpu())
+            if bar is not None:
+                bar.update(1); bar.set_description("loss: %.4f" % float(loss_epoch))
+        if bar is not None:
+            bar.close()
+        return self
+
+    def sample(self, C=10):
+        core = self._core
+        if type(C) != type(1):
+            Z = torch.normal(0, 1, (len(C), self.lat_size))                        # cvae.py:285 (CPU generator)
+            X = self.decoder(Z, torch.tensor(np.asarray(C), dtype=torch.float, device=core.device))
+        else:
+            Z = torch.normal(0, 1, (C, self.lat_size))
+            X = self.decoder(Z, None)
+        return X.cpu().detach().numpy()

@@ -1,0 +1,109 @@
+"""CVAE on the GPU: HIP kernels through the C ABI (include/cvae_hip.h)
+against the reference's own fixtures and the oracle; seeded end-to-end fit/sample against the
+reference; the reference's API contract (tests/test_models.py) for the CVAE class."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"default": (5, 3, 2, (10,), "tanh", 0.001), "nocond": (5, 0, 2, (10,), "tanh", 0.001),
+         "c5": (16, 4, 2, (128,), "tanh", 0.001), "relu_mh": (4, 2, 3, (7, 9), "relu", 0.5)}
+
+
+def _dev(a):
+    return None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda().contiguous()
+
+
+def _load(name):
+    from probaforms_amd import _hip
+    d, c, lat, hidden, act, klw = CASES[name]
+    g = np.load(os.path.join(GOLDEN, "cvae_%s.npz" % name))
+    shape = _hip.CvaeShape.make(d, c, lat, hidden, act)
+    assert _hip.cvae_param_count(shape) == g["init_params"].size
+    return _hip, g, shape, klw, (g["C"] if c else None)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encode_decode(name):
+    _hip, g, shape, klw, C = _load(name)
+    n = g["X"].shape[0]
+    p = _dev(g["init_params"])
+    mu = torch.empty(n, shape.lat, device="cuda"); ls = torch.empty_like(mu)
+    _hip.cvae_encode(shape, p, _dev(g["X"]), _dev(C), n, mu, ls)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ls.cpu().numpy(), g["log_sigma"], rtol=2e-6, atol=2e-6)
+    x = torch.empty(n, shape.d, device="cuda")
+    _hip.cvae_decode(shape, p, _dev(g["Z"]), _dev(C), n, x)
+    np.testing.assert_allclose(x.cpu().numpy(), g["decoded"], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_loss_grad_and_adam(name):
+    from oracle import CvaeOracle, CvaeShape
+    _hip, g, shape, klw, C = _load(name)
+    d, c, lat, hidden, act, _ = CASES[name]
+    n = g["X"].shape[0]; P = g["init_params"].size
+    x, cc = _dev(g["X"]), _dev(C)
+    ws = torch.empty(_hip.cvae_workspace_bytes(shape, n), dtype=torch.uint8, device="cuda")
+    grad = torch.full((P,), float("nan"), device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.cvae_loss_grad(shape, _dev(g["init_params"]), x, cc, None, _dev(g["eps"]), n, 1.0 / n, klw, grad, loss, ws)
+    assert abs(float(loss) - g["loss"]) < 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert np.abs(grad.cpu().numpy() - g["grad"]).max() < 3e-6 * np.abs(g["grad"]).max() + 1e-9
+    # loss only (per-epoch evaluation) + gathered / sharded batch vs the oracle
+    l2 = torch.empty(1, device="cuda")
+    _hip.cvae_loss_grad(shape, _dev(g["init_params"]), x, cc, None, _dev(g["eps"]), n, 1.0 / n, klw, None, l2, ws)
+    assert float(l2) == float(loss)
+    perm = np.random.default_rng(1).permutation(n).astype(np.int64)
+    idx = torch.from_numpy(perm).cuda()
+    a = torch.empty(P + 1, device="cuda"); b = torch.empty(P + 1, device="cuda"); k = 17
+    eps = _dev(g["eps"])
+    _hip.cvae_loss_grad(shape, _dev(g["init_params"]), x, cc, idx[:k], eps[:k], k, 1.0 / n, klw, a[:P], a[P:], ws)
+    _hip.cvae_loss_grad(shape, _dev(g["init_params"]), x, cc, idx[k:].contiguous(), eps[k:].contiguous(), n - k, 1.0 / n, klw,
+                        b[:P], b[P:], ws)
+    o = CvaeOracle(32); s = CvaeShape.make(d, c, lat, hidden, act)
+    lo, go = o.loss_grad(s, g["init_params"], g["X"][perm], None if C is None else C[perm], g["eps"], klw)
+    tot = (a + b).cpu().numpy()
+    assert abs(tot[P] - lo) < 5e-6 * max(1.0, abs(lo))
+    assert np.abs(tot[:P] - go).max() < 5e-6 * np.abs(go).max() + 1e-9
+    # 3 Adam steps against the reference's trajectory
+    p = _dev(g["init_params"]).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+    for step in range(3):
+        _hip.cvae_loss_grad(shape, p, x, cc, None, _dev(g["adam_eps"][step]), n, 1.0 / n, klw, grad, loss, ws)
+        assert abs(float(loss) - g["adam_loss"][step]) < 5e-5 * max(1.0, abs(float(loss)))
+        _hip.adam_step(p, grad, m, v, P, 0.01, 0.9, 0.999, 1e-8, 0.0, step + 1)
+        assert np.abs(p.cpu().numpy() - g["adam_p"][step]).mean() < 2e-6
+
+
+@pytest.mark.parametrize("name", ["default", "nocond", "relu_mh"])
+def test_seeded_fit_and_sample_match_reference(name):
+    """same seed -> same init, same shuffle, same eps stream, same latent draws as the reference CVAE"""
+    from probaforms_amd.models import CVAE
+    d, c, lat, hidden, act, klw = CASES[name]
+    g = np.load(os.path.join(GOLDEN, "cvae_%s.npz" % name))
+    X, C = g["X"], (g["C"] if c else None)
+    m = CVAE(latent_dim=lat, hidden=hidden, activation=act, KL_weight=klw, lr=0.01, n_epochs=3, batch_size=16)
+    torch.manual_seed(5)
+    assert m.fit(X, C) is m
+    hist = np.array([float(v) for v in m.loss_history], np.float32)
+    np.testing.assert_allclose(hist, g["fit_loss_history"], rtol=2e-4, atol=2e-5)
+    xs = m.sample(C if C is not None else X.shape[0])
+    assert xs.shape == g["fit_sample"].shape and xs.dtype == np.float32
+    assert np.abs(xs - g["fit_sample"]).max() < 2e-3
+    sd = m.encoder.state_dict()
+    assert list(sd)[-4:] == ["mu.weight", "mu.bias", "log_sigma.weight", "log_sigma.bias"]
+    m.fit(X, C)                                                      # re-initialises: history restarts
+    assert len(m.loss_history) == 3
+
+
+def test_api_contract_like_reference_tests():
+    from probaforms_amd.models import CVAE
+    n = 100
+    X = np.random.normal(size=(n, 5)); C = np.random.normal(size=(n, 3))
+    gen = CVAE(); gen.fit(X, C)
+    assert gen.sample(C).shape == X.shape
+    gen = CVAE(); gen.fit(X, C=None)
+    assert gen.sample(C=n).shape == X.shape

@@ -15,8 +15,8 @@ from probaforms_amd.models import GenModel, RealNVP, RealNVPLayer, StandardNorma
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "rnvp_hip.h")).read()
-    declared = set(re.findall(r"\b(rnvp_[a-z_]+)\s*\(", hdr))
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("rnvp_hip.h", "cvae_hip.h"))
+    declared = set(re.findall(r"\b((?:rnvp|cvae)_[a-z_]+)\s*\(", hdr))
     assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
