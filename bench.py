@@ -113,10 +113,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_ONE_GPU=1 (developer aid): run the N-rank code path on a 1-GPU box -- every rank on cuda:0,
+    # gloo instead of RCCL.  Never used by the driver; numbers from it mean nothing.
+    one_gpu = os.environ.get("BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -152,12 +160,19 @@ def main():
         s, e = bounds[i % (len(bounds) - 1)]                          # full batches only
         rows = perm[s:e]
         g = eng.loss_grad(X, C, rows, e - s, inv_B)
-        if world > 1:
-            _engine.all_reduce_sum(g[:P + 1])
-        losses[i:i + 1].copy_(g[P:P + 1])
-        eng.adam(opt)
         c_rows = C[s:e]                                               # conditions of the sampled rows
-        eng.inverse(z, c_rows, out=xs)
+        if world > 1:
+            # the gradient all-reduce (RCCL, its own stream) runs under the sampling kernel, which
+            # does not depend on it; Adam waits for the reduced gradient
+            work = dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM, async_op=True)
+            eng.inverse(z, c_rows, out=xs)
+            work.wait()
+            losses[i:i + 1].copy_(g[P:P + 1])
+            eng.adam(opt)
+        else:
+            losses[i:i + 1].copy_(g[P:P + 1])
+            eng.adam(opt)
+            eng.inverse(z, c_rows, out=xs)
 
     for i in range(args.warmup):
         step(i)

@@ -13,6 +13,12 @@ for p in (ROOT, GOLDEN):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HIP library and the oracle are built in-tree (hipcc cross-compiles without a GPU); build them
+    # if a fresh checkout has not done so yet, so that the suite does not depend on a prior build step
+    lib = os.path.join(ROOT, "probaforms_amd", "csrc", "librnvp_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.dirname(lib), "-j4", "-s"])
 
 
 def pytest_collection_modifyitems(config, items):
