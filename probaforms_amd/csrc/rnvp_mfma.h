@@ -34,7 +34,7 @@ struct Geo {
     int NTI;    // N tiles of the W1 gradient (KS1*4 input columns + 1 ones column for the bias)
     int MTI;    // M tiles of the input gradient: max(1, NF / 4)
     // float offsets inside one layer's packed block
-    int oA1, oB1, oA2, oB2, oA2T, oA1T, layer_floats;
+    int oA1, oB1, oA2, oB2, oA2T, oA1T, oA2X, oA1X, layer_floats;
     // packed gradient block of one layer
     int oG1, oG2, oGb2, glayer_floats;
 };
@@ -54,6 +54,10 @@ __host__ __device__ inline Geo make_geo(int d, int c, int h) {
     g.oB2 = o; o += g.NT2 * 16;                     // [ot][q][4]
     g.oA2T = o; o += 2 * g.HT * g.OTL * 256;        // [tile][otl][lane][4 (rho)]   (backward: W2^T)
     g.oA1T = o; o += 2 * g.HT * g.MTI * 256;        // [tile][mt][lane][4 (rho)]    (backward: W1^T)
+    // d == 16 only: per-lane fragments of the 4x4x1 (16-block) MFMA forms of GEMM2 and of the
+    // input-gradient product, which avoid the structural zeros of the shared t|s out tile
+    g.oA2X = o; o += (g.NF == 2) ? 2 * g.HT * 2 * 256 : 0;   // [tile][og][lane][4 (rho)]
+    g.oA1X = o; o += (g.NF == 2) ? 2 * g.HT * 2 * 256 : 0;   // [tile][og][lane][4 (rho)]
     g.layer_floats = o;
     o = 0;
     g.oG1 = o; o += 2 * g.HT * g.NTI * 256;         // [tile][nt][lane][4]: dW1 (+ db1 in the ones column)

@@ -77,6 +77,24 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         if (net_out != net) return 0.f;
         return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, q, f, pc) * h + hid];
     }
+    if (idx >= g.oA1X) {                                   // A1X [tile][og][lane][4 rho]  (d == 16)
+        // 4x4x1 blocks: lane (q, r), i = r & 3 supplies W1[hid 16t+4q+rho][conditioning feature (og, i)],
+        // feature owner q_f = 2*og + (i >> 1), slot f = i & 1
+        const int j = idx - g.oA1X;
+        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int og = rest & 1, tile = rest >> 1;
+        const int q = lane >> 4, i = lane & 3, net = tile / g.HT;
+        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
+        return pl[net * k.npn + k.woff[0] + hid * nin + feat_cond(g.NF, 2 * og + (i >> 1), i & 1, pc)];
+    }
+    if (idx >= g.oA2X) {                                   // A2X [tile][og][lane][4 rho]  (d == 16)
+        const int j = idx - g.oA2X;
+        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int og = rest & 1, tile = rest >> 1;
+        const int q = lane >> 4, i = lane & 3, net = tile / g.HT;
+        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
+        return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, 2 * og + (i >> 1), i & 1, pc) * h + hid];
+    }
     {                                                      // A1T [tile][mt][lane][4 rho]
         const int j = idx - g.oA1T;
         const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;

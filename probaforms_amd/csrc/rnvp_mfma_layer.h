@@ -24,8 +24,31 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 16 independent 4x4x1 outer products: D_b[i][j] (VGPR i of lane 4b+j) += A_b[i] (lane 4b+i) * B_b[j]
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// reduce-scatter steps across the 4 lane groups q = lane >> 4 (v_permlane32_swap / v_permlane16_swap):
+// lanes of the lower half (q < 2) end with x(own) + x(partner q ^ 2), the upper half with y + y(partner)
+__device__ __forceinline__ float swap_add32(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// even 16-lane rows (q & 1 == 0) end with x(own) + x(partner q ^ 1), odd rows with y + y(partner)
+__device__ __forceinline__ float swap_add16(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 #ifndef RNVP_ABLATE
 #define RNVP_ABLATE 0
+#endif
+// RNVP_NO_X4: developer switch to fall back to the shared-tile 16x16x4 GEMM2 for d == 16 (A/B timing)
+#ifdef RNVP_NO_X4
+constexpr bool kUseX4 = false;
+#else
+constexpr bool kUseX4 = true;
 #endif
 
 // tanh(v) = 1 - 2 / (1 + e^{2v}) with u = 2*log2(e)*v arriving PRE-SCALED: k_pack_weights folds
@@ -164,6 +187,106 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
     }
 }
 
+// d == 16 (NF == 2): the t and s nets would share ONE 16-row out tile in which every hidden tile
+// multiplies 8 rows of structural zeros.  Here GEMM2 runs instead as 16 independent 4x4x1 blocks per
+// instruction: block (q, rg = r >> 2) multiplies the lane group's own hidden unit 16t+4q+rho (B = the
+// GEMM1 accumulator register, as before) by 4 outputs (A, pre-packed per lane) for rows 4rg..4rg+3.
+// Partial sums over the lane groups q are combined once per layer by a two-step reduce-scatter.
+// Measured on MI355X: 8 x 4x4x1 take 37 ns against 58 ns for the 4 x 16x16x4 they replace.
+template <int CQ, int R, int PC, int NET>
+__device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const Geo &g, int lane, int tile0,
+                                             int ntiles, const float (&xr)[R][4],
+                                             const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4]) {
+    constexpr int NF = 2;
+    using D = FwdDims<NF, CQ>;
+    constexpr int K4 = D::K4;
+    const int q = lane >> 4;
+    const float *pA1 = W + g.oA1 + ((size_t)tile0 * K4 * 64 + lane) * 4;
+    const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
+    const float *pA2 = W + g.oA2X + ((size_t)tile0 * 2 * 64 + lane) * 4;
+    const int last = ntiles - 1;
+    f4 a1n[K4], b1n, a2c[2], acc[R];
+    {
+        f4 a1c[K4], b1c;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1c[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
+        b1c = *reinterpret_cast<const f4 *>(pB1);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) a2c[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
+        const int t1 = last < 1 ? last : 1;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
+        b1n = *opaque(pB1 + t1 * 16);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
+    }
+    for (int t = 0; t < last; ++t) {
+        const int t2 = (t + 2 < last) ? t + 2 : last;
+        f4 a1f[K4], b1f, a2f[2];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1f[k4] = *opaque(pA1 + ((size_t)t2 * K4 + k4) * 256);
+        b1f = *opaque(pB1 + t2 * 16);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) a2f[o] = *opaque(pA2 + ((size_t)(t + 1) * 2 + o) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        f4 accn[R], hv[R];
+        constexpr int RB = (R % 2 == 0) ? 2 : 1;
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += RB) {           // phase A: GEMM1 of tile t+1 || tanh of tile t
+#pragma unroll
+            for (int u = 0; u < RB; ++u) accn[r0 + u] = b1n;
+#pragma unroll
+            for (int kk = 0; kk < NF + CQ; ++kk)
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    accn[r0 + u] = mfma16(a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), accn[r0 + u]);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) hv[r0 + u] = tanh4(acc[r0 + u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)              // phase B: 4x4x1 GEMM2, 2R independent chains
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt)
+                    outx[rt][2 * NET + o] = mfma4(a2c[o][rho], hv[rt][rho], outx[rt][2 * NET + o]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) acc[rt] = accn[rt];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = a1f[k4];
+        b1n = b1f;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) a2c[o] = a2f[o];
+    }
+    {
+        f4 hv[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) hv[rt] = tanh4(acc[rt]);
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt)
+                    outx[rt][2 * NET + o] = mfma4(a2c[o][rho], hv[rt][rho], outx[rt][2 * NET + o]);
+    }
+}
+
+// partial sums over lane groups -> each lane keeps (net, slot f) of the features it owns:
+// out (og, i) belongs to lane group 2*og + (i >> 1), slot i & 1
+__device__ __forceinline__ void reduce_scatter_x4(const f4 (&part)[4], float (&tv)[2], float (&sv)[2]) {
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        float s4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s4[i] = swap_add32(part[2 * net][i], part[2 * net + 1][i]);
+        const float f0 = swap_add16(s4[0], s4[2]), f1 = swap_add16(s4[1], s4[3]);
+        if (net == 0) { tv[0] = f0; tv[1] = f1; } else { sv[0] = f0; sv[1] = f1; }
+    }
+}
+
 // MODE 0: forward (x*exp(s)+t, log-det)   realnvp.py:99-100
 // MODE 1: inverse ((x-t)*exp(-s))          realnvp.py:128
 // MODE 2: forward, also writing the layer input of the transformed features and exp(s) to scr
@@ -175,17 +298,34 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4;
     f4 out[R][NT2];
+    const f4 bias2 = *reinterpret_cast<const f4 *>(W + g.oB2 + q * 4);      // out tile 0 (all of it when NF == 2)
+    if constexpr (NF == 2 && kUseX4) {
+        f4 outx[R][4];
 #pragma unroll
-    for (int ot = 0; ot < NT2; ++ot) {
-        const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+        for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
-    }
-    if (NF >= 4) {      // each net feeds its own out tiles
-        run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
-        run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
-    } else {            // t and s share one out tile: one pipelined pass over all 2*HT tiles
-        run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, 2 * g.HT, xr, cr, out);
+            for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
+        run_tiles_x4<CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, outx);
+        run_tiles_x4<CQ, R, PC, 1>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            float tv[2], sv[2];
+            reduce_scatter_x4(outx[rt], tv, sv);
+            out[rt][0] = f4{tv[0], tv[1], sv[0], sv[1]} + bias2;              // same slots as the shared tile
+        }
+    } else {
+#pragma unroll
+        for (int ot = 0; ot < NT2; ++ot) {
+            const f4 b = (ot == 0) ? bias2 : *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
+        }
+        if (NF >= 4) {      // each net feeds its own out tiles
+            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
+        } else {            // t and s share one out tile: one pipelined pass over all 2*HT tiles
+            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, 2 * g.HT, xr, cr, out);
+        }
     }
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {

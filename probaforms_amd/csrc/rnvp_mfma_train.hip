@@ -88,8 +88,8 @@ template <int NF, int CQ> struct Dims {
     static constexpr int MTI = OTL;                   // M tiles of the input gradient
     static constexpr int KSP = 4 * KP4;               // input columns per lane group
     static constexpr int SIN = 16 * NTI + 4;          // row stride of the input transposition tile
-    // LDS scratch per wave: g_out^T staging (NT2 tiles), [in|1]^T staging, and 2 tiles (h, g_pre) per row tile
-    template <int R> static constexpr int tb() { return NT2 * 16 * kTS + 16 * SIN + 2 * R * 16 * kTS; }
+    // LDS scratch per wave: g_out^T staging (NT2 tiles), [in|1]^T staging, and 2 tiles (h, g_pre) per row tile of a sub-pass
+    template <int R> static constexpr int tb() { return NT2 * 16 * kTS + 16 * SIN + 2 * (R >= 4 ? 2 : R) * 16 * kTS; }
 #ifdef RNVP_TRAIN_FT
     static constexpr int FT = RNVP_TRAIN_FT;
 #else
@@ -168,11 +168,14 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) inT[rt][nt][ks] = bufI[(4 * ks + q) * SIN + 16 * nt + r];
     }
-    f4 gin[R][MTI];
+    // d == 16: the input gradient runs as 4x4x1 blocks (see run_tiles_x4): 2 x 4 partial outputs per lane
+    constexpr bool X4 = (NF == 2) && kUseX4;
+    constexpr int NGI = X4 ? 2 : MTI;
+    f4 gin[R][NGI];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-        for (int mt = 0; mt < MTI; ++mt) gin[rt][mt] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < NGI; ++mt) gin[rt][mt] = f4{0.f, 0.f, 0.f, 0.f};
     STAMP_ADD(stp.bsetup, t0);
 
     // 3. the two nets, hidden tile by hidden tile.  Hand-scheduled like the forward layer
@@ -184,120 +187,136 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
         const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
         const float *pA2T = W + g.oA2T + ((size_t)net * HT * OTL * 64 + lane) * 4;
-        const float *pA1T = W + g.oA1T + ((size_t)net * HT * MTI * 64 + lane) * 4;
-        f4 a1[K4], a2t[OTL], a1t[MTI], b1;
+        const float *pA1T = W + (X4 ? g.oA1X : g.oA1T) + ((size_t)net * HT * NGI * 64 + lane) * 4;
+        f4 a1[K4], a2t[OTL], a1t[NGI], b1;
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
         b1 = *reinterpret_cast<const f4 *>(pB1);
 #pragma unroll
         for (int o = 0; o < OTL; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + o * 256);
 #pragma unroll
-        for (int m = 0; m < MTI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + m * 256);
+        for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + m * 256);
         for (int ht = 0; ht < HT; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < HT) ? ht + 1 : ht);
-            f4 na1[K4], na2t[OTL], na1t[MTI], nb1;
+            f4 na1[K4], na2t[OTL], na1t[NGI], nb1;
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
             nb1 = *opaque(pB1 + nx * 16);
 #pragma unroll
             for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
 #pragma unroll
-            for (int m = 0; m < MTI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * MTI + m) * 256);
+            for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
             __builtin_amdgcn_sched_barrier(0);
 
-            // phase 1 (MFMA): GEMM1 recompute and g_h = W2^T g_out, chains interleaved over row tiles
-            f4 acc[R], gh[R];
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) { acc[rt] = b1; gh[rt] = f4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int kk = 0; kk < KS1; ++kk)
-#pragma unroll
-                for (int rt = 0; rt < R; ++rt)
-                    acc[rt] = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, rt, kk), acc[rt]);
-            if (NF >= 4) {
-#pragma unroll
-                for (int o = 0; o < OTL; ++o)
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho)
-#pragma unroll
-                        for (int rt = 0; rt < R; ++rt)
-                            gh[rt] = mfma16(a2t[o][rho], go[rt][(NF >= 4 ? net * OTL : 0) + o][rho], gh[rt]);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int rt = 0; rt < R; ++rt)
-                        gh[rt] = mfma16(a2t[0][2 * net + u], go[rt][0][2 * net + u], gh[rt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-
-            STAMP_ADD(stp.p1, t0);
-            // phase 2 (VALU + LDS writes): h = tanh, g_pre = g_h * (1 - h^2); both go to this wave's
-            // per-row-tile transposition tiles
-            f4 gpv[R];
-            wave_lds_fence();
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) {
-                const f4 hv = tanh4(acc[rt]);
-                gpv[rt] = gh[rt] * (1.0f - hv * hv);                                   // tanh'
-                if (!(kAblate & 1)) {
-                    *reinterpret_cast<f4 *>(bufH + (2 * rt) * 16 * kTS + r * kTS + 4 * q) = hv;
-                    *reinterpret_cast<f4 *>(bufH + (2 * rt + 1) * 16 * kTS + r * kTS + 4 * q) = gpv[rt];
-                } else {
-                    asm volatile("" ::"v"(hv));
-                }
-            }
-            wave_lds_fence();
-            __builtin_amdgcn_sched_barrier(0);
-
-            STAMP_ADD(stp.p2, t0);
-            // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
-#pragma unroll
-            for (int m = 0; m < MTI; ++m)
-#pragma unroll
-                for (int rho = 0; rho < 4; ++rho)
-#pragma unroll
-                    for (int rt = 0; rt < R; ++rt) gin[rt][m] = mfma16(a1t[m][rho], gpv[rt][rho], gin[rt][m]);
-            float hT[R][4], pT[R][4];
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (!(kAblate & 1)) {
-                        hT[rt][ks] = bufH[(2 * rt) * 16 * kTS + (4 * ks + q) * kTS + r];
-                        pT[rt][ks] = bufH[(2 * rt + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
-                    } else {
-                        hT[rt][ks] = gpv[rt][ks]; pT[rt][ks] = gpv[rt][ks];
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);
-
-            STAMP_ADD(stp.p3, t0);
-            // phase 4 (MFMA): dW2 += h g_out^T, dW1|db1 += g_pre [in|1]^T; two+ independent chains
             f4 gW2[OTL], gW1[NTI];
 #pragma unroll
             for (int o = 0; o < OTL; ++o) gW2[o] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < NTI; ++nt) gW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
-            if (!(kAblate & 32)) {
+            // The four phases run over RH row tiles at a time (two interleaved MFMA chains are enough for
+            // the 16x16x4 issue rate; holding the transients of all R tiles at once spills at 256 VGPRs).
+            constexpr int RH = (R >= 4) ? 2 : R;
 #pragma unroll
-                for (int rt = 0; rt < R; ++rt)
+            for (int r0 = 0; r0 < R; r0 += RH) {
+                // phase 1 (MFMA): GEMM1 recompute and g_h = W2^T g_out, chains interleaved over row tiles
+                f4 acc[RH], gh[RH];
+#pragma unroll
+                for (int u = 0; u < RH; ++u) { acc[u] = b1; gh[u] = f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk)
+#pragma unroll
+                    for (int u = 0; u < RH; ++u)
+                        acc[u] = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), acc[u]);
+                if (NF >= 4) {
+#pragma unroll
+                    for (int o = 0; o < OTL; ++o)
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                            for (int u = 0; u < RH; ++u)
+                                gh[u] = mfma16(a2t[o][rho], go[r0 + u][(NF >= 4 ? net * OTL : 0) + o][rho], gh[u]);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int u = 0; u < RH; ++u)
+                            gh[u] = mfma16(a2t[0][2 * net + v], go[r0 + u][0][2 * net + v], gh[u]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP_ADD(stp.p1, t0);
+
+                // phase 2 (VALU + LDS writes): h = tanh, g_pre = g_h * (1 - h^2); both go to this wave's
+                // per-row-tile transposition tiles
+                f4 gpv[RH];
+                wave_lds_fence();
+#pragma unroll
+                for (int u = 0; u < RH; ++u) {
+                    const f4 hv = tanh4(acc[u]);
+                    gpv[u] = gh[u] * (1.0f - hv * hv);                                   // tanh'
+                    if (!(kAblate & 1)) {
+                        *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
+                        *reinterpret_cast<f4 *>(bufH + (2 * u + 1) * 16 * kTS + r * kTS + 4 * q) = gpv[u];
+                    } else {
+                        asm volatile("" ::"v"(hv));
+                    }
+                }
+                wave_lds_fence();
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP_ADD(stp.p2, t0);
+
+                // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
+                if constexpr (X4) {
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int u = 0; u < RH; ++u) gin[r0 + u][m] = mfma4(a1t[m][rho], gpv[u][rho], gin[r0 + u][m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MTI; ++m)
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                            for (int u = 0; u < RH; ++u)
+                                gin[r0 + u][m] = mfma16(a1t[m][rho], gpv[u][rho], gin[r0 + u][m]);
+                }
+                float hT[RH][4], pT[RH][4];
+#pragma unroll
+                for (int u = 0; u < RH; ++u)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                        for (int o = 0; o < OTL; ++o)
-                            gW2[o] = mfma16(hT[rt][ks], goT[rt][(NF >= 4 ? net * OTL : 0) + o][ks], gW2[o]);
-#pragma unroll
-                        for (int nt = 0; nt < NTI; ++nt) gW1[nt] = mfma16(pT[rt][ks], inT[rt][nt][ks], gW1[nt]);
+                        if (!(kAblate & 1)) {
+                            hT[u][ks] = bufH[(2 * u) * 16 * kTS + (4 * ks + q) * kTS + r];
+                            pT[u][ks] = bufH[(2 * u + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
+                        } else {
+                            hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
+                        }
                     }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP_ADD(stp.p3, t0);
+
+                // phase 4 (MFMA): dW2 += h g_out^T, dW1|db1 += g_pre [in|1]^T; independent chains alternate
+                if (!(kAblate & 32)) {
 #pragma unroll
-                for (int rt = 0; rt < R; ++rt)
+                    for (int u = 0; u < RH; ++u)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[rt][ks]; gW1[0][ks] += pT[rt][ks]; }
+                        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                            for (int o = 0; o < OTL; ++o)
+                                gW2[o] = mfma16(hT[u][ks], goT[r0 + u][(NF >= 4 ? net * OTL : 0) + o][ks], gW2[o]);
+#pragma unroll
+                            for (int nt = 0; nt < NTI; ++nt) gW1[nt] = mfma16(pT[u][ks], inT[r0 + u][nt][ks], gW1[nt]);
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RH; ++u)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[u][ks]; gW1[0][ks] += pT[u][ks]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP_ADD(stp.p4, t0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP_ADD(stp.p4, t0);
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
             if (!(kAblate & 2)) {
                 float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
@@ -355,17 +374,26 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
             for (int o = 0; o < OTL; ++o) a2t[o] = na2t[o];
 #pragma unroll
-            for (int m = 0; m < MTI; ++m) a1t[m] = na1t[m];
+            for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
         }
     }
     // 4. gradient reaching the conditioning features through the nets
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt)
+    for (int rt = 0; rt < R; ++rt) {
+        if constexpr (X4) {      // partial sums over the lane groups -> the owner of each conditioning feature
+            float s4[4];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const float gi = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
-            gy[rt][2 * f + PC] += gi;
+            for (int i = 0; i < 4; ++i) s4[i] = swap_add32(gin[rt][0][i], gin[rt][1][i]);
+            gy[rt][PC] += swap_add16(s4[0], s4[2]);
+            gy[rt][2 + PC] += swap_add16(s4[1], s4[3]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float gi = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
+                gy[rt][2 * f + PC] += gi;
+            }
         }
+    }
     STAMP_ADD(stp.btail, t0);
 }
 
