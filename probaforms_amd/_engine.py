@@ -47,6 +47,54 @@ def loader_permutation(n):
     return torch.randperm(n, generator=g)
 
 
+def draw_loader_seed():
+    """the two int64 draws a fresh DataLoader iterator makes on the global CPU generator; returns the
+    RandomSampler seed (the second one)"""
+    torch.empty((), dtype=torch.int64).random_()
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def permutation_from_seed(n, seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g)
+
+
+class PermutationPrefetcher:
+    """Epoch permutations of `DataLoader(shuffle=True)` computed ahead of the GPU.
+
+    Nothing else consumes the global generator during RealNVP.fit, so the per-epoch seed draws can all
+    be made up front (same values, same final generator state as the reference's epoch-by-epoch
+    draws); the expensive `randperm(n)` calls then use PRIVATE generators and are independent, so a
+    few worker threads run them while the GPU trains (randperm releases the GIL).  At n = 1M one
+    permutation costs ~9 ms of host time against ~5 ms of GPU time per epoch."""
+
+    def __init__(self, n, n_epochs, workers=4, lookahead=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.n, self.n_epochs = n, n_epochs
+        self.seeds = [draw_loader_seed() for _ in range(n_epochs)]
+        self.lookahead = max(1, lookahead)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, min(workers, n_epochs))) if n_epochs > 1 and n >= 65536 else None
+        self.futs = {}
+        self.next_submit = 0
+
+    def _submit_upto(self, epoch):
+        while self.next_submit < self.n_epochs and self.next_submit <= epoch + self.lookahead:
+            e = self.next_submit
+            self.futs[e] = self.pool.submit(permutation_from_seed, self.n, self.seeds[e])
+            self.next_submit += 1
+
+    def get(self, epoch):
+        if self.pool is None:
+            return permutation_from_seed(self.n, self.seeds[epoch])
+        self._submit_upto(epoch)
+        return self.futs.pop(epoch).result()
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+
+
 def batch_bounds(n, batch_size):
     """[(start, stop)] of consecutive slices of the permutation; last one ragged (drop_last=False)."""
     return [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
@@ -299,8 +347,9 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     n = X.shape[0]
     bounds = batch_bounds(n, batch_size)
     dev = engine.device
+    perms = PermutationPrefetcher(n, n_epochs)
     for epoch in range(n_epochs):
-        perm = loader_permutation(n).to(dev, non_blocking=False)
+        perm = perms.get(epoch).to(dev, non_blocking=False)
         losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
         for k, (s, e) in enumerate(bounds):
             inv_B = 1.0 / (e - s)
@@ -316,4 +365,5 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
         loss_history.extend(host[i].clone() for i in range(host.numel()))
         if epoch_hook is not None:
             epoch_hook(epoch, float(host[-1]))
+    perms.close()
     return loss_history

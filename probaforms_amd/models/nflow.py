@@ -40,9 +40,10 @@ class StandardNormalPrior:
     bit-equal to the reference's distribution object (tests/golden/prior.npz) --
     which lets the kernels fold the prior term into the forward pass."""
 
-    def __init__(self, var_size, device):
+    def __init__(self, var_size, device, host_rng=True):
         self.var_size = int(var_size)
         self.device = torch.device(device)
+        self.host_rng = host_rng
         self.loc = torch.zeros(var_size)
         self.covariance_matrix = torch.eye(var_size)
 
@@ -51,6 +52,8 @@ class StandardNormalPrior:
 
     def sample(self, sample_shape=()):
         shape = tuple(sample_shape) + (self.var_size,)
+        if not self.host_rng:
+            return torch.randn(shape, device=self.device)  # throughput option: not the reference's stream
         return torch.randn(shape).to(self.device)          # host generator: the reference's CPU stream
 
 
