@@ -225,6 +225,19 @@ def main():
         if not args.no_cpu_baseline:
             params = eng.params.detach().cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(Xh, Ch, params)
+            # second half of BASELINE.json's metric: per-row log-prob MAE of the HIP path against the
+            # CPU restatement of the reference (float32 oracle, and its float64 referee) on the
+            # trained weights, 4096 rows
+            from oracle import Oracle, Shape
+            rows = 4096
+            lp = nf.log_prob_samples(X[:rows], C[:rows]).cpu().numpy()
+            sh = Shape.make(LAYERS, D, CDIM, HIDDEN, "tanh")
+            _, lp32, _ = Oracle(32).log_prob(sh, params, Xh[:rows], Ch[:rows])
+            _, lp64, _ = Oracle(64).log_prob(sh, params, Xh[:rows], Ch[:rows])
+            out["logprob_mae"] = {"vs_oracle_f32": float(np.abs(lp - lp32).mean()),
+                                  "vs_oracle_f64": float(np.abs(lp - lp64).mean()),
+                                  "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
+                                  "target": 1e-5}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
