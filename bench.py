@@ -174,6 +174,15 @@ def main():
             eng.adam(opt)
             eng.inverse(z, c_rows, out=xs)
 
+    def step1(i):
+        """single GPU: the fused rnvp_train_step (loss + gradient + Adam), as RealNVP.fit uses it"""
+        s, e = bounds[i % (len(bounds) - 1)]
+        eng.train_step(opt, X, C, perm[s:e], e - s, inv_B, losses[i:i + 1])
+        eng.inverse(z, C[s:e], out=xs)
+
+    if world == 1:
+        step = lambda i, timed_idx=None: step1(i)
+
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

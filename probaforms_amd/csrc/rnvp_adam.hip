@@ -9,26 +9,6 @@
 namespace rnvp {
 namespace {
 
-struct AdamK {
-    float step_size;    // lr / (1 - beta1^t)
-    float bc2_sqrt;     // sqrt(1 - beta2^t)
-    float w1;           // 1 - beta1
-    float beta2, w2;    // beta2, 1 - beta2
-    float wd, eps;
-    int use_wd;
-};
-
-// This file is compiled with -ffp-contract=off (see Makefile): torch applies these as
-// separately rounded tensor ops, and without FMA contraction the update is bit-identical to
-// the oracle's (IEEE sqrt and divide are hipcc's default).
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamK &a) {
-    if (a.use_wd) g = g + a.wd * p;                     // grad = grad + wd * param
-    m = m + a.w1 * (g - m);                             // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * a.beta2 + a.w2 * (g * g);                   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;  // (sqrt(v) / sqrt(bc2)).add_(eps)
-    p = p - a.step_size * (m / denom);                  // param.addcdiv_(m, denom, -step_size)
-}
-
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
        int64_t n, AdamK a) {
@@ -54,14 +34,9 @@ k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m
 
 }  // namespace
 
-int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
-              double lr, double beta1, double beta2, double eps, double wd, int64_t step) {
-    if (n == 0) return RNVP_OK;
-    if (!p || !g || !m || !v || n < 0 || step < 1) return RNVP_EINVAL;
-    const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v;
-    if (al & 15) return RNVP_EINVAL;                    // float4 path needs 16-B aligned buffers
+AdamK make_adam(double lr, double beta1, double beta2, double eps, double wd, int64_t step) {
     AdamK a;
-    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);       // scalar bookkeeping in double, like torch
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
     a.step_size = (float)(lr / bc1);
     a.bc2_sqrt = (float)std::sqrt(bc2);
@@ -71,6 +46,16 @@ int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int6
     a.wd = (float)wd;
     a.eps = (float)eps;
     a.use_wd = wd != 0.0;
+    return a;
+}
+
+int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
+              double lr, double beta1, double beta2, double eps, double wd, int64_t step) {
+    if (n == 0) return RNVP_OK;
+    if (!p || !g || !m || !v || n < 0 || step < 1) return RNVP_EINVAL;
+    const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v;
+    if (al & 15) return RNVP_EINVAL;                    // float4 path needs 16-B aligned buffers
+    const AdamK a = make_adam(lr, beta1, beta2, eps, wd, step);
     const int threads = 256;
     int64_t blocks = ((n >> 2) + threads - 1) / threads;
     if (blocks < 1) blocks = 1;

@@ -175,8 +175,17 @@ int rnvp_train_step(void *stream, const rnvp_shape *shape, float *params, const 
                     float *grad_buf, float *loss_out, float *exp_avg, float *exp_avg_sq,
                     double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                     void *workspace, size_t workspace_bytes) {
-    int rc = rnvp_loss_grad(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out,
-                            workspace, workspace_bytes);
+    KShape k;
+    int rc = make_kshape(shape, &k);
+    if (rc) return rc;
+    if (n_rows > 0 && mfma::train_supported(k)) {
+        if (bad_ptrs(k, params, masks, x, c) || !grad_buf || !exp_avg || !exp_avg_sq || step < 1) return RNVP_EINVAL;
+        return mfma::train_step(static_cast<hipStream_t>(stream), k, params, x, c, row_index, n_rows, inv_B, grad_buf,
+                                loss_out, exp_avg, exp_avg_sq, make_adam(lr, beta1, beta2, eps, weight_decay, step),
+                                workspace, workspace_bytes);
+    }
+    rc = rnvp_loss_grad(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out,
+                        workspace, workspace_bytes);
     if (rc) return rc;
     return rnvp_adam_step(stream, params, grad_buf, exp_avg, exp_avg_sq, (int64_t)rnvp_param_count(shape), lr,
                           beta1, beta2, eps, weight_decay, step);

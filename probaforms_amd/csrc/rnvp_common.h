@@ -69,6 +69,37 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
 int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
                             float loss_scale, float *grad_out, float *loss_out);
 
+// ---- Adam arithmetic shared by k_adam (rnvp_adam.hip) and the fused reduce+Adam kernel ------------
+// torch.optim.Adam (realnvp.py:205-207,251) as separately rounded tensor ops; written so that
+// no build flag can contract them into FMAs: bit-identical to the oracle.
+struct AdamK {
+    float step_size;    // lr / (1 - beta1^t)
+    float bc2_sqrt;     // sqrt(1 - beta2^t)
+    float w1;           // 1 - beta1
+    float beta2, w2;    // beta2, 1 - beta2
+    float wd, eps;
+    int use_wd;
+};
+
+#ifdef __HIPCC__
+// Separately rounded multiply / add / subtract.  HIP's __fmul_rn & co. are plain operators and DO get
+// contracted into FMAs under -ffp-contract=fast, so the three ops are pinned with one-instruction asm.
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamK &a) {
+    if (a.use_wd) g = add_rn(g, mul_rn(a.wd, p));                              // grad = grad + wd * param
+    m = add_rn(m, mul_rn(a.w1, sub_rn(g, m)));                                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = add_rn(mul_rn(v, a.beta2), mul_rn(a.w2, mul_rn(g, g)));                // mul_(b2).addcmul_(g, g, 1-b2)
+    // sqrtf and '/' are IEEE correctly rounded under hipcc's defaults and cannot be contracted
+    const float denom = add_rn(sqrtf(v) / a.bc2_sqrt, a.eps);
+    p = sub_rn(p, mul_rn(a.step_size, m / denom));                             // addcdiv_(m, denom, -step_size)
+}
+#endif
+
+AdamK make_adam(double lr, double beta1, double beta2, double eps, double wd, int64_t step);
+
 // ---- optimizer: rnvp_adam.hip -----------------------------------------------------------
 int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
               double lr, double beta1, double beta2, double eps, double wd, int64_t step);

@@ -85,5 +85,9 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const float 
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
               void *ws, size_t ws_bytes);
 
+int train_step(hipStream_t st, const KShape &k, float *params, const float *x, const float *c,
+               const int64_t *row_index, int64_t n, float inv_B, float *grad_buf, float *loss_out,
+               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes);
+
 }  // namespace mfma
 }  // namespace rnvp

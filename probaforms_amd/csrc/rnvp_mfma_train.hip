@@ -506,8 +506,9 @@ k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restr
 // One thread per flat parameter; finds where the packed gradient keeps it (or that the masks make
 // it dead: exactly zero, as in the reference) and sums the workgroup partials in index order.
 __global__ void __launch_bounds__(256)
-k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restrict__ gpart,
-              const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss) {
+k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restrict__ seg, int S,
+              const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss,
+              float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
     const size_t P = (size_t)2 * k.npn * k.L;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) {
@@ -571,12 +572,12 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
     }
     float a = 0.f;
     if (loc >= 0) {
-        const float *src = gpart + (size_t)l * glayer_floats + loc;
+        const float *src = seg + (size_t)l * glayer_floats + loc;
         const size_t stride = (size_t)glayer_floats * k.L;
-        a = src[0];                                  // already summed over workgroups
-        (void)stride;
+        for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];      // segment order: deterministic
     }
     grad[p] = a;
+    if (adam_p) adam_one(adam_p[p], a, adam_m[p], adam_v[p], adam);  // fused optimizer (rnvp_train_step)
 }
 
 #ifndef RNVP_TRAIN_R2
@@ -657,9 +658,9 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
     return b;
 }
 
-int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
-              const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes) {
+static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+                          const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
+                          void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
     if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     TrainPlan pl;
@@ -692,15 +693,28 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const float 
     hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), kSeg), dim3(256), 0, st, gpart, grid, n4, seg);
     RNVP_HIP_TRY(hipGetLastError());
     RNVP_HIP_TRY(hipGetLastError());
-    // second level: the kSeg segment sums -> one packed gradient (kept in segment 0's place is not
-    // possible in place, so it lands behind the segments' first row: reuse gpart's head, now dead)
+    // second level (<= kSeg segment sums per parameter) is folded into the scatter to flat order
     const int S = grid < kSeg ? grid : kSeg;
-    hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, st, seg, S, n4, gpart);
-    RNVP_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, gpart, losspart,
-                       grid, inv_B, grad_out, loss_out);
+    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, seg, S, losspart,
+                       grid, inv_B, grad_out, loss_out, adam_p, adam_m, adam_v, adam);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
+}
+
+int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+              const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
+              void *ws, size_t ws_bytes) {
+    return loss_grad_impl(st, k, params, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, nullptr,
+                          nullptr, nullptr, AdamK{});
+}
+
+// loss + gradient + Adam with the optimizer fused into the final scatter kernel (one launch and one
+// round trip of the gradient fewer than rnvp_loss_grad + rnvp_adam_step; same arithmetic, bit for bit)
+int train_step(hipStream_t st, const KShape &k, float *params, const float *x, const float *c,
+               const int64_t *row_index, int64_t n, float inv_B, float *grad_buf, float *loss_out,
+               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes) {
+    return loss_grad_impl(st, k, params, x, c, row_index, n, inv_B, grad_buf, loss_out, ws, ws_bytes, params, exp_avg,
+                          exp_avg_sq, adam);
 }
 
 }  // namespace mfma

@@ -202,3 +202,79 @@ def test_large_batch_properties():
     back = torch.empty_like(x)
     _hip.inverse(shape, params, masks, z, cc, n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
     assert (back - x).abs().max().item() < 5e-4 and (back - x).abs().mean().item() < 2e-6
+
+
+def test_fused_train_step_equals_loss_grad_plus_adam():
+    """rnvp_train_step (optimizer fused into the gradient scatter on the MFMA path) is bit-identical to
+    rnvp_loss_grad followed by rnvp_adam_step"""
+    for name in ("c2", "tm"):
+        _hip, cs, shape, params, masks = _setup(name)
+        n = cs["X"].shape[0]; P = cs["params"].size
+        x, c = _dev(cs["X"]), _dev(cs["C"])
+        ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+        pa, pb = params.clone(), params.clone()
+        ma, va, mb, vb = (torch.zeros(P, device="cuda") for _ in range(4))
+        ga, gb = torch.empty(P, device="cuda"), torch.empty(P, device="cuda")
+        la, lb = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+        for step in (1, 2):
+            _hip.train_step(shape, pa, masks, x, c, None, n, 1.0 / n, ga, la, ma, va, 0.01, 0.9, 0.999, 1e-8, 0.1, step, ws)
+            _hip.loss_grad(shape, pb, masks, x, c, None, n, 1.0 / n, gb, lb, ws)
+            _hip.adam_step(pb, gb, mb, vb, P, 0.01, 0.9, 0.999, 1e-8, 0.1, step)
+            assert torch.equal(ga, gb) and torch.equal(la, lb)
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+@pytest.mark.parametrize("L,d,c,h,n", [(3, 16, 4, 48, 37), (1, 32, 8, 16, 5), (2, 64, 16, 32, 100), (5, 16, 0, 16, 1),
+                                       (3, 32, 8, 80, 300)])
+def test_mfma_path_edge_shapes_vs_oracle(L, d, c, h, n, oracle32):
+    """odd layer counts, hidden sizes that are not a multiple of the flush interval, ragged and tiny
+    batches, gathered rows: MFMA kernels (forward, inverse, loss+grad) against the oracle"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(L * 1000 + d + h)
+    shape = _hip.RnvpShape.make(L, d, c, (h,), "tanh", alt_masks=1)
+    assert _hip.kernel_path(shape, None, _hip.OP_TRAIN) == _hip.PATH_MFMA
+    P = _hip.param_count(shape)
+    params = (rng.uniform(-1, 1, size=P) * 0.12).astype(np.float32)      # ~ the default init range for these widths
+    N = 3 * n + 7
+    X = rng.normal(size=(N, d)).astype(np.float32); C = rng.normal(size=(N, c)).astype(np.float32) if c else None
+    idx = rng.permutation(N)[:n].astype(np.int64)
+    s = Shape.make(L, d, c, (h,), "tanh")
+    pd, xd, cd, id_ = _dev(params), _dev(X), _dev(C), _dev(idx, torch.int64)
+    masks = _dev(((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8), torch.uint8)
+    z = torch.empty(n, d, device="cuda"); lp = torch.empty(n, device="cuda"); tot = torch.empty(1, device="cuda")
+    _hip.forward_logprob(shape, pd, masks, xd, cd, id_, n, z, None, lp, tot, _ws(_hip, shape, _hip.OP_FORWARD, n))
+    Xg = X[idx]; Cg = None if C is None else C[idx]
+    zo, lpo, _ = oracle32.log_prob(s, params, Xg, Cg)
+    # random weights of this size amplify rounding through exp(s): bound the mean tightly, the max loosely
+    assert np.abs(z.cpu().numpy() - zo).mean() < 2e-6 and np.abs(z.cpu().numpy() - zo).max() < 2e-4
+    # |log p| reaches several hundred with these weights: the bar is 2 float32 ulp of that magnitude
+    assert np.abs(lp.cpu().numpy() - lpo).mean() < max(1e-5, 2.4e-7 * np.abs(lpo).max())
+    assert abs(float(tot) - lpo.astype(np.float64).sum()) < 2e-5 * max(1.0, np.abs(lpo).sum())
+    back = torch.empty_like(z)
+    _hip.inverse(shape, pd, masks, z, _dev(Cg), n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
+    assert np.abs(back.cpu().numpy() - Xg).mean() < 2e-6 and np.abs(back.cpu().numpy() - Xg).max() < 5e-4
+    grad = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.loss_grad(shape, pd, masks, xd, cd, id_, n, 1.0 / n, grad, loss, _ws(_hip, shape, _hip.OP_TRAIN, n))
+    lo, go = oracle32.loss_grad(s, params, Xg, Cg)
+    assert abs(float(loss) - lo) < max(1e-5, 5e-7 * abs(lo))
+    assert np.abs(grad.cpu().numpy() - go).max() < 3e-6 * np.abs(go).max() + 1e-9
+
+
+def test_large_inverse_16m_rows():
+    """BASELINE.json configs[3]-sized sampling call (16M draws, d=64, cond=16): index arithmetic beyond
+    2^31 elements; checked through the round trip on a slice"""
+    from probaforms_amd import _hip
+    L, d, c, h = 8, 64, 16, 128
+    n = 16 * 1024 * 1024 + 3
+    shape = _hip.RnvpShape.make(L, d, c, (h,), "tanh", alt_masks=1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    params = (torch.rand(_hip.param_count(shape), device="cuda", generator=g) - 0.5) * 0.2
+    masks = _dev(((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8), torch.uint8)
+    z = torch.randn(n, d, device="cuda", generator=g); cc = torch.randn(n, c, device="cuda", generator=g)
+    keep = z[-1000:].clone()
+    _hip.inverse(shape, params, masks, z, cc, n, z, _ws(_hip, shape, _hip.OP_INVERSE, n))       # in place
+    tail = z[-1000:].contiguous(); zz = torch.empty_like(tail)
+    _hip.forward_logprob(shape, params, masks, tail, cc[-1000:].contiguous(), None, 1000, zz, None, None, None,
+                         _ws(_hip, shape, _hip.OP_FORWARD, 1000))
+    assert (zz - keep).abs().max().item() < 1e-3 and (zz - keep).abs().mean().item() < 5e-6
