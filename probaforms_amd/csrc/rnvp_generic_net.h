@@ -7,8 +7,13 @@
 
 namespace rnvp {
 
+// tanh(v) = 1 - 2 / (1 + e^{2v}) on v_exp_f32 / v_rcp_f32 (~1 ulp each; absolute error ~1e-7, the
+// rounding level of values near 1; exact saturation through e = +inf / 0).  ocml's tanhf costs ~40
+// instructions and dominated the small-network step time (README config: 303 us -> see DESIGN.md).
 __device__ __forceinline__ float act_fwd(float v, int act) {
-    return act == RNVP_ACT_TANH ? tanhf(v) : fmaxf(v, 0.f);
+    if (act != RNVP_ACT_TANH) return fmaxf(v, 0.f);
+    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
 
 // One s/t net (Linear, act, ..., Linear) for row t of the block; buffers are LDS [feature][TBP].

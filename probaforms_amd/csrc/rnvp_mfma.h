@@ -1,5 +1,9 @@
 // rnvp_mfma.h -- geometry of the register-chained f32 MFMA path (gfx950, wave64).
 //
+// Shapes: any d <= 64, cdim <= 16, one hidden layer of any width, tanh, alternating masks; sizes are
+// padded up to the tile geometry (d -> 16/32/64, cdim -> 0/4/8/16, h -> multiple of 16) with zero
+// weights, so the README shape (d=2, c=1, h=10) and the reference's test shape (d=5, c=3) run here too.
+//
 // One wave owns R tiles of 16 rows for the whole L-layer stack.  Every contraction is a
 // v_mfma_f32_16x16x4_f32 computed TRANSPOSED (features on the MFMA M axis, rows on N), so that
 // lane (q = lane >> 4, r = lane & 15) always holds data of row r:
@@ -24,9 +28,11 @@ namespace rnvp {
 namespace mfma {
 
 struct Geo {
-    int NF;     // d / 8: features per parity class per lane
-    int CQ;     // c / 4: conditions per lane
-    int HT;     // h / 16: hidden tiles per net
+    int d, c, h;  // the caller's real sizes; the tile geometry below is padded up from them (padded
+                  // features / conditions / hidden units carry zero weights and never reach the output)
+    int NF;     // padded d / 8: features per parity class per lane
+    int CQ;     // padded c / 4: conditions per lane
+    int HT;     // padded h / 16: hidden tiles per net
     int KS1;    // NF + CQ: k-steps of GEMM1
     int K4;     // ceil(KS1 / 4): float4 groups of A1 per lane
     int OTL;    // out tiles fed by one hidden tile: max(1, NF / 4)
@@ -39,9 +45,21 @@ struct Geo {
     int oG1, oG2, oGb2, glayer_floats;
 };
 
+// smallest instantiated (NF, CQ) that holds d features and c conditions: (2,0) (2,1) (4,2) (8,4)
+__host__ __device__ inline bool pick_tiles(int d, int c, int *NF, int *CQ) {
+    if (d <= 16 && c == 0) { *NF = 2; *CQ = 0; return true; }
+    if (d <= 16 && c <= 4) { *NF = 2; *CQ = 1; return true; }
+    if (d <= 32 && c <= 8) { *NF = 4; *CQ = 2; return true; }
+    if (d <= 64 && c <= 16) { *NF = 8; *CQ = 4; return true; }
+    return false;
+}
+
 __host__ __device__ inline Geo make_geo(int d, int c, int h) {
     Geo g;
-    g.NF = d / 8; g.CQ = c / 4; g.HT = h / 16;
+    g.d = d; g.c = c; g.h = h;
+    g.NF = 2; g.CQ = 0;
+    pick_tiles(d, c, &g.NF, &g.CQ);
+    g.HT = (h + 15) / 16;
     g.KS1 = g.NF + g.CQ; g.K4 = (g.KS1 + 3) / 4;
     g.OTL = g.NF >= 4 ? g.NF / 4 : 1;
     g.NT2 = g.NF >= 4 ? 2 * g.OTL : 1;

@@ -25,24 +25,29 @@ constexpr int kMaxGrid = 2048;
 // reflects the caller's current parameters (76 k .. 450 k floats: a few microseconds).
 __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const float *__restrict__ params) {
     const int pc = (l + k.alt) & 1;
-    const int nin = k.d + k.c, h = k.nout[0];
+    const int nin = k.d + k.c, h = k.nout[0];                 // REAL sizes: flat indexing; padded slots -> 0
     const float *pl = params + (size_t)l * 2 * k.npn;
+#define RNVP_W1(net, hid, col) (((hid) < h && (col) >= 0) ? pl[(net) * k.npn + k.woff[0] + (hid) * nin + (col)] : 0.f)
+#define RNVP_W2(net, feat, hid) (((hid) < h && (feat) < k.d) ? pl[(net) * k.npn + k.woff[1] + (feat) * h + (hid)] : 0.f)
+    // real input column of a padded feature / condition slot, or -1
+    auto xcol = [&](int feat) { return feat < k.d ? feat : -1; };
+    auto ccol = [&](int ci) { return ci < k.c ? k.d + ci : -1; };
     if (idx < g.oB1) {                                     // A1 [tile][k4][lane][4]
         const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
         const int k4 = rest % g.K4, tile = rest / g.K4;
         const int kk = 4 * k4 + e, q = lane >> 4, i = lane & 15;
         const int net = tile / g.HT, hid = 16 * (tile % g.HT) + i;
         int col;
-        if (kk < g.NF) col = feat_cond(g.NF, q, kk, pc);
-        else if (kk < g.KS1) col = k.d + q * g.CQ + (kk - g.NF);
+        if (kk < g.NF) col = xcol(feat_cond(g.NF, q, kk, pc));
+        else if (kk < g.KS1) col = ccol(q * g.CQ + (kk - g.NF));
         else return 0.f;
-        return kTanhScale * pl[net * k.npn + k.woff[0] + hid * nin + col];      // pre-scaled: see tanh4
+        return kTanhScale * RNVP_W1(net, hid, col);                            // pre-scaled: see tanh4
     }
     if (idx < g.oA2) {                                     // bias1 [tile][q][4]
         const int j = idx - g.oB1;
         const int e = j & 3, q = (j >> 2) & 3, tile = j >> 4;
-        const int net = tile / g.HT;
-        return kTanhScale * pl[net * k.npn + k.boff[0] + 16 * (tile % g.HT) + 4 * q + e];
+        const int net = tile / g.HT, hid = 16 * (tile % g.HT) + 4 * q + e;
+        return hid < h ? kTanhScale * pl[net * k.npn + k.boff[0] + hid] : 0.f;
     }
     if (idx < g.oB2) {                                     // A2 [tile][otl][lane][4 rho]
         const int j = idx - g.oA2;
@@ -55,7 +60,7 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         if (g.NF >= 4) { f = 4 * otl + ro; net_out = net; }
         else { f = ro & 1; net_out = ro >> 1; }
         if (net_out != net) return 0.f;
-        return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, qo, f, pc) * h + hid];
+        return RNVP_W2(net, feat_trans(g.NF, qo, f, pc), hid);
     }
     if (idx < g.oA2T) {                                    // bias2 [ot][q][4]
         const int j = idx - g.oB2;
@@ -63,7 +68,8 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         int f, net;
         if (g.NF >= 4) { net = ot / g.OTL; f = 4 * (ot % g.OTL) + ro; }
         else { net = ro >> 1; f = ro & 1; }
-        return pl[net * k.npn + k.boff[1] + feat_trans(g.NF, qo, f, pc)];
+        const int feat = feat_trans(g.NF, qo, f, pc);
+        return feat < k.d ? pl[net * k.npn + k.boff[1] + feat] : 0.f;
     }
     if (idx < g.oA1T) {                                    // A2T [tile][otl][lane][4 rho]
         const int j = idx - g.oA2T;
@@ -75,7 +81,7 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         if (g.NF >= 4) { f = 4 * otl + rho; net_out = net; }
         else { f = rho & 1; net_out = rho >> 1; }
         if (net_out != net) return 0.f;
-        return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, q, f, pc) * h + hid];
+        return RNVP_W2(net, feat_trans(g.NF, q, f, pc), hid);
     }
     if (idx >= g.oA1X) {                                   // A1X [tile][og][lane][4 rho]  (d == 16)
         // 4x4x1 blocks: lane (q, r), i = r & 3 supplies W1[hid 16t+4q+rho][conditioning feature (og, i)],
@@ -85,7 +91,7 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         const int og = rest & 1, tile = rest >> 1;
         const int q = lane >> 4, i = lane & 3, net = tile / g.HT;
         const int hid = 16 * (tile % g.HT) + 4 * q + rho;
-        return pl[net * k.npn + k.woff[0] + hid * nin + feat_cond(g.NF, 2 * og + (i >> 1), i & 1, pc)];
+        return RNVP_W1(net, hid, xcol(feat_cond(g.NF, 2 * og + (i >> 1), i & 1, pc)));
     }
     if (idx >= g.oA2X) {                                   // A2X [tile][og][lane][4 rho]  (d == 16)
         const int j = idx - g.oA2X;
@@ -93,7 +99,7 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         const int og = rest & 1, tile = rest >> 1;
         const int q = lane >> 4, i = lane & 3, net = tile / g.HT;
         const int hid = 16 * (tile % g.HT) + 4 * q + rho;
-        return pl[net * k.npn + k.woff[1] + feat_trans(g.NF, 2 * og + (i >> 1), i & 1, pc) * h + hid];
+        return RNVP_W2(net, feat_trans(g.NF, 2 * og + (i >> 1), i & 1, pc), hid);
     }
     {                                                      // A1T [tile][mt][lane][4 rho]
         const int j = idx - g.oA1T;
@@ -105,8 +111,10 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         int f;
         if (g.NF >= 4) f = 4 * mt + ri;
         else { if (ri >= 2) return 0.f; f = ri; }
-        return pl[net * k.npn + k.woff[0] + hid * nin + feat_cond(g.NF, qi, f, pc)];
+        return RNVP_W1(net, hid, xcol(feat_cond(g.NF, qi, f, pc)));
     }
+#undef RNVP_W1
+#undef RNVP_W2
 }
 
 __global__ void __launch_bounds__(256)
@@ -136,12 +144,13 @@ __global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_e
 k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n,
             float *out_x, float *logdet_out, float *logp_out, float *part) {
-    constexpr int D = 8 * NF, CD = 4 * CQ;
+    constexpr int D = 8 * NF, CD = 4 * CQ;               // padded sizes; g.d / g.c are the caller's
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, r = lane & 15;
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
-    const float prior_c = 0.5f * (float)D * kLog2Pi;
+    const float prior_c = 0.5f * (float)g.d * kLog2Pi;
+    const bool full = (g.d == D) && (g.c == CD);        // exact fit: vector row loads / stores
     float wave_sum = 0.f;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
@@ -152,19 +161,7 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__
             const int64_t row = base + rt * 16 + r;
             const bool valid = row < n;
             const int64_t src = valid ? (row_index ? row_index[row] : row) : 0;
-            const float *xp = x + src * D + q * 2 * NF;
-#pragma unroll
-            for (int v = 0; v < 2 * NF; v += 4) {
-                const f4 t = *reinterpret_cast<const f4 *>(xp + v);
-                xr[rt][v] = t[0]; xr[rt][v + 1] = t[1]; xr[rt][v + 2] = t[2]; xr[rt][v + 3] = t[3];
-            }
-            if (CQ > 0) {
-                const float *cp = c + src * CD + q * CQ;
-#pragma unroll
-                for (int v = 0; v < CQ; ++v) cr[rt][v] = cp[v];
-            } else {
-                cr[rt][0] = 0.f;
-            }
+            load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
             ld[rt] = 0.f;
         }
         for (int lp = 0; lp < L; ++lp) {
@@ -177,15 +174,7 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__
         for (int rt = 0; rt < R; ++rt) {
             const int64_t row = base + rt * 16 + r;
             const bool valid = row < n;
-            if (out_x && valid) {
-                float *op = out_x + row * D + q * 2 * NF;
-#pragma unroll
-                for (int v = 0; v < 2 * NF; v += 4) {
-                    f4 t;
-                    t[0] = xr[rt][v]; t[1] = xr[rt][v + 1]; t[2] = xr[rt][v + 2]; t[3] = xr[rt][v + 3];
-                    *reinterpret_cast<f4 *>(op + v) = t;
-                }
-            }
+            if (out_x && valid) store_row<NF>(out_x, row, g.d, full, q, xr[rt]);
             if (!INVERSE) {
                 float ss = 0.f;
 #pragma unroll
@@ -269,10 +258,8 @@ int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *par
 
 bool supported(const KShape &k) {
     if (!k.alt || k.nh != 1 || k.act != RNVP_ACT_TANH) return false;
-    if (k.nout[0] % 16 != 0 || k.nout[0] < 16) return false;
-    const int NF = k.d / 8, CQ = k.c / 4;
-    if (k.d != 8 * NF || k.c != 4 * CQ) return false;
-    return (NF == 2 && (CQ == 1 || CQ == 0)) || (NF == 4 && CQ == 2) || (NF == 8 && CQ == 4);
+    int NF, CQ;
+    return pick_tiles(k.d, k.c, &NF, &CQ);       // d <= 64, cdim <= 16; everything else is padding
 }
 
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {

@@ -410,7 +410,8 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     float *tb = lds + kWaves * DM::SLOT + wave * DM::template tb<R>();
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
-    const float prior_c = 0.5f * (float)D * kLog2Pi;
+    const float prior_c = 0.5f * (float)g.d * kLog2Pi;
+    const bool full = (g.d == D) && (g.c == CD);
     float *gp = gpart + (size_t)blockIdx.x * glayer_floats * L;
     float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + wave) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
@@ -428,19 +429,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             const int64_t row = base + rt * 16 + r;
             valid[rt] = row < n;
             const int64_t src = valid[rt] ? (row_index ? row_index[row] : row) : 0;
-            const float *xp = x + src * D + q * 2 * NF;
-#pragma unroll
-            for (int v = 0; v < 2 * NF; v += 4) {
-                const f4 t = *reinterpret_cast<const f4 *>(xp + v);
-                xr[rt][v] = t[0]; xr[rt][v + 1] = t[1]; xr[rt][v + 2] = t[2]; xr[rt][v + 3] = t[3];
-            }
-            if (CQ > 0) {
-                const float *cp = c + src * CD + q * CQ;
-#pragma unroll
-                for (int v = 0; v < CQ; ++v) cr[rt][v] = cp[v];
-            } else {
-                cr[rt][0] = 0.f;
-            }
+            load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
             ld[rt] = 0.f;
         }
         STAMP_ADD(stp.ld, t0);
@@ -533,11 +522,11 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
     int loc = -1;
     if (idx < k.boff[0]) {                                     // W1 [h][d + c]
         const int hid = idx / nin, col = idx - hid * nin;
-        int jn = -1;
+        int jn = -1;                                           // (k.d, k.c, h are the REAL sizes; NF, CQ the padded tiles)
         if (col < k.d) {
             const int qq = col / (2 * NF), e = col % (2 * NF);
             if ((e & 1) == pc) jn = qq * KSP + (e >> 1);
-        } else {
+        } else if (CQ > 0) {
             const int ci = col - k.d;
             jn = (ci / CQ) * KSP + NF + (ci % CQ);
         }

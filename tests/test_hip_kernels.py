@@ -15,12 +15,18 @@ def _dev(a, dtype=torch.float32):
     return None if a is None else torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda().contiguous()
 
 
-def _setup(name):
+PATHS = ["declared", "table"]     # masks declared alternating (MFMA path where it applies) / read from the table (generic path)
+
+
+def _setup(name, path="declared"):
     from probaforms_amd import _hip
     cs = load_case(name)
-    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"],
-                                alt_masks=_hip.RnvpShape.classify_masks(cs["masks"]))
-    assert shape.alt_masks == 1 and _hip.param_count(shape) == cs["params"].size
+    alt = _hip.RnvpShape.classify_masks(cs["masks"])
+    assert alt == 1
+    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=alt if path == "declared" else 0)
+    assert _hip.param_count(shape) == cs["params"].size
+    if path == "table":
+        assert _hip.kernel_path(shape, cs["masks"], _hip.OP_TRAIN) == _hip.PATH_GENERIC
     return _hip, cs, shape, _dev(cs["params"]), _dev(cs["masks"], torch.uint8)
 
 
@@ -29,10 +35,11 @@ def _ws(_hip, shape, op, n):
     return torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", ALL)
-def test_forward_vs_golden_and_oracle(name, oracle32, oracle64):
+def test_forward_vs_golden_and_oracle(name, path, oracle32, oracle64):
     from oracle import Shape
-    _hip, cs, shape, params, masks = _setup(name)
+    _hip, cs, shape, params, masks = _setup(name, path)
     n, d = cs["X"].shape
     x, c = _dev(cs["X"]), _dev(cs["C"])
     z = torch.empty(n, d, device="cuda"); ld = torch.empty(n, device="cuda")
@@ -77,9 +84,10 @@ def test_single_layer_f_and_g(name, oracle32):
         np.testing.assert_allclose(y.cpu().numpy(), g["G3_layer_out"][k], rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", ALL)
-def test_inverse_and_roundtrip(name):
-    _hip, cs, shape, params, masks = _setup(name)
+def test_inverse_and_roundtrip(name, path):
+    _hip, cs, shape, params, masks = _setup(name, path)
     n, d = cs["Z"].shape
     zt, c = _dev(cs["Z"]), _dev(cs["C"])
     x = torch.empty(n, d, device="cuda")
@@ -93,11 +101,12 @@ def test_inverse_and_roundtrip(name):
     assert (z - xx).abs().max().item() < max(2e-5, 10 * float(cs["gold"]["G3_roundtrip_maxerr"]))
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("tag,rows", [("G4", None), ("G8", 8)])
-def test_loss_grad(name, tag, rows, oracle32):
+def test_loss_grad(name, tag, rows, path, oracle32):
     from oracle import Shape
-    _hip, cs, shape, params, masks = _setup(name)
+    _hip, cs, shape, params, masks = _setup(name, path)
     g = cs["gold"]
     X = cs["X"][:rows]; C = None if cs["C"] is None else cs["C"][:rows]
     n = X.shape[0]
@@ -121,10 +130,11 @@ def test_loss_grad(name, tag, rows, oracle32):
     assert np.abs(grad[gor == 0]).max(initial=0.0) < 1e-9      # dead (masked) entries stay exactly ~0
 
 
-def test_loss_grad_gather_and_shards(oracle32):
+@pytest.mark.parametrize("path", PATHS)
+def test_loss_grad_gather_and_shards(path, oracle32):
     """row_index gather + two shards scaled by 1/B_global add up to the full-batch result."""
     from oracle import Shape
-    _hip, cs, shape, params, masks = _setup("tm")
+    _hip, cs, shape, params, masks = _setup("tm", path)
     n = cs["X"].shape[0]
     perm = np.random.default_rng(0).permutation(n).astype(np.int64)
     x, c, idx = _dev(cs["X"]), _dev(cs["C"]), _dev(perm, torch.int64)
@@ -146,11 +156,12 @@ def test_loss_grad_gather_and_shards(oracle32):
     assert float(z.abs().max().item()) == 0.0
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", ["c1_L8", "tm", "d8"])
 @pytest.mark.parametrize("wd", [0.0, 0.2])
-def test_adam_trajectory_vs_reference(name, wd):
+def test_adam_trajectory_vs_reference(name, wd, path):
     """3 fused train steps against the reference's own Adam trajectory (G4)."""
-    _hip, cs, shape, params, masks = _setup(name)
+    _hip, cs, shape, params, masks = _setup(name, path)
     g = cs["gold"]; k = "G4_adam_wd%g" % wd
     n = cs["X"].shape[0]; P = cs["params"].size
     x, c = _dev(cs["X"]), _dev(cs["C"])
