@@ -208,6 +208,7 @@ class FlowEngine:
                                % (self.P, _hip.param_count(self.shape)))
         self.flat = None
         self.masks_host = None
+        self._mask_key = None
         self.layers = layers
         self._ws = {op: _Workspace(self.device) for op in (_hip.OP_FORWARD, _hip.OP_INVERSE, _hip.OP_TRAIN)}
         self._ws_rows = {}
@@ -219,13 +220,16 @@ class FlowEngine:
         """(Re)build the flat buffer if the module parameters were moved or replaced."""
         if not is_flat(self.param_list, self.flat):
             self.flat = flatten_parameters(self.param_list, self.device)
-        masks = torch.stack([l.mask.detach().to("cpu").to(torch.uint8).reshape(-1) for l in self.layers])
-        host = np.ascontiguousarray(masks.numpy())
-        if getattr(self, "masks_host", None) is None or not np.array_equal(host, self.masks_host):
-            self.masks_host = host
+        # masks are plain attributes of the layers (realnvp.py:68); re-read them only when one was
+        # replaced or modified in place (identity + version counter), not on every call
+        key = tuple((id(l.mask), l.mask._version) for l in self.layers)
+        if key != self._mask_key:
+            self._mask_key = key
+            masks = torch.stack([l.mask.detach().to("cpu").to(torch.uint8).reshape(-1) for l in self.layers])
+            self.masks_host = np.ascontiguousarray(masks.numpy())
             self.masks = masks.to(self.device).contiguous()
             # declare the reference's alternating pattern (realnvp.py:199) when that is what we hold
-            self.shape.alt_masks = _hip.RnvpShape.classify_masks(host)
+            self.shape.alt_masks = _hip.RnvpShape.classify_masks(self.masks_host)
         return self.flat
 
     @property

@@ -49,6 +49,12 @@ constexpr int kAblate = RNVP_ABLATE;
 #define STAMP(var) do { } while (0)
 #define STAMP_ADD(acc, t0) do { } while (0)
 #endif
+// RNVP_NO_BWD_SCHED_BARRIER: developer A/B switch (lets hipcc schedule the backward phases freely)
+#ifdef RNVP_NO_BWD_SCHED_BARRIER
+#define BWD_SCHED_BARRIER() do { } while (0)
+#else
+#define BWD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2, p3, p4, p5; };
 
 #ifndef RNVP_TRAIN_WAVES
@@ -206,7 +212,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
 #pragma unroll
             for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_SCHED_BARRIER();
 
             f4 gW2[OTL], gW1[NTI];
 #pragma unroll
@@ -242,7 +248,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         for (int u = 0; u < RH; ++u)
                             gh[u] = mfma16(a2t[0][2 * net + v], go[r0 + u][0][2 * net + v], gh[u]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p1, t0);
 
                 // phase 2 (VALU + LDS writes): h = tanh, g_pre = g_h * (1 - h^2); both go to this wave's
@@ -261,7 +267,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     }
                 }
                 wave_lds_fence();
-                __builtin_amdgcn_sched_barrier(0);
+                BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p2, t0);
 
                 // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
@@ -293,7 +299,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
                         }
                     }
-                __builtin_amdgcn_sched_barrier(0);
+                BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p3, t0);
 
                 // phase 4 (MFMA): dW2 += h g_out^T, dW1|db1 += g_pre [in|1]^T; independent chains alternate
@@ -314,7 +320,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) { gW2[0][ks] += hT[u][ks]; gW1[0][ks] += pT[u][ks]; }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p4, t0);
             }
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
