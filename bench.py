@@ -258,6 +258,7 @@ def main():
                                   "target": 1e-5}
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0 may still be timing the CPU baseline
         dist.destroy_process_group()
 
 
