@@ -37,12 +37,9 @@ struct Geo {
     int K4;     // ceil(KS1 / 4): float4 groups of A1 per lane
     int OTL;    // out tiles fed by one hidden tile: max(1, NF / 4)
     int NT2;    // out tiles in total: NF >= 4 ? 2 * OTL : 1 (t and s share one tile when NF == 2)
-    int NTI;    // N tiles of the W1 gradient (KS1*4 input columns + 1 ones column for the bias)
     int MTI;    // M tiles of the input gradient: max(1, NF / 4)
     // float offsets inside one layer's packed block
     int oA1, oB1, oA2, oB2, oA2T, oA1T, oA2X, oA1X, layer_floats;
-    // packed gradient block of one layer
-    int oG1, oG2, oGb2, glayer_floats;
 };
 
 // smallest instantiated (NF, CQ) that holds d features and c conditions: (2,0) (2,1) (4,2) (8,4)
@@ -63,7 +60,6 @@ __host__ __device__ inline Geo make_geo(int d, int c, int h) {
     g.KS1 = g.NF + g.CQ; g.K4 = (g.KS1 + 3) / 4;
     g.OTL = g.NF >= 4 ? g.NF / 4 : 1;
     g.NT2 = g.NF >= 4 ? 2 * g.OTL : 1;
-    g.NTI = (g.KS1 * 4 + 1 + 15) / 16;
     g.MTI = g.NF >= 4 ? g.NF / 4 : 1;
     int o = 0;
     g.oA1 = o; o += 2 * g.HT * g.K4 * 256;          // [tile][k4][lane][4]
@@ -77,11 +73,6 @@ __host__ __device__ inline Geo make_geo(int d, int c, int h) {
     g.oA2X = o; o += (g.NF == 2) ? 2 * g.HT * 2 * 256 : 0;   // [tile][og][lane][4 (rho)]
     g.oA1X = o; o += (g.NF == 2) ? 2 * g.HT * 2 * 256 : 0;   // [tile][og][lane][4 (rho)]
     g.layer_floats = o;
-    o = 0;
-    g.oG1 = o; o += 2 * g.HT * g.NTI * 256;         // [tile][nt][lane][4]: dW1 (+ db1 in the ones column)
-    g.oG2 = o; o += 2 * g.HT * g.OTL * 256;         // [tile][otl][lane][4]: dW2
-    g.oGb2 = o; o += g.NT2 * 64;                    // [ot][lane]... db2 kept per lane group, see kernel
-    g.glayer_floats = o;
     return g;
 }
 

@@ -1,13 +1,13 @@
 // rnvp_mfma.hip -- register-chained f32 MFMA kernels for the RealNVP coupling stack (gfx950).
 // Layout and rationale: rnvp_mfma.h.  Replaces RealNVPLayer.f / .g for every layer and the
 // loops of NormalizingFlow.log_prob / .sample (/root/reference/probaforms/models/realnvp.py:
-// 91-101,120-129; nflow.py:107-117,141-145) for d in {16,32,64}, cdim in {0,4,8,16}, one hidden
-// layer with h % 16 == 0, tanh, and the reference's alternating masks.
+// 91-101,120-129; nflow.py:107-117,141-145) for d <= 64, cdim <= 16 (padded up to the tile
+// geometry), one hidden layer, tanh, and the reference's alternating masks.
 #include "rnvp_mfma_layer.h"
 
-// occupancy the scheduler is told to aim for: exactly RNVP_WPE waves per SIMD, so that it spends
-// the rest of the 512/RNVP_WPE register budget on instruction-level parallelism instead of
-// serialising the tanh / MFMA chains to save registers (measured: see DESIGN.md).
+// amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE): with at most 256 registers per wave hipcc keeps MFMA
+// results in VGPRs (above that it allocates AGPRs and pays a v_accvgpr_read per value the VALU
+// touches), and it stops trading instruction-level parallelism for a higher occupancy it cannot use.
 #ifndef RNVP_WPE
 #define RNVP_WPE 2
 #endif

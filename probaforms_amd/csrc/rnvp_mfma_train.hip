@@ -19,15 +19,16 @@
 //     stored (plain ds_write_b128; LDS float atomics measured ~1 lane/clk on gfx950) into the
 //     wave's own LDS slot, and every FT hidden tiles the workgroup adds the four slots in wave
 //     order into its private partial in global memory.  A second pass sums the partials over
-//     workgroups in a fixed order and scatters them into the reference's flat parameter order.
+//     workgroups in a fixed order and scatters them into the reference's flat parameter order
+//     (optionally applying Adam in the same kernel: rnvp_train_step).
 //     No float atomics anywhere: results are bitwise reproducible.
+//   The tile loops are hand-scheduled in phases (rnvp_mfma_layer.h explains why); for d == 16 the
+//   input-gradient product, like GEMM2 in the forward, runs as 4x4x1 MFMA blocks.
 #include <atomic>
 
 #include "rnvp_mfma_layer.h"
 
-// occupancy the scheduler is told to aim for: exactly RNVP_WPE waves per SIMD, so that it spends
-// the rest of the 512/RNVP_WPE register budget on instruction-level parallelism instead of
-// serialising the tanh / MFMA chains to save registers (measured: see DESIGN.md).
+// amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE): see rnvp_mfma.hip (VGPR-form MFMAs, no AGPR copies).
 #ifndef RNVP_WPE
 #define RNVP_WPE 2
 #endif
@@ -606,8 +607,6 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
     if (g.NF == 8 && g.CQ == 4) { *p = make_plan<8, 4>(g, L); return true; }
     return false;
 }
-
-std::atomic<int> g_lds_ok{0};
 
 template <int NF, int CQ>
 int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
