@@ -153,6 +153,22 @@ int rnvp_train_step(void *stream, const rnvp_shape *shape,
                     void *workspace, size_t workspace_bytes);
 
 /*
+ * One epoch of the single-GPU batch loop of RealNVP.fit (realnvp.py:237-254) in one call: for every
+ * consecutive slice of `batch_size` entries of `perm` (the epoch's DataLoader permutation, int64 [n]
+ * on the device; the last slice may be ragged) run rnvp_train_step with inv_B = 1 / rows_in_slice
+ * and store that batch's loss in loss_hist[k].  `first_step` is the 1-based Adam step number of the
+ * first batch.  Removes the per-batch host round trip through Python; the kernels are enqueued
+ * back to back on `stream`.  Returns the first non-zero status.
+ */
+int rnvp_fit_epoch(void *stream, const rnvp_shape *shape,
+                   float *params, const uint8_t *masks,
+                   const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                   float *grad_buf, float *loss_hist,
+                   float *exp_avg, float *exp_avg_sq,
+                   double lr, double beta1, double beta2, double eps, double weight_decay,
+                   int64_t first_step, void *workspace, size_t workspace_bytes);
+
+/*
  * Measurement aid (bench.py): while enabled, the DOMINANT kernel of each rnvp_loss_grad /
  * rnvp_train_step call (the fused forward+backward kernel) is bracketed by a pair of HIP events
  * recorded on the caller's stream.  rnvp_profile_read synchronises on them and returns the

@@ -306,6 +306,16 @@ class FlowEngine:
         _hip.adam_step(self.params, g[:self.P], opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], self.P,
                        lr, b1, b2, eps, wd, opt.step_count)
 
+    def fit_epoch(self, opt, x, c, perm, batch_size, losses):
+        """single-GPU: all batches of one epoch in ONE library call (rnvp_fit_epoch)"""
+        lr, b1, b2, eps, wd = opt.hyper
+        n = perm.numel()
+        g = self.ensure_gbuf()
+        ws = self.workspace(_hip.OP_TRAIN, min(n, batch_size))
+        _hip.fit_epoch(self.shape, self.params, self.masks, x, c, perm, n, batch_size, g[:self.P], losses,
+                       opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
+        opt.step_count += len(batch_bounds(n, batch_size))
+
     def train_step(self, opt, x, c, rows, n_rows, inv_B, loss_out):
         """single-GPU fused step: loss+grad, Adam; the batch loss lands in loss_out[0:1]."""
         lr, b1, b2, eps, wd = opt.hyper
@@ -341,7 +351,8 @@ def broadcast_(t, src=0):
 def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None):
     """The batch loop of RealNVP.fit (realnvp.py:235-262) on device-resident X [n,d], C [n,c].
 
-    Single GPU: one fused rnvp_train_step per batch.  With torch.distributed initialised every
+    Single GPU: one rnvp_fit_epoch call per epoch (a fused rnvp_train_step per batch, looped inside the
+    library).  With torch.distributed initialised every
     rank walks the SAME permutation, takes its contiguous share of each global batch, and the
     flat [gradient | loss] buffer is all-reduced (SUM) before an identical Adam step on every
     rank -- gradients are scaled by 1/B_global inside the kernel, so the sum is the batch mean.
@@ -355,13 +366,12 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     for epoch in range(n_epochs):
         perm = perms.get(epoch).to(dev, non_blocking=False)
         losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
-        for k, (s, e) in enumerate(bounds):
-            inv_B = 1.0 / (e - s)
-            if world == 1:
-                engine.train_step(opt, X, C, perm[s:e], e - s, inv_B, losses[k:k + 1])
-            else:
+        if world == 1:
+            engine.fit_epoch(opt, X, C, perm, batch_size, losses)       # every batch, one library call
+        else:
+            for k, (s, e) in enumerate(bounds):
                 lo, hi = shard_bounds(s, e, rank, world)
-                g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, inv_B)
+                g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
                 all_reduce_sum(g[:engine.P + 1])
                 losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
                 engine.adam(opt)

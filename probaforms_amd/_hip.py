@@ -99,6 +99,8 @@ _SIGNATURES = {
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "rnvp_fit_epoch": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
+                                 _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
     "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
@@ -224,6 +226,16 @@ def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, l
         _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
         _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(eps),
         float(weight_decay), int(step), wp, wn))
+
+
+def fit_epoch(shape, params, masks, x, c, perm, n, batch_size, grad_buf, loss_hist, exp_avg, exp_avg_sq,
+              lr, beta1, beta2, eps, weight_decay, first_step, ws):
+    wp, wn = _ws(ws)
+    _call("rnvp_fit_epoch", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+          _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), int(n),
+          int(batch_size), _ptr(grad_buf, torch.float32, "grad_buf"), _ptr(loss_hist, torch.float32, "loss_hist"),
+          _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
+          float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn))
 
 
 # ---- CVAE (include/cvae_hip.h) ----------------------------------------------------------------

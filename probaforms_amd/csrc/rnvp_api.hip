@@ -191,4 +191,21 @@ int rnvp_train_step(void *stream, const rnvp_shape *shape, float *params, const 
                           beta1, beta2, eps, weight_decay, step);
 }
 
+int rnvp_fit_epoch(void *stream, const rnvp_shape *shape, float *params, const uint8_t *masks,
+                   const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                   float *grad_buf, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                   double lr, double beta1, double beta2, double eps, double weight_decay,
+                   int64_t first_step, void *workspace, size_t workspace_bytes) {
+    if (n < 0 || batch_size < 1 || !perm || !loss_hist || first_step < 1) return RNVP_EINVAL;
+    int64_t k = 0;
+    for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
+        const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
+        const int rc = rnvp_train_step(stream, shape, params, masks, x, c, perm + s0, rows, 1.0f / (float)rows,
+                                       grad_buf, loss_hist + k, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+                                       weight_decay, first_step + k, workspace, workspace_bytes);
+        if (rc) return rc;
+    }
+    return RNVP_OK;
+}
+
 }  // extern "C"

@@ -57,7 +57,15 @@ def _install_oracle_backend():
         x_out.copy_(torch.from_numpy(o.sample(oshape(shape), params.numpy(), z.numpy(),
                                               None if c is None else c.numpy(), masks.numpy())))
 
+    def fit_epoch(shape, params, masks, x, c, perm, n, batch_size, grad_buf, loss_hist, m, v, lr, b1, b2, eps, wd,
+                  first_step, ws):
+        for k, s0 in enumerate(range(0, n, batch_size)):
+            rows = min(batch_size, n - s0)
+            train_step(shape, params, masks, x, c, perm[s0:s0 + rows], rows, 1.0 / rows, grad_buf, loss_hist[k:k + 1],
+                       m, v, lr, b1, b2, eps, wd, first_step + k, ws)
+
     _hip.loss_grad, _hip.adam_step, _hip.train_step, _hip.inverse = loss_grad, adam_step, train_step, inverse
+    _hip.fit_epoch = fit_epoch
     _hip.workspace_bytes = lambda shape, op, rows: 16
     for mod in (_engine, nflow, realnvp):
         mod.require_hip = lambda device: None
