@@ -289,3 +289,35 @@ def test_large_inverse_16m_rows():
     _hip.forward_logprob(shape, params, masks, tail, cc[-1000:].contiguous(), None, 1000, zz, None, None, None,
                          _ws(_hip, shape, _hip.OP_FORWARD, 1000))
     assert (zz - keep).abs().max().item() < 1e-3 and (zz - keep).abs().mean().item() < 5e-6
+
+
+def test_calls_can_be_captured_in_a_hip_graph():
+    """the entry points only enqueue work on the caller's stream (no allocation, no synchronisation):
+    a training step + sampling captured once and replayed gives the same results as eager calls"""
+    _hip, cs, shape, params, masks = _setup("c2")
+    n = cs["X"].shape[0]; P = cs["params"].size
+    x, c = _dev(cs["X"]), _dev(cs["C"])
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n); wsi = _ws(_hip, shape, _hip.OP_INVERSE, n)
+    zin = _dev(cs["Z"])
+
+    def run(p, m, v, g, loss, xs, step):
+        _hip.train_step(shape, p, masks, x, c, None, n, 1.0 / n, g, loss, m, v, 0.01, 0.9, 0.999, 1e-8, 0.0, step, ws)
+        _hip.inverse(shape, p, masks, zin, c, n, xs, wsi)
+
+    def fresh():
+        return (params.clone(), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda"), torch.empty(P, device="cuda"),
+                torch.empty(1, device="cuda"), torch.empty_like(zin))
+
+    ref = fresh(); run(*ref, 1)                                       # eager (also warms up one-time setup)
+    cap = fresh()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(*fresh(), 1)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run(*cap, 1)
+    graph.replay(); torch.cuda.synchronize()
+    for a, b in zip(ref, cap):
+        assert torch.equal(a, b)
