@@ -129,3 +129,16 @@ def test_flatten_parameters_keeps_state_dict_live():
     assert all(float(p.abs().sum()) == 0 for p in layer.state_dict().values())   # same memory
     layer.nn_t[0].weight.data = torch.ones(8, 6)                                   # user replaces a tensor
     assert not _engine.is_flat(plist, flat)
+
+
+def test_install_as_probaforms_import_path():
+    """drop-in name: after install_as_probaforms() the reference's import line resolves to the build"""
+    import subprocess, sys
+    code = ("import probaforms_amd; probaforms_amd.install_as_probaforms();"
+            "from probaforms.models import RealNVP, CVAE;"
+            "from probaforms.models.realnvp import RealNVPLayer;"
+            "from probaforms.models.interfaces import GenModel;"
+            "import probaforms_amd.models as m;"
+            "assert RealNVP is m.RealNVP and CVAE is m.CVAE and issubclass(RealNVP, GenModel); print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
