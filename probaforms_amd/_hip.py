@@ -103,6 +103,8 @@ _SIGNATURES = {
                                  _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
+    "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
+    "cvae_force_generic": (None, [C.c_int]),
     "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
     "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP]),
     "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP]),
@@ -245,6 +247,16 @@ def cvae_param_count(shape):
 
 def cvae_workspace_bytes(shape, max_rows):
     return int(lib().cvae_workspace_bytes(C.byref(shape), int(max_rows)))
+
+
+def cvae_kernel_path(shape):
+    """PATH_MFMA / PATH_GENERIC: the kernels cvae_loss_grad runs for this shape"""
+    return int(lib().cvae_kernel_path(C.byref(shape)))
+
+
+def cvae_force_generic(on):
+    """test / measurement aid: pin the generic CVAE kernels process-wide"""
+    lib().cvae_force_generic(1 if on else 0)
 
 
 def cvae_loss_grad(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out, ws):

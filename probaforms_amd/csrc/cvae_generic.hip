@@ -192,12 +192,28 @@ size_t cvae_param_count(const cvae_shape *shape) {
     return (size_t)k.enc.npn + k.dec.npn;
 }
 
+static std::atomic<int> g_force_generic{0};
+
+void cvae_force_generic(int on) { g_force_generic.store(on ? 1 : 0); }
+
+int cvae_kernel_path(const cvae_shape *shape) {
+    CvaeK k;
+    if (make_cvae(shape, &k) != RNVP_OK) return RNVP_EINVAL;
+    return (!g_force_generic.load() && cvae_mfma::supported(shape)) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
+}
+
+static size_t generic_cvae_workspace(const CvaeK &k) {
+    const size_t P = (size_t)k.enc.npn + k.dec.npn;
+    return align_up((size_t)kMaxGridTrain * P * sizeof(float), 256) + align_up(kMaxGridTrain * sizeof(float), 256) + 256;
+}
+
 size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows) {
     (void)max_rows;
     CvaeK k;
     if (make_cvae(shape, &k) != RNVP_OK) return 0;
-    const size_t P = (size_t)k.enc.npn + k.dec.npn;
-    return align_up((size_t)kMaxGridTrain * P * sizeof(float), 256) + align_up(kMaxGridTrain * sizeof(float), 256) + 256;
+    size_t b = generic_cvae_workspace(k);                       // either path may run (cvae_force_generic)
+    if (cvae_mfma::supported(shape)) { const size_t m = cvae_mfma::workspace_bytes(shape) + 256; if (m > b) b = m; }
+    return b;
 }
 
 int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, const float *x, const float *c,
@@ -216,6 +232,9 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, c
     }
     if (!params || !x || (k.c > 0 && !c) || !eps) return RNVP_EINVAL;
     if (!workspace || workspace_bytes < cvae_workspace_bytes(shape, n_rows)) return RNVP_EWORKSPACE;
+    if (!g_force_generic.load() && cvae_mfma::supported(shape))
+        return cvae_mfma::loss_grad(st, shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out,
+                                    workspace, workspace_bytes);
     int TB; size_t lds;
     if (!pick_tb(train_floats_per_row(k), n_rows, &TB, &lds)) return RNVP_EUNSUPPORTED;
     rc = allow(k_cvae_train, g_attr_train);

@@ -1,0 +1,546 @@
+// cvae_mfma.hip -- conditional VAE training step on f32 MFMA (gfx950): encoder -> reparameterise ->
+// decoder -> KL + MSE loss -> backward, one kernel, built from the register-chained blocks of the
+// RealNVP path (rnvp_mfma_layer.h).  Replaces CVAE.compute_loss + loss.backward()
+// (/root/reference/probaforms/models/cvae.py:186-203,243-246) for d <= 16, cdim <= 4, latent <= 4, one
+// hidden layer of any width, tanh (BASELINE.json configs[4] and the reference's defaults); other
+// shapes run on cvae_generic.hip.  C ABI: include/cvae_hip.h (cvae_loss_grad).
+//
+// Lane (q = lane >> 4, r = lane & 15) holds, for row r: x[4q..4q+3], c[q], eps[q], and -- after a
+// reduce-scatter over the lane groups -- mu[q], log_sigma[q], z[q].
+//   encoder : GEMM1 (K = 4 x-steps + 1 c-step) -> tanh -> heads as 4x4x1 blocks (mu | log_sigma)
+//   z       : mu + exp(log_sigma / 2) * eps, per lane
+//   decoder : GEMM1 (k-steps: z, c) -> tanh -> GEMM2 (one 16-row out tile: lane gets x_rec[4q..4q+3])
+//   backward: per hidden tile recompute GEMM1 + tanh; g_h by MFMA from register-resident g_out;
+//             d loss / d z as 4x4x1 blocks; weight gradients contract over rows through wave-private
+//             LDS transposition tiles, a ones column yields the hidden biases; per-wave LDS slots are
+//             added in wave order into the workgroup's partial (deterministic, no float atomics).
+#include <atomic>
+
+#include "../../include/cvae_hip.h"
+#include "rnvp_mfma_layer.h"
+
+#ifndef RNVP_WPE
+#define RNVP_WPE 2
+#endif
+
+namespace rnvp {
+namespace cvae_mfma {
+namespace {
+
+using mfma::f4;
+using mfma::mfma16;
+using mfma::mfma4;
+using mfma::tanh4;
+using mfma::swap_add32;
+using mfma::swap_add16;
+using mfma::opaque;
+using mfma::transpose16;
+using mfma::wave_lds_fence;
+using mfma::kTS;
+using mfma::kTanhScale;
+
+constexpr int kWaves = 4, kR = 4, kMaxGrid = 512, kSeg = 16, kFT = 8;
+
+struct CG {                      // geometry + offsets (floats)
+    int d, c, lat, h, HT;
+    // flat (oracle-order) parameter offsets
+    int fW1e, fb1e, fWmu, fWls, fbmu, fbls, fW1d, fb1d, fW2d, fb2d, P;
+    // packed weights
+    int oA1E, oB1E, oA2E, oA2ET, oA1D, oB1D, oA2D, oA2DT, oA1DX, oBH, oB2D, packed_floats;
+    // per-workgroup partial gradient: [enc: HT x 3 blocks][dec: HT x 2 blocks][head biases 16][b2d 16]
+    int gEnc, gDec, gBH, gB2D, gfloats;
+};
+
+CG make_cg(const cvae_shape *s) {
+    CG g;
+    g.d = s->d; g.c = s->c; g.lat = s->lat; g.h = s->hidden[0]; g.HT = (g.h + 15) / 16;
+    const int ne = g.d + g.c, nd = g.lat + g.c;
+    int o = 0;
+    g.fW1e = o; o += g.h * ne; g.fb1e = o; o += g.h;
+    g.fWmu = o; o += g.lat * g.h; g.fWls = o; o += g.lat * g.h; g.fbmu = o; o += g.lat; g.fbls = o; o += g.lat;
+    g.fW1d = o; o += g.h * nd; g.fb1d = o; o += g.h; g.fW2d = o; o += g.d * g.h; g.fb2d = o; o += g.d;
+    g.P = o;
+    o = 0;
+    g.oA1E = o; o += g.HT * 2 * 256; g.oB1E = o; o += g.HT * 16;
+    g.oA2E = o; o += g.HT * 2 * 256; g.oA2ET = o; o += g.HT * 256;
+    g.oA1D = o; o += g.HT * 256; g.oB1D = o; o += g.HT * 16;
+    g.oA2D = o; o += g.HT * 256; g.oA2DT = o; o += g.HT * 256; g.oA1DX = o; o += g.HT * 256;
+    g.oBH = o; o += 16; g.oB2D = o; o += 16;
+    g.packed_floats = o;
+    o = 0;
+    g.gEnc = o; o += g.HT * 3 * 256; g.gDec = o; o += g.HT * 2 * 256; g.gBH = o; o += 16; g.gB2D = o; o += 16;
+    g.gfloats = o;
+    return g;
+}
+
+// ---- packing ----------------------------------------------------------------------------------------
+__device__ float pack_value(const CG &g, int idx, const float *__restrict__ p) {
+    const int ne = g.d + g.c, nd = g.lat + g.c, h = g.h;
+    auto W1e = [&](int hid, int col) { return (hid < h && col >= 0) ? p[g.fW1e + hid * ne + col] : 0.f; };
+    auto W1d = [&](int hid, int col) { return (hid < h && col >= 0) ? p[g.fW1d + hid * nd + col] : 0.f; };
+    auto Whead = [&](int og, int i, int hid) {
+        return (hid < h && i < g.lat) ? p[(og == 0 ? g.fWmu : g.fWls) + i * h + hid] : 0.f;
+    };
+    auto W2d = [&](int out, int hid) { return (hid < h && out < g.d) ? p[g.fW2d + out * h + hid] : 0.f; };
+    if (idx < g.oB1E) {                                        // A1E [t][2][lane][4]: k-steps 0-3 x, 4 c
+        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8, k4 = rest & 1, t = rest >> 1;
+        const int kk = 4 * k4 + e, q = lane >> 4, i = lane & 15, hid = 16 * t + i;
+        int col = -1;
+        if (kk < 4) { const int j = 4 * q + kk; col = j < g.d ? j : -1; }
+        else if (kk == 4) col = q < g.c ? g.d + q : -1;
+        return kTanhScale * W1e(hid, col);
+    }
+    if (idx < g.oA2E) {                                        // B1E [t][q][4]
+        const int j = idx - g.oB1E, hid = 16 * (j >> 4) + (j & 15);
+        return hid < h ? kTanhScale * p[g.fb1e + hid] : 0.f;
+    }
+    if (idx < g.oA2ET) {                                       // A2E [t][og][lane][4 rho]  (4x4x1 heads)
+        const int j = idx - g.oA2E, rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8, og = rest & 1, t = rest >> 1;
+        return Whead(og, lane & 3, 16 * t + 4 * (lane >> 4) + rho);
+    }
+    if (idx < g.oA1D) {                                        // A2ET [t][lane][4]: k-step s: head (s, q)
+        const int j = idx - g.oA2ET, sidx = j & 3, lane = (j >> 2) & 63, t = j >> 8;
+        return sidx < 2 ? Whead(sidx, lane >> 4, 16 * t + (lane & 15)) : 0.f;
+    }
+    if (idx < g.oB1D) {                                        // A1D [t][lane][4]: k-step 0 z[q], 1 c[q]
+        const int j = idx - g.oA1D, kk = j & 3, lane = (j >> 2) & 63, t = j >> 8, q = lane >> 4, hid = 16 * t + (lane & 15);
+        int col = -1;
+        if (kk == 0) col = q < g.lat ? q : -1;
+        else if (kk == 1) col = q < g.c ? g.lat + q : -1;
+        return kTanhScale * W1d(hid, col);
+    }
+    if (idx < g.oA2D) {                                        // B1D [t][q][4]
+        const int j = idx - g.oB1D, hid = 16 * (j >> 4) + (j & 15);
+        return hid < h ? kTanhScale * p[g.fb1d + hid] : 0.f;
+    }
+    if (idx < g.oA2DT) {                                       // A2D [t][lane][4 rho]: A[i = out][k = q <-> hid 16t+4q+rho]
+        const int j = idx - g.oA2D, rho = j & 3, lane = (j >> 2) & 63, t = j >> 8;
+        return W2d(lane & 15, 16 * t + 4 * (lane >> 4) + rho);
+    }
+    if (idx < g.oA1DX) {                                       // A2DT [t][lane][4 rho]: A[i = hid][k = q <-> out 4q+rho]
+        const int j = idx - g.oA2DT, rho = j & 3, lane = (j >> 2) & 63, t = j >> 8;
+        return W2d(4 * (lane >> 4) + rho, 16 * t + (lane & 15));
+    }
+    if (idx < g.oBH) {                                         // A1DX [t][lane][4 rho]: W1d[hid 16t+4q+rho][z col i]
+        const int j = idx - g.oA1DX, rho = j & 3, lane = (j >> 2) & 63, t = j >> 8, i = lane & 3;
+        return W1d(16 * t + 4 * (lane >> 4) + rho, i < g.lat ? i : -1);
+    }
+    if (idx < g.oB2D) {                                        // BH [q][4]: b_mu[q], b_ls[q]
+        const int j = idx - g.oBH, e = j & 3, q = j >> 2;
+        if (q >= g.lat || e > 1) return 0.f;
+        return p[(e == 0 ? g.fbmu : g.fbls) + q];
+    }
+    {                                                          // B2D [q][4]
+        const int j = idx - g.oB2D;
+        return j < g.d ? p[g.fb2d + j] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack(CG g, const float *__restrict__ params, float *__restrict__ packed) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.packed_floats; t += gridDim.x * blockDim.x)
+        packed[t] = pack_value(g, t, params);
+}
+
+// lane group q keeps element q of a 4-vector whose partial sums are spread over the 4 lane groups
+__device__ __forceinline__ float reduce_scatter4(f4 v) {
+    return swap_add16(swap_add32(v[0], v[2]), swap_add32(v[1], v[3]));
+}
+
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+
+// ---- the fused step --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, const float *__restrict__ c,
+            const int64_t *__restrict__ row_index, const float *__restrict__ eps, int64_t n, float inv_B, float klw,
+            float *gpart, float *losspart, int do_grad) {
+    constexpr int R = kR, RH = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int q = lane >> 4, r = lane & 15;
+    const int HT = g.HT;
+    const int SLOT = kFT * 3 * 256 + 32;                          // floats of one wave's slot (+ bias sums)
+    float *slot = lds + wave * SLOT;
+    float *tb = lds + kWaves * SLOT + wave * (7 * 16 * kTS);      // wave-private transposition tiles
+    float *bufG = tb, *bufI = tb + 16 * kTS, *bufH = tb + 3 * 16 * kTS;   // g_out^T | [in|1]^T (2 tiles) | (h, g_pre) x RH
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const bool full = (g.d == 16) && (g.c == 4);
+    float *gp = gpart + (size_t)blockIdx.x * g.gfloats;
+    float wave_sum = 0.f;
+    bool first = true;
+    const f4 bh = *reinterpret_cast<const f4 *>(wp + g.oBH + q * 4);
+    const f4 b2d = *reinterpret_cast<const f4 *>(wp + g.oB2D + q * 4);
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
+        float xr[R][4], cr[R][1], er[R], mu[R], ls[R], el[R], z[R];
+        bool valid[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const int64_t row = base + rt * 16 + r;
+            valid[rt] = row < n;
+            const int64_t src = valid[rt] ? (row_index ? row_index[row] : row) : 0;
+            mfma::load_row<2, 1>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
+            er[rt] = (valid[rt] && q < g.lat) ? eps[row * g.lat + q] : 0.f;
+        }
+        // ---- encoder forward ---------------------------------------------------------------------
+        {
+            f4 outE[R][2];
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) { outE[rt][0] = f4{0.f, 0.f, 0.f, 0.f}; outE[rt][1] = f4{0.f, 0.f, 0.f, 0.f}; }
+            const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2 = wp + g.oA2E + lane * 4;
+            for (int t = 0; t < HT; ++t) {
+                const f4 a10 = *opaque(pA1 + (size_t)(2 * t) * 256), a11 = *opaque(pA1 + (size_t)(2 * t + 1) * 256);
+                const f4 b1 = *opaque(pB1 + t * 16);
+                const f4 a20 = *opaque(pA2 + (size_t)(2 * t) * 256), a21 = *opaque(pA2 + (size_t)(2 * t + 1) * 256);
+                f4 hv[R];
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) {
+                    f4 acc = b1;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = mfma16(a10[kk], xr[rt][kk], acc);
+                    acc = mfma16(a11[0], cr[rt][0], acc);
+                    hv[rt] = tanh4(acc);
+                }
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) {
+                        outE[rt][0] = mfma4(a20[rho], hv[rt][rho], outE[rt][0]);
+                        outE[rt][1] = mfma4(a21[rho], hv[rt][rho], outE[rt][1]);
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                mu[rt] = reduce_scatter4(outE[rt][0]) + bh[0];
+                ls[rt] = reduce_scatter4(outE[rt][1]) + bh[1];
+                el[rt] = expf(0.5f * ls[rt]);
+                z[rt] = fmaf(el[rt], er[rt], mu[rt]);                                      // cvae.py:188
+            }
+        }
+        // ---- decoder forward -----------------------------------------------------------------------
+        f4 xrec[R];
+        {
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) xrec[rt] = b2d;
+            const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4, *pA2 = wp + g.oA2D + lane * 4;
+            for (int t = 0; t < HT; ++t) {
+                const f4 a1 = *opaque(pA1 + (size_t)t * 256), b1 = *opaque(pB1 + t * 16), a2 = *opaque(pA2 + (size_t)t * 256);
+                f4 hv[R];
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) {
+                    f4 acc = mfma16(a1[0], z[rt], b1);
+                    acc = mfma16(a1[1], cr[rt][0], acc);
+                    hv[rt] = tanh4(acc);
+                }
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) xrec[rt] = mfma16(a2[rho], hv[rt][rho], xrec[rt]);
+            }
+        }
+        // ---- loss: KL_weight * KL + MSE (cvae.py:190-193) ----------------------------------------
+        f4 gx[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            float kl = (q < g.lat) ? (1.f + ls[rt] - mu[rt] * mu[rt] - expf(ls[rt])) : 0.f, se = 0.f;
+            const float sc = valid[rt] ? inv_B : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float df = xrec[rt][e] - xr[rt][e];
+                se = fmaf(df, df, se);
+                gx[rt][e] = (2.f * sc / (float)g.d) * df;                                    // d MSE / d x_rec
+            }
+            kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+            se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+            float v = (valid[rt] && q == 0) ? klw * (-0.5f * kl) + se / (float)g.d : 0.f;
+            wave_sum += row16_sum(v);
+        }
+        if (!do_grad) continue;                                                              // uniform
+
+        // ---- decoder backward ------------------------------------------------------------------------
+        float goT[R][4], inT[R][4];
+        f4 gb2 = gx[0];
+#pragma unroll
+        for (int rt = 1; rt < R; ++rt) gb2 += gx[rt];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            transpose16(bufG, gx[rt], lane, goT[rt]);
+            transpose16(bufI, f4{z[rt], cr[rt][0], q == 0 ? 1.f : 0.f, 0.f}, lane, inT[rt]);       // [z | c | 1]
+        }
+        f4 ginz[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) ginz[rt] = f4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4;
+            const float *pA2T = wp + g.oA2DT + lane * 4, *pA1X = wp + g.oA1DX + lane * 4;
+            for (int t = 0; t < HT; ++t) {
+                const f4 a1 = *opaque(pA1 + (size_t)t * 256), b1 = *opaque(pB1 + t * 16);
+                const f4 a2t = *opaque(pA2T + (size_t)t * 256), a1x = *opaque(pA1X + (size_t)t * 256);
+                f4 gW1 = f4{0.f, 0.f, 0.f, 0.f}, gW2 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r0 = 0; r0 < R; r0 += RH) {
+                    f4 gpv[RH];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int u = 0; u < RH; ++u) {
+                        const int rt = r0 + u;
+                        f4 acc = mfma16(a1[0], z[rt], b1);
+                        acc = mfma16(a1[1], cr[rt][0], acc);
+                        const f4 hv = tanh4(acc);
+                        f4 gh = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho) gh = mfma16(a2t[rho], gx[rt][rho], gh);
+                        gpv[u] = gh * (1.0f - hv * hv);
+                        *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
+                        *reinterpret_cast<f4 *>(bufH + (2 * u + 1) * 16 * kTS + r * kTS + 4 * q) = gpv[u];
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                        for (int u = 0; u < RH; ++u) ginz[r0 + u] = mfma4(a1x[rho], gpv[u][rho], ginz[r0 + u]);
+#pragma unroll
+                    for (int u = 0; u < RH; ++u)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const float hT = bufH[(2 * u) * 16 * kTS + (4 * ks + q) * kTS + r];
+                            const float pT = bufH[(2 * u + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
+                            gW2 = mfma16(hT, goT[r0 + u][ks], gW2);
+                            gW1 = mfma16(pT, inT[r0 + u][ks], gW1);
+                        }
+                }
+                float *sb = slot + (size_t)(t % kFT) * 2 * 256 + lane * 4;
+                *reinterpret_cast<f4 *>(sb) = gW1;
+                *reinterpret_cast<f4 *>(sb + 256) = gW2;
+                const bool last = (t + 1 == HT);
+                if ((t + 1) % kFT == 0 || last) {
+                    if (last) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float v = row16_sum(gb2[e]); if (r == 0) slot[kFT * 3 * 256 + q * 4 + e] = v; }
+                    }
+                    __syncthreads();
+                    const int t0 = (t / kFT) * kFT, nfl4 = (t + 1 - t0) * 2 * 256 / 4;
+                    f4 *dst = reinterpret_cast<f4 *>(gp + g.gDec + (size_t)t0 * 2 * 256);
+                    const f4 *s0 = reinterpret_cast<const f4 *>(lds);
+                    for (int i = tid; i < nfl4; i += kWaves * 64) {
+                        f4 v = s0[i];
+#pragma unroll
+                        for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
+                        dst[i] = first ? v : dst[i] + v;
+                    }
+                    if (last && tid < 16) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < kWaves; ++w) v += lds[w * SLOT + kFT * 3 * 256 + tid];
+                        gp[g.gB2D + tid] = first ? v : gp[g.gB2D + tid] + v;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        // ---- gradient wrt mu / log_sigma ------------------------------------------------------------
+        float gmu[R], gls[R];
+        f4 gbh = f4{0.f, 0.f, 0.f, 0.f};
+        float goTe[R][4], inTe[R][2][4];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const float gz = reduce_scatter4(ginz[rt]);
+            const float sc = valid[rt] ? inv_B : 0.f;
+            gmu[rt] = fmaf(klw * sc, mu[rt], gz);
+            gls[rt] = gz * er[rt] * 0.5f * el[rt] + klw * sc * (-0.5f) * (1.f - expf(ls[rt]));
+            if (q >= g.lat) { gmu[rt] = 0.f; gls[rt] = 0.f; }
+            gbh[0] += gmu[rt]; gbh[1] += gls[rt];
+            transpose16(bufG, f4{gmu[rt], gls[rt], 0.f, 0.f}, lane, goTe[rt]);                    // out 4q: mu[q], 4q+1: ls[q]
+            transpose16(bufI, f4{xr[rt][0], xr[rt][1], xr[rt][2], xr[rt][3]}, lane, inTe[rt][0]);   // x features
+            transpose16(bufI + 16 * kTS, f4{cr[rt][0], q == 0 ? 1.f : 0.f, 0.f, 0.f}, lane, inTe[rt][1]);   // [c | 1]
+        }
+        // ---- encoder backward ------------------------------------------------------------------------
+        {
+            const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2T = wp + g.oA2ET + lane * 4;
+            for (int t = 0; t < HT; ++t) {
+                const f4 a10 = *opaque(pA1 + (size_t)(2 * t) * 256), a11 = *opaque(pA1 + (size_t)(2 * t + 1) * 256);
+                const f4 b1 = *opaque(pB1 + t * 16), a2t = *opaque(pA2T + (size_t)t * 256);
+                f4 gW1a = f4{0.f, 0.f, 0.f, 0.f}, gW1b = f4{0.f, 0.f, 0.f, 0.f}, gW2 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r0 = 0; r0 < R; r0 += RH) {
+                    wave_lds_fence();
+#pragma unroll
+                    for (int u = 0; u < RH; ++u) {
+                        const int rt = r0 + u;
+                        f4 acc = b1;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) acc = mfma16(a10[kk], xr[rt][kk], acc);
+                        acc = mfma16(a11[0], cr[rt][0], acc);
+                        const f4 hv = tanh4(acc);
+                        f4 gh = mfma16(a2t[0], gmu[rt], f4{0.f, 0.f, 0.f, 0.f});
+                        gh = mfma16(a2t[1], gls[rt], gh);
+                        const f4 gpv = gh * (1.0f - hv * hv);
+                        *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
+                        *reinterpret_cast<f4 *>(bufH + (2 * u + 1) * 16 * kTS + r * kTS + 4 * q) = gpv;
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int u = 0; u < RH; ++u)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const float hT = bufH[(2 * u) * 16 * kTS + (4 * ks + q) * kTS + r];
+                            const float pT = bufH[(2 * u + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
+                            gW2 = mfma16(hT, goTe[r0 + u][ks], gW2);
+                            gW1a = mfma16(pT, inTe[r0 + u][0][ks], gW1a);
+                            gW1b = mfma16(pT, inTe[r0 + u][1][ks], gW1b);
+                        }
+                }
+                float *sb = slot + (size_t)(t % kFT) * 3 * 256 + lane * 4;
+                *reinterpret_cast<f4 *>(sb) = gW1a;
+                *reinterpret_cast<f4 *>(sb + 256) = gW1b;
+                *reinterpret_cast<f4 *>(sb + 512) = gW2;
+                const bool last = (t + 1 == HT);
+                if ((t + 1) % kFT == 0 || last) {
+                    if (last) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) { const float v = row16_sum(gbh[e]); if (r == 0) slot[kFT * 3 * 256 + 16 + q * 4 + e] = v; }
+                    }
+                    __syncthreads();
+                    const int t0 = (t / kFT) * kFT, nfl4 = (t + 1 - t0) * 3 * 256 / 4;
+                    f4 *dst = reinterpret_cast<f4 *>(gp + g.gEnc + (size_t)t0 * 3 * 256);
+                    const f4 *s0 = reinterpret_cast<const f4 *>(lds);
+                    for (int i = tid; i < nfl4; i += kWaves * 64) {
+                        f4 v = s0[i];
+#pragma unroll
+                        for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
+                        dst[i] = first ? v : dst[i] + v;
+                    }
+                    if (last && tid < 16) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < kWaves; ++w) v += lds[w * SLOT + kFT * 3 * 256 + 16 + tid];
+                        gp[g.gBH + tid] = first ? v : gp[g.gBH + tid] + v;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        first = false;
+    }
+    if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
+}
+
+__global__ void __launch_bounds__(256)
+k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restrict__ seg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f4 a = f4{0.f, 0.f, 0.f, 0.f};
+    for (int b = blockIdx.y; b < G; b += gridDim.y) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
+    reinterpret_cast<f4 *>(seg)[(size_t)blockIdx.y * n4 + i] = a;
+}
+
+// D-layout location of (row i of the 16-row M tile = hid & 15, column j) inside a 256-float block
+__device__ __forceinline__ int dloc(int hid, int col) { const int i = hid & 15; return (16 * (i >> 2) + col) * 4 + (i & 3); }
+
+__global__ void __launch_bounds__(256)
+k_unpack(CG g, const float *__restrict__ seg, int S, const float *__restrict__ losspart, int nloss, float inv_B,
+         float *__restrict__ grad, float *loss) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.P) {
+        if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
+            const int lane = threadIdx.x - 192;
+            float a = 0.f;
+            for (int i = lane; i < nloss; i += 64) a += losspart[i];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            if (lane == 0) loss[0] = a * inv_B;
+        }
+        return;
+    }
+    if (!grad) return;
+    const int h = g.h, ne = g.d + g.c, nd = g.lat + g.c;
+    int loc;
+    if (p < g.fb1e) {                                          // W1e [h][d + c]
+        const int hid = p / ne, col = p - hid * ne;
+        const int nt = col < g.d ? 0 : 1, cj = col < g.d ? col : 4 * (col - g.d);
+        loc = g.gEnc + ((hid >> 4) * 3 + nt) * 256 + dloc(hid, cj);
+    } else if (p < g.fWmu) {                                   // b1e: the ones column (tile 1, column 1)
+        const int hid = p - g.fb1e;
+        loc = g.gEnc + ((hid >> 4) * 3 + 1) * 256 + dloc(hid, 1);
+    } else if (p < g.fbmu) {                                   // W_mu / W_ls [lat][h]
+        const int j = p - g.fWmu, og = j >= g.lat * h, jj = j - og * g.lat * h, i = jj / h, hid = jj - i * h;
+        loc = g.gEnc + ((hid >> 4) * 3 + 2) * 256 + dloc(hid, 4 * i + og);
+    } else if (p < g.fW1d) {                                   // b_mu, b_ls
+        const int j = p - g.fbmu, og = j >= g.lat, i = j - og * g.lat;
+        loc = g.gBH + i * 4 + og;
+    } else if (p < g.fb1d) {                                   // W1d [h][lat + c]
+        const int j = p - g.fW1d, hid = j / nd, col = j - hid * nd;
+        const int cj = col < g.lat ? 4 * col : 4 * (col - g.lat) + 1;
+        loc = g.gDec + ((hid >> 4) * 2) * 256 + dloc(hid, cj);
+    } else if (p < g.fW2d) {                                   // b1d: ones column 2
+        const int hid = p - g.fb1d;
+        loc = g.gDec + ((hid >> 4) * 2) * 256 + dloc(hid, 2);
+    } else if (p < g.fb2d) {                                   // W2d [d][h]
+        const int j = p - g.fW2d, out = j / h, hid = j - out * h;
+        loc = g.gDec + ((hid >> 4) * 2 + 1) * 256 + dloc(hid, out);
+    } else {                                                   // b2d
+        loc = g.gB2D + (p - g.fb2d);
+    }
+    float a = 0.f;
+    for (int b = 0; b < S; ++b) a += seg[(size_t)b * g.gfloats + loc];
+    grad[p] = a;
+}
+
+size_t lds_bytes() { return ((size_t)kWaves * (kFT * 3 * 256 + 32) + (size_t)kWaves * 7 * 16 * kTS) * sizeof(float); }
+
+}  // namespace
+
+bool supported(const cvae_shape *s) {
+    return s && s->n_hidden == 1 && s->act == 0 && s->d >= 1 && s->d <= 16 && s->c >= 0 && s->c <= 4 && s->lat >= 1 &&
+           s->lat <= 4 && s->hidden[0] >= 1;
+}
+
+size_t workspace_bytes(const cvae_shape *s) {
+    const CG g = make_cg(s);
+    return align_up((size_t)g.packed_floats * 4, 256) + align_up((size_t)kMaxGrid * g.gfloats * 4, 256) +
+           align_up((size_t)kSeg * g.gfloats * 4, 256) + align_up((size_t)kMaxGrid * kWaves * 4, 256);
+}
+
+int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const float *x, const float *c,
+              const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
+              float *loss_out, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < workspace_bytes(s)) return RNVP_EWORKSPACE;
+    const CG g = make_cg(s);
+    char *w = static_cast<char *>(ws);
+    float *packed = reinterpret_cast<float *>(w); w += align_up((size_t)g.packed_floats * 4, 256);
+    float *gpart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * g.gfloats * 4, 256);
+    float *seg = reinterpret_cast<float *>(w); w += align_up((size_t)kSeg * g.gfloats * 4, 256);
+    float *losspart = reinterpret_cast<float *>(w);
+    hipLaunchKernelGGL(k_pack, dim3((g.packed_floats + 255) / 256), dim3(256), 0, st, g, params, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    static std::atomic<int> attr{0};
+    if (!attr.load(std::memory_order_relaxed)) {
+        RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvae_mfma),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.store(1, std::memory_order_relaxed);
+    }
+    const int64_t rows_per_wg = (int64_t)kWaves * kR * 16, ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
+    {
+        KernelTimer timer(st);
+        hipLaunchKernelGGL(k_cvae_mfma, dim3(grid), dim3(kWaves * 64), lds_bytes(), st, g, packed, x, c, row_index, eps, n,
+                           inv_B, klw, gpart, losspart, grad_out ? 1 : 0);
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    int S = 0;
+    if (grad_out) {
+        const size_t n4 = (size_t)g.gfloats / 4;
+        S = grid < kSeg ? grid : kSeg;
+        hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), S), dim3(256), 0, st, gpart, grid, n4, seg);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_unpack, dim3(g.P / 256 + 2), dim3(256), 0, st, g, seg, S, losspart, grid * kWaves, inv_B, grad_out,
+                       loss_out);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+}  // namespace cvae_mfma
+}  // namespace rnvp

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../include/rnvp_hip.h"
+#include "../../include/cvae_hip.h"
 
 namespace rnvp {
 
@@ -68,6 +69,15 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
 
 int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
                             float loss_scale, float *grad_out, float *loss_out);
+
+// ---- CVAE step on MFMA: cvae_mfma.hip (d <= 16, c <= 4, latent <= 4, one tanh hidden layer) ----
+namespace cvae_mfma {
+bool supported(const ::cvae_shape *s);
+size_t workspace_bytes(const ::cvae_shape *s);
+int loss_grad(hipStream_t st, const ::cvae_shape *s, const float *params, const float *x, const float *c,
+              const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
+              float *loss_out, void *ws, size_t ws_bytes);
+}  // namespace cvae_mfma
 
 // ---- Adam arithmetic shared by k_adam (rnvp_adam.hip) and the fused reduce+Adam kernel ------------
 // torch.optim.Adam (realnvp.py:205-207,251) as separately rounded tensor ops; written so that

@@ -63,27 +63,6 @@ struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2
 #endif
 constexpr int kWaves = RNVP_TRAIN_WAVES;    // waves per workgroup
 constexpr int kMaxGridTrain = 512;
-constexpr int kTS = 20;                  // row stride (floats) of a 16-wide transposition tile
-
-// LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, so only the
-// compiler has to be kept from reordering the accesses.
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// accumulator-layout tile (lane (q, r): features 4q..4q+3 of row r)  ->  k-step operands for a
-// contraction over rows (lane (qk, j): feature j of rows 4*ks + qk, ks = 0..3)
-__device__ __forceinline__ void transpose16(float *buf, f4 v, int lane, float (&o)[4]) {
-    if (kAblate & 1) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; return; }
-    const int q = lane >> 4, r = lane & 15;
-    wave_lds_fence();
-    *reinterpret_cast<f4 *>(buf + r * kTS + 4 * q) = v;
-    wave_lds_fence();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) o[ks] = buf[(4 * ks + q) * kTS + r];
-}
 
 template <int NF, int CQ> struct Dims {
     static constexpr int KS1 = NF + CQ;

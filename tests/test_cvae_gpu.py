@@ -41,8 +41,58 @@ def test_encode_decode(name):
     np.testing.assert_allclose(x.cpu().numpy(), g["decoded"], rtol=2e-6, atol=2e-6)
 
 
+@pytest.fixture(params=["auto", "generic"])
+def path(request):
+    """run the step on the kernels the library picks (MFMA where supported) and pinned to the generic ones"""
+    from probaforms_amd import _hip
+    _hip.cvae_force_generic(request.param == "generic")
+    yield request.param
+    _hip.cvae_force_generic(False)
+
+
+def test_kernel_path_selection():
+    from probaforms_amd import _hip
+    for name, (d, c, lat, hidden, act, _) in CASES.items():
+        want = _hip.PATH_GENERIC if name == "relu_mh" else _hip.PATH_MFMA
+        assert _hip.cvae_kernel_path(_hip.CvaeShape.make(d, c, lat, hidden, act)) == want
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(17, 4, 2, (128,), "tanh")) == _hip.PATH_GENERIC
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 5, 2, (128,), "tanh")) == _hip.PATH_GENERIC
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 5, (128,), "tanh")) == _hip.PATH_GENERIC
+    _hip.cvae_force_generic(True)
+    try:
+        assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 2, (128,), "tanh")) == _hip.PATH_GENERIC
+    finally:
+        _hip.cvae_force_generic(False)
+
+
+@pytest.mark.parametrize("d,c,lat,h", [(1, 0, 1, 1), (13, 1, 3, 37), (16, 2, 4, 200), (7, 4, 1, 16), (2, 2, 2, 300),
+                                       (16, 4, 4, 128)])
+@pytest.mark.parametrize("n", [1, 63, 257, 5000])
+def test_mfma_step_shapes_vs_oracle(d, c, lat, h, n):
+    """padded sizes, ragged row tiles, hidden widths past one flush block: MFMA step == float64 oracle"""
+    from oracle import CvaeOracle, CvaeShape
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(d * 1000 + h + n)
+    shape = _hip.CvaeShape.make(d, c, lat, (h,), "tanh")
+    assert _hip.cvae_kernel_path(shape) == _hip.PATH_MFMA
+    P = _hip.cvae_param_count(shape)
+    p = (rng.standard_normal(P) * 0.3).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    C = rng.standard_normal((n, c)).astype(np.float32) if c else None
+    eps = rng.standard_normal((n, lat)).astype(np.float32)
+    lo, go = CvaeOracle(64).loss_grad(CvaeShape.make(d, c, lat, (h,), "tanh"), p, X, C, eps, 0.3)
+    ws = torch.empty(_hip.cvae_workspace_bytes(shape, n), dtype=torch.uint8, device="cuda")
+    grad = torch.full((P,), float("nan"), device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.cvae_loss_grad(shape, _dev(p), _dev(X), _dev(C), None, _dev(eps), n, 1.0 / n, 0.3, grad, loss, ws)
+    assert abs(float(loss) - lo) < 3e-6 * max(1.0, abs(lo))
+    assert np.abs(grad.cpu().numpy() - go).max() < 3e-6 * np.abs(go).max()
+    g2 = torch.empty_like(grad)                                     # deterministic: run-to-run bit-identical
+    _hip.cvae_loss_grad(shape, _dev(p), _dev(X), _dev(C), None, _dev(eps), n, 1.0 / n, 0.3, g2, loss, ws)
+    assert torch.equal(grad, g2)
+
+
 @pytest.mark.parametrize("name", list(CASES))
-def test_loss_grad_and_adam(name):
+def test_loss_grad_and_adam(name, path):
     from oracle import CvaeOracle, CvaeShape
     _hip, g, shape, klw, C = _load(name)
     d, c, lat, hidden, act, _ = CASES[name]
