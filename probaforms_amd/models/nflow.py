@@ -57,6 +57,18 @@ class StandardNormalPrior:
         return torch.randn(shape).to(self.device)          # host generator: the reference's CPU stream
 
 
+def row_chunks(n, rows):
+    """[(lo, m)] covering n rows in chunks of `rows` (a multiple of 16); a tail shorter than 16 rows is
+    merged into the chunk before it.  torch's CPU randn fills blocks of 16 values and redraws the LAST
+    16 values of a call whose size is not a multiple of 16, so these chunked draws consume the global
+    generator exactly like one randn(n, d) for any d."""
+    out = [(lo, min(rows, n - lo)) for lo in range(0, n, rows)]
+    if len(out) > 1 and out[-1][1] < 16:
+        lo, m = out[-2]
+        out[-2:] = [(lo, m + out[-1][1])]
+    return out
+
+
 class NormalizingFlow(nn.Module):
     """Layers + prior (nflow.py:71-145).
 
@@ -121,3 +133,81 @@ class NormalizingFlow(nn.Module):
         z = self.prior.sample((n,))
         z = torch.as_tensor(z, dtype=torch.float32).to(eng.device).contiguous()
         return eng.inverse(z, C, out=z)
+
+    # -- host staging -------------------------------------------------
+    PIPELINE_CHUNK_BYTES = 32 << 20        # of one chunk of output rows
+
+    def pipelined_rows(self, n):
+        """rows per chunk (a multiple of 16, see row_chunks) if sample_to_host() would pipeline n rows, else 0"""
+        if not self._fused_prior():
+            return 0
+        rows = max(16, (self.PIPELINE_CHUNK_BYTES // (4 * self.prior.var_size)) // 16 * 16)
+        return rows if n > 2 * rows else 0
+
+    def sample_to_host(self, C):
+        """``sample(C).cpu().numpy()`` (realnvp.py:279-282) as a three-stage pipeline over row chunks:
+        prior draw on the host generator (or on the device) + H2D of z and C | inverse kernel | D2H
+        into a pinned result, each on its own HIP stream, double buffered.  C: python int, numpy array
+        or tensor.  Returns a float32 numpy array [n, var_size] (backed by pinned host memory); the
+        values are those of the one-shot path."""
+        import numpy as np
+        eng = self.engine()
+        dev = eng.device
+        if type(C) == type(1):
+            n, Cn, Cd = C, None, None
+        else:
+            n = len(C)
+            on_dev = torch.is_tensor(C) and C.device.type == "cuda"
+            Cd = C.to(dev, torch.float32).contiguous() if on_dev else None
+            Cn = None if on_dev else (C.detach().numpy() if torch.is_tensor(C) else np.asarray(C))
+        rows = self.pipelined_rows(n)
+        if rows == 0:
+            if Cn is not None:
+                Cd = self._on_device(torch.from_numpy(np.ascontiguousarray(Cn)), eng)
+            return self.sample(n if Cd is None else Cd).cpu().detach().numpy()
+        d = self.prior.var_size
+        cdim = 0 if type(C) == type(1) else C.shape[1]
+        host_rng = self.prior.host_rng
+        NB, cap = 3, rows + 15
+        out = torch.empty((n, d), dtype=torch.float32, pin_memory=True)
+        zdev = [torch.empty((cap, d), dtype=torch.float32, device=dev) for _ in range(NB)]
+        zpin = [torch.empty((cap, d), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if host_rng else None
+        stage_c = cdim > 0 and Cn is not None
+        cdev = [torch.empty((cap, cdim), dtype=torch.float32, device=dev) for _ in range(NB)] if stage_c else None
+        cpin = [torch.empty((cap, cdim), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if stage_c else None
+        cpin_np = [t.numpy() for t in cpin] if stage_c else None
+        cur = torch.cuda.current_stream(dev)
+        h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ev_in = [torch.cuda.Event() for _ in range(NB)]
+        ev_k = [torch.cuda.Event() for _ in range(NB)]
+        ev_out = [torch.cuda.Event() for _ in range(NB)]
+        h2d.wait_stream(cur)
+        for k, (lo, m) in enumerate(row_chunks(n, rows)):
+            i = k % NB
+            if k >= NB:
+                ev_out[i].synchronize()                 # buffer set i is free again (its D2H has landed)
+            if host_rng:
+                torch.randn((m, d), out=zpin[i][:m])    # global CPU generator: the reference's stream
+            if stage_c:
+                # numpy's single-threaded copy/cast (float32 rounding = torch's): torch's CPU copy_ wakes
+                # its whole thread pool per call, measured 5 ms per 8 MB chunk on a 256-core host
+                np.copyto(cpin_np[i][:m], Cn[lo:lo + m], casting="unsafe")
+            with torch.cuda.stream(h2d):
+                if host_rng:
+                    zdev[i][:m].copy_(zpin[i][:m], non_blocking=True)
+                if stage_c:
+                    cdev[i][:m].copy_(cpin[i][:m], non_blocking=True)
+                ev_in[i].record(h2d)
+            cur.wait_event(ev_in[i])
+            if not host_rng:
+                zdev[i][:m].normal_()
+            cc = None if cdim == 0 else (cdev[i][:m] if stage_c else Cd[lo:lo + m])
+            eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
+            ev_k[i].record(cur)
+            d2h.wait_event(ev_k[i])
+            with torch.cuda.stream(d2h):
+                out[lo:lo + m].copy_(zdev[i][:m], non_blocking=True)
+                ev_out[i].record(d2h)
+        d2h.synchronize()
+        cur.wait_stream(d2h)
+        return out.numpy()

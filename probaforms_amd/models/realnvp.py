@@ -20,6 +20,8 @@ DEVICE = default_device()
 
 
 def _to_device_f32(a, device):
+    if torch.is_tensor(a):
+        return a.to(device).to(torch.float32).contiguous()
     a = np.asarray(a)
     if a.ndim > 0 and not a.flags.c_contiguous:
         a = np.ascontiguousarray(a)              # (a 0-d input stays 0-d: len() then raises TypeError as in the reference)
@@ -201,6 +203,10 @@ class RealNVP(GenModel):
             bar.close()
 
     def sample(self, C=100):
+        n = C if type(C) == type(1) else len(C)
+        if self.nf.pipelined_rows(n):
+            # large draws: prior / H2D / inverse kernel / D2H overlapped over row chunks, same values
+            return self.nf.sample_to_host(C)
         if type(C) != type(1):
             C = _to_device_f32(C, self.nf.engine().device)
         X = self.nf.sample(C).cpu().detach().numpy()
