@@ -38,8 +38,10 @@ using mfma::transpose16;
 using mfma::wave_lds_fence;
 using mfma::kTS;
 using mfma::kTanhScale;
+using mfma::kSeg;
+using mfma::k_sum_segments;
 
-constexpr int kWaves = 4, kR = 4, kMaxGrid = 512, kSeg = 16, kFT = 8;
+constexpr int kWaves = 4, kR = 4, kMaxGrid = 512, kFT = 8;
 
 struct CG {                      // geometry + offsets (floats)
     int d, c, lat, h, HT;
@@ -426,15 +428,6 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
         first = false;
     }
     if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
-}
-
-__global__ void __launch_bounds__(256)
-k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restrict__ seg) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    f4 a = f4{0.f, 0.f, 0.f, 0.f};
-    for (int b = blockIdx.y; b < G; b += gridDim.y) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
-    reinterpret_cast<f4 *>(seg)[(size_t)blockIdx.y * n4 + i] = a;
 }
 
 // D-layout location of (row i of the 16-row M tile = hid & 15, column j) inside a 256-float block

@@ -146,6 +146,21 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- partial sums over workgroups, stage 1 (shared by the RealNVP and CVAE steps) ---------------------
+// G per-workgroup partials of n4 float4 -> kSeg segment sums (segment s adds partials s, s+kSeg, ... in
+// index order: deterministic); coalesced float4 streaming.
+constexpr int kSeg = 16;
+
+static __global__ void __launch_bounds__(256)
+k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restrict__ seg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sgi = blockIdx.y;
+    if (i >= n4) return;
+    f4 a = f4{0.f, 0.f, 0.f, 0.f};
+    for (int b = sgi; b < G; b += gridDim.y) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
+    reinterpret_cast<f4 *>(seg)[(size_t)sgi * n4 + i] = a;
+}
+
 // accumulator-layout tile (lane (q, r): features 4q..4q+3 of row r)  ->  k-step operands for a
 // contraction over rows (lane (qk, j): feature j of rows 4*ks + qk, ks = 0..3)
 __device__ __forceinline__ void transpose16(float *buf, f4 v, int lane, float (&o)[4]) {

@@ -464,19 +464,6 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
 #endif
 }
 
-// ---- partial sums over workgroups, stage 1: coalesced, float4, G partials -> kSeg segment sums -------
-constexpr int kSeg = 16;
-
-__global__ void __launch_bounds__(256)
-k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restrict__ seg) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int sgi = blockIdx.y;
-    if (i >= n4) return;
-    f4 a = f4{0.f, 0.f, 0.f, 0.f};
-    for (int b = sgi; b < G; b += gridDim.y) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
-    reinterpret_cast<f4 *>(seg)[(size_t)sgi * n4 + i] = a;
-}
-
 // ---- stage 2: segment sums -> flat reference-order gradient -----------------------------------------
 // One thread per flat parameter; finds where the packed gradient keeps it (or that the masks make
 // it dead: exactly zero, as in the reference) and sums the workgroup partials in index order.
