@@ -545,13 +545,32 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
 #ifndef RNVP_TRAIN_R2
 #define RNVP_TRAIN_R2 4
 #endif
+// Row tiles per wave.  RMAX (4 / 2 / 1 for NF = 2 / 4 / 8, what the registers allow) is fastest once every CU has a
+// workgroup; smaller batches spread over the chip with fewer tiles per wave instead of running long chains on
+// a few CUs.  Measured on C2 (one workgroup resident per CU): a workgroup's run time is ~1 : 1.4 : 2.15 for
+// R = 1 : 2 : 4 and the step takes ceil(workgroups / 256) such rounds -- pick the cheapest
+// (8192 rows: 0.300 -> 0.162 ms, 32768 rows: 0.319 -> 0.218 ms, 65536 rows and up: R = RMAX as before).
+// A row's gradient contribution does not depend on R; the summation order over rows does (still
+// deterministic for a given batch size).
 template <int NF, int CQ> struct TrainRows { static constexpr int value = NF == 2 ? RNVP_TRAIN_R2 : (NF == 4 ? 2 : 1); };
+
+static int pick_rows(int rmax, int64_t n) {
+    int best = rmax;
+    double best_cost = 0.0;
+    for (int R = rmax; R >= 1; R >>= 1) {
+        const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+        const int64_t rounds = ((n + rows_per_wg - 1) / rows_per_wg + 255) / 256;
+        const double cost = (double)rounds * (R == 1 ? 1.0 : R == 2 ? 1.4 : 2.15);
+        if (R == rmax || cost < best_cost) { best = R; best_cost = cost; }
+    }
+    return best;
+}
 
 struct TrainPlan {
     int glayer_floats;      // per layer: 2 net blocks + db2
-    size_t lds_bytes;
-    int R;
-    size_t scratch_per_wave;   // floats
+    size_t lds_bytes;       // at RMAX (the largest)
+    int RMAX;
+    size_t scratch_per_wave;   // floats, at RMAX
 };
 
 template <int NF, int CQ>
@@ -560,9 +579,9 @@ TrainPlan make_plan(const Geo &g, int L) {
     TrainPlan p;
     const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
     p.glayer_floats = 2 * netblock + DM::NT2 * 16;
-    p.R = TrainRows<NF, CQ>::value;
+    p.RMAX = TrainRows<NF, CQ>::value;
     p.lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::template tb<TrainRows<NF, CQ>::value>()) * sizeof(float);
-    p.scratch_per_wave = (size_t)L * p.R * 2 * NF * 64;
+    p.scratch_per_wave = (size_t)L * p.RMAX * 2 * NF * 64;
     return p;
 }
 
@@ -574,11 +593,11 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
     return false;
 }
 
-template <int NF, int CQ>
-int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
-                 const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                 float *losspart, float *scratch, int grid) {
-    constexpr int R = TrainRows<NF, CQ>::value;
+template <int NF, int CQ, int R>
+int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+                   const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
+                   float *losspart, float *scratch, int *grid_out) {
+    using DM = Dims<NF, CQ>;
     auto kern = k_mfma_train<NF, CQ, R>;
     static std::atomic<int> attr_done{0};
     if (!attr_done.load(std::memory_order_relaxed)) {
@@ -586,13 +605,35 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.store(1, std::memory_order_relaxed);
     }
+    const size_t lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::template tb<R>()) * sizeof(float);
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
+    *grid_out = grid;
     {
         KernelTimer timer(st);      // rnvp_profile_*: brackets exactly this launch when enabled
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), pl.lds_bytes, st, packed, g, k.L, k.alt, x, c,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds_bytes, st, packed, g, k.L, k.alt, x, c,
                            row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
+}
+
+template <int NF, int CQ>
+int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+                 const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
+                 float *losspart, float *scratch, int *grid_out) {
+    constexpr int RMAX = TrainRows<NF, CQ>::value;
+    const int R = pick_rows(RMAX, n);
+#define RNVP_ROWS(r)                                                                                              \
+    if constexpr (RMAX >= r) {                                                                                    \
+        if (R == r)                                                                                               \
+            return launch_train_r<NF, CQ, r>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, \
+                                             grid_out);                                                           \
+    }
+    RNVP_ROWS(4) RNVP_ROWS(2) RNVP_ROWS(1)
+#undef RNVP_ROWS
+    return RNVP_EUNSUPPORTED;
 }
 
 }  // namespace
@@ -637,13 +678,11 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     float *scratch = reinterpret_cast<float *>(w);
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
-    const int64_t rows_per_wg = (int64_t)kWaves * pl.R * 16;
-    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
-    const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
-    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
-    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
-    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
-    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid);
+    int grid = 0;
+    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
+    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
+    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
+    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
     const size_t P = (size_t)2 * k.npn * k.L;

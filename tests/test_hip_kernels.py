@@ -272,6 +272,37 @@ def test_mfma_path_edge_shapes_vs_oracle(L, d, c, h, n, oracle32):
     assert np.abs(grad.cpu().numpy() - go).max() < 3e-6 * np.abs(go).max() + 1e-9
 
 
+@pytest.mark.parametrize("n", [3000, 20000, 40000, 70000])
+def test_loss_grad_linearity_across_row_tilings(n, oracle32):
+    """The training kernel picks its row tiles per wave from the batch size (1, 2 or 4 on C2's geometry).
+    Size-independent property: the gradient of a batch is the sum of the gradients of its parts (same
+    1/B scale), whatever tiling each call used; the smallest case is also checked against the oracle."""
+    from oracle import Shape
+    from cases import numpy_params
+    _hip, cs, shape, params, masks = _setup("c2")
+    L, d, c, hidden, act, _ = CASES["c2"]
+    P = cs["params"].size
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, d, device="cuda", generator=gen); cc = torch.randn(n, c, device="cuda", generator=gen)
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    full = torch.empty(P + 1, device="cuda")
+    _hip.loss_grad(shape, params, masks, x, cc, None, n, 1.0 / n, full[:P], full[P:], ws)
+    acc = torch.zeros(P + 1, device="cuda", dtype=torch.float64)
+    cuts = [0, 1000, n // 3, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = torch.empty(P + 1, device="cuda")
+        idx = torch.arange(lo, hi, device="cuda", dtype=torch.int64)
+        _hip.loss_grad(shape, params, masks, x, cc, idx, hi - lo, 1.0 / n, part[:P], part[P:], ws)
+        acc += part.double()
+    scale = full[:P].abs().max().item()
+    assert (full[:P].double() - acc[:P]).abs().max().item() < 2e-6 * scale
+    assert abs(full[P].item() - acc[P].item()) < 2e-6 * abs(full[P].item())
+    if n == 3000:
+        lo_, go = oracle32.loss_grad(Shape.make(L, d, c, hidden, act), numpy_params("c2"), x.cpu().numpy(), cc.cpu().numpy())
+        assert abs(full[P].item() - lo_) < max(1e-5, 5e-7 * abs(lo_))
+        assert np.abs(full[:P].cpu().numpy() - go).max() < 3e-6 * np.abs(go).max() + 1e-9
+
+
 def test_large_inverse_16m_rows():
     """BASELINE.json configs[3]-sized sampling call (16M draws, d=64, cond=16): index arithmetic beyond
     2^31 elements; checked through the round trip on a slice"""
