@@ -87,19 +87,108 @@ template <int NF, int CQ> struct Dims {
     static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
 };
 
-// ---- backward of one layer ---------------------------------------------------------------------------
+// Forward of one layer in net-split mode (see layer_bwd): this wave runs the hidden tiles of its own net,
+// reduces them to its net's output for the features each lane owns, and swaps it with the partner wave.
 template <int NF, int CQ, int R, int PC>
+__device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
+                                                 float *xown, const float *xother, float (&xr)[R][2 * NF],
+                                                 const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
+                                                 float *__restrict__ scr) {
+    using D = FwdDims<NF, CQ>;
+    constexpr int OTL = D::OTL, NT2 = D::NT2;
+    const int q = lane >> 4;
+    float own[R][NF];
+    if constexpr (NF == 2 && kUseX4) {
+        const f4 bias2 = *reinterpret_cast<const f4 *>(W + g.oB2 + q * 4);
+        f4 outx[R][4];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
+        if (role == 0) {
+            run_tiles_x4<CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, outx);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                float s4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[i] = swap_add32(outx[rt][0][i], outx[rt][1][i]);
+                own[rt][0] = swap_add16(s4[0], s4[2]) + bias2[0];
+                own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[1];
+            }
+        } else {
+            run_tiles_x4<CQ, R, PC, 1>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                float s4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[i] = swap_add32(outx[rt][2][i], outx[rt][3][i]);
+                own[rt][0] = swap_add16(s4[0], s4[2]) + bias2[2];
+                own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[3];
+            }
+        }
+    } else {
+        f4 out[R][NT2];
+#pragma unroll
+        for (int ot = 0; ot < NT2; ++ot) {
+            const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
+        }
+        if (role == 0) {
+            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) own[rt][f] = out[rt][f >> 2][f & 3];
+        } else {
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) own[rt][f] = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][(f & 3) + (NF >= 4 ? 0 : 2)];
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = own[rt][f];
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float oth = xother[(rt * NF + f) * 64 + lane];
+            const float tv = role == 0 ? own[rt][f] : oth, sv = role == 0 ? oth : own[rt][f];
+            const int e = 2 * f + 1 - PC;
+            const float es = expf(sv), xv = xr[rt][e];
+            // the pair shares one scratch record: the t wave saves the layer input, the s wave exp(s)
+            if (role == 0) scr[((rt * 2 * NF) + f) * 64 + lane] = xv;
+            else scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;
+            xr[rt][e] = fmaf(xv, es, tv);
+            ld[rt] += sv;
+        }
+    }
+}
+
+// ---- backward of one layer ---------------------------------------------------------------------------
+// NS (net split): the workgroup has 8 waves; waves w and w + 4 hold the SAME row tiles and take one net each
+// (role 0: t, role 1: s).  Each runs its own net's hidden tiles and accumulates its own net's weight
+// gradients; the two exchange only the net outputs (forward) and the input-gradient partial sums (here)
+// through xown / xother in LDS, once per layer.
+template <int NF, int CQ, int R, int PC, int NS>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
                                           const float *__restrict__ scr, float *lds, float *tb,
-                                          float *gp_layer, bool first, Stamps &stp) {
+                                          float *gp_layer, bool first, Stamps &stp, float *xown,
+                                          const float *xother) {
     unsigned long long t0 = 0; (void)t0;
     STAMP(t0);
     using D = Dims<NF, CQ>;
     constexpr int KS1 = D::KS1, K4 = D::K4, OTL = D::OTL, NT2 = D::NT2, KP4 = D::KP4, NTI = D::NTI,
                   MTI = D::MTI, KSP = D::KSP, SIN = D::SIN;
     const int q = lane >> 4, r = lane & 15, tid = wave * 64 + lane;
+    const int role = NS ? (wave >> 2) : 0;
     const int HT = g.HT;
     constexpr int FT = D::FT, SLOT = D::SLOT, TBLK = (NTI + OTL) * 256;
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
@@ -171,8 +260,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     //    (rnvp_mfma_layer.h): every phase runs over all R row tiles so that dependent MFMA chains
     //    interleave, LDS round trips are covered by the input-gradient MFMAs, and the weight
     //    fragments of the next tile are in flight for a whole iteration.
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
+    auto net_pass = [&](auto net_c) {
+        constexpr int net = decltype(net_c)::value;
         const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
         const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
         const float *pA2T = W + g.oA2T + ((size_t)net * HT * OTL * 64 + lane) * 4;
@@ -334,6 +423,29 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         }
                 }
                 __syncthreads();
+                if constexpr (NS) {
+                    // both nets flush together: threads 0..255 add the slots of waves 0..3 (t net), threads
+                    // 256..511 those of waves 4..7 (s net), each in wave order
+                    const int t0 = (ht / FT) * FT, ntile = ht + 1 - t0;
+                    const int nfl4 = ntile * TBLK / 4;
+                    const int fr = tid >> 8, ft = tid & 255;
+                    f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)fr * netblock + (size_t)t0 * TBLK);
+                    const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)fr * kWaves * SLOT);
+                    for (int i = ft; i < nfl4; i += 256) {
+                        f4 v = s0[i];
+#pragma unroll
+                        for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
+                        dst[i] = first ? v : dst[i] + v;
+                    }
+                    if (last_tile && tid < NT2 * 16) {
+                        const int i = kWaves * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
+                        float v = lds[i];
+#pragma unroll
+                        for (int w = 1; w < kWaves; ++w) v += lds[w * SLOT + i];
+                        float *p = gp_layer + 2 * (size_t)netblock + tid;
+                        *p = first ? v : *p + v;
+                    }
+                } else
                 {   // slot0 + slot1 + slot2 + slot3 (wave order) -> the workgroup's partial in global memory
                     const int t0 = (ht / FT) * FT, ntile = ht + 1 - t0;
                     const int nfl4 = ntile * TBLK / 4;
@@ -365,44 +477,72 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
             for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
         }
+    };
+    if constexpr (NS) {
+        if (role == 0) net_pass(std::integral_constant<int, 0>{});
+        else net_pass(std::integral_constant<int, 1>{});
+    } else {
+        net_pass(std::integral_constant<int, 0>{});
+        net_pass(std::integral_constant<int, 1>{});
     }
     // 4. gradient reaching the conditioning features through the nets
+    float gi[R][NF];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
         if constexpr (X4) {      // partial sums over the lane groups -> the owner of each conditioning feature
             float s4[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) s4[i] = swap_add32(gin[rt][0][i], gin[rt][1][i]);
-            gy[rt][PC] += swap_add16(s4[0], s4[2]);
-            gy[rt][2 + PC] += swap_add16(s4[1], s4[3]);
+            gi[rt][0] = swap_add16(s4[0], s4[2]);
+            gi[rt][1] = swap_add16(s4[1], s4[3]);
         } else {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const float gi = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
-                gy[rt][2 * f + PC] += gi;
-            }
+            for (int f = 0; f < NF; ++f) gi[rt][f] = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
         }
+    }
+    if constexpr (NS) {          // this wave summed its own net only: add the partner's share (t + s, both waves alike)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = gi[rt][f];
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float o = xother[(rt * NF + f) * 64 + lane];
+                gi[rt][f] = role == 0 ? gi[rt][f] + o : o + gi[rt][f];
+            }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) gy[rt][2 * f + PC] += gi[rt][f];
     }
     STAMP_ADD(stp.btail, t0);
 }
 
-template <int NF, int CQ, int R>
-__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+template <int NF, int CQ, int R, int NS>
+__global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats) {
     using DM = Dims<NF, CQ>;
     constexpr int D = 8 * NF, CD = 4 * CQ;
+    constexpr int NW = kWaves * (1 + NS);                 // waves in the workgroup
+    constexpr int XW = R * NF * 64;                       // floats one wave exchanges per layer (NS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pw = wave & (kWaves - 1), role = NS ? wave >> 2 : 0;     // row owner index; net of this wave (NS)
     const int q = lane >> 4, r = lane & 15;
-    float *tb = lds + kWaves * DM::SLOT + wave * DM::template tb<R>();
+    float *tb = lds + NW * DM::SLOT + wave * DM::template tb<R>();
+    float *xbuf = lds + NW * DM::SLOT + NW * DM::template tb<R>();     // NS: 2 x NW x XW, double buffered by layer parity
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
     const bool full = (g.d == D) && (g.c == CD);
     float *gp = gpart + (size_t)blockIdx.x * glayer_floats * L;
-    float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + wave) * L * R * 2 * NF * 64;
+    float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + pw) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
     bool first = true;
     Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -410,7 +550,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     STAMP(tk0);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         STAMP(t0);
-        const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
+        const int64_t base = grp * rows_per_wg + (int64_t)pw * R * 16;
         float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R], gy[R][2 * NF], gld[R];
         bool valid[R];
 #pragma unroll
@@ -425,9 +565,16 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
         for (int l = 0; l < L; ++l) {
             const float *W = wp + (size_t)l * g.layer_floats;
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
-            if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2>(W, g, lane, xr, cr, ld, scr);
-            else layer_forward<NF, CQ, R, 0, 2>(W, g, lane, xr, cr, ld, scr);
+            if constexpr (NS) {
+                float *xb = xbuf + (size_t)(l & 1) * NW * XW;
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+                else layer_forward_ns<NF, CQ, R, 0>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+            } else {
+                if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2>(W, g, lane, xr, cr, ld, scr);
+                else layer_forward<NF, CQ, R, 0, 2>(W, g, lane, xr, cr, ld, scr);
+            }
         }
+        if constexpr (NS) __syncthreads();      // the pair's scratch records (written half by each wave) and the exchange buffers
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
             float ss = 0.f;
@@ -451,12 +598,16 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             const float *W = wp + (size_t)l * g.layer_floats;
             const float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             float *gpl = gp + (size_t)l * glayer_floats;
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp);
-            else layer_bwd<NF, CQ, R, 0>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp);
+            float *xb = xbuf + (size_t)(l & 1) * NW * XW;
+            float *xo = NS ? xb + wave * XW : nullptr;
+            const float *xp = NS ? xb + (wave ^ kWaves) * XW : nullptr;
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            else layer_bwd<NF, CQ, R, 0, NS>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
         }
+        if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
     }
-    if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
+    if (lane == 0 && role == 0) losspart[blockIdx.x * kWaves + pw] = wave_sum;
 #ifdef RNVP_STAMP
     {
         unsigned long long tk1; STAMP(tk1);
@@ -596,30 +747,48 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
     return false;
 }
 
-template <int NF, int CQ, int R>
-int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
-                   const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                   float *losspart, float *scratch, int *grid_out) {
-    using DM = Dims<NF, CQ>;
-    auto kern = k_mfma_train<NF, CQ, R>;
+template <int NF, int CQ, int R, int NS>
+int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+                    const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
+                    float *losspart, float *scratch, int grid, size_t lds_bytes) {
+    auto kern = k_mfma_train<NF, CQ, R, NS>;
     static std::atomic<int> attr_done{0};
     if (!attr_done.load(std::memory_order_relaxed)) {
         RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.store(1, std::memory_order_relaxed);
     }
-    const size_t lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::template tb<R>()) * sizeof(float);
-    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
-    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
-    const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
-    *grid_out = grid;
     {
         KernelTimer timer(st);      // rnvp_profile_*: brackets exactly this launch when enabled
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds_bytes, st, packed, g, k.L, k.alt, x, c,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, packed, g, k.L, k.alt, x, c,
                            row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
+}
+
+#ifndef RNVP_NET_SPLIT
+#define RNVP_NET_SPLIT 1
+#endif
+
+template <int NF, int CQ, int R>
+int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+                   const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
+                   float *losspart, float *scratch, int *grid_out) {
+    using DM = Dims<NF, CQ>;
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
+    *grid_out = grid;
+    const size_t per_wave = (size_t)DM::SLOT + DM::template tb<R>();
+    // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
+    // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
+    const size_t lds_ns = (2 * kWaves * per_wave + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float);
+    if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024)
+        return launch_train_ns<NF, CQ, R, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+                                             grid, lds_ns);
+    return launch_train_ns<NF, CQ, R, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
+                                         kWaves * per_wave * sizeof(float));
 }
 
 template <int NF, int CQ>
