@@ -441,5 +441,95 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
     }
 }
 
+// One layer in net-split mode: the workgroup has 8 waves; waves w and w + 4 hold the SAME row tiles and take one
+// net each (role 0: t, role 1: s).  This wave runs the hidden tiles of its own net, reduces them to its net's
+// output for the features each lane owns, and swaps it with the partner wave through xown / xother in LDS
+// (one __syncthreads per layer; the caller double-buffers the records by layer parity).  MODE as layer_forward.
+template <int NF, int CQ, int R, int PC, int MODE>
+__device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
+                                                 float *xown, const float *xother, float (&xr)[R][2 * NF],
+                                                 const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
+                                                 float *__restrict__ scr) {
+    using D = FwdDims<NF, CQ>;
+    constexpr int OTL = D::OTL, NT2 = D::NT2;
+    const int q = lane >> 4;
+    float own[R][NF];
+    if constexpr (NF == 2 && kUseX4) {
+        const f4 bias2 = *reinterpret_cast<const f4 *>(W + g.oB2 + q * 4);
+        f4 outx[R][4];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
+        if (role == 0) {
+            run_tiles_x4<CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, outx);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                float s4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[i] = swap_add32(outx[rt][0][i], outx[rt][1][i]);
+                own[rt][0] = swap_add16(s4[0], s4[2]) + bias2[0];
+                own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[1];
+            }
+        } else {
+            run_tiles_x4<CQ, R, PC, 1>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                float s4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[i] = swap_add32(outx[rt][2][i], outx[rt][3][i]);
+                own[rt][0] = swap_add16(s4[0], s4[2]) + bias2[2];
+                own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[3];
+            }
+        }
+    } else {
+        f4 out[R][NT2];
+#pragma unroll
+        for (int ot = 0; ot < NT2; ++ot) {
+            const f4 b = *reinterpret_cast<const f4 *>(W + g.oB2 + (ot * 4 + q) * 4);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
+        }
+        if (role == 0) {
+            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) own[rt][f] = out[rt][f >> 2][f & 3];
+        } else {
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) own[rt][f] = out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][(f & 3) + (NF >= 4 ? 0 : 2)];
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = own[rt][f];
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float oth = xother[(rt * NF + f) * 64 + lane];
+            const float tv = role == 0 ? own[rt][f] : oth, sv = role == 0 ? oth : own[rt][f];
+            const int e = 2 * f + 1 - PC;
+            if (MODE == 1) {
+                xr[rt][e] = (xr[rt][e] - tv) * expf(-sv);
+            } else {
+                const float es = expf(sv), xv = xr[rt][e];
+                if (MODE == 2) {    // the pair shares one scratch record: the t wave saves the layer input, the s wave exp(s)
+                    if (role == 0) scr[((rt * 2 * NF) + f) * 64 + lane] = xv;
+                    else scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;
+                }
+                xr[rt][e] = fmaf(xv, es, tv);
+                ld[rt] += sv;
+            }
+        }
+    }
+}
+
 }  // namespace mfma
 }  // namespace rnvp
