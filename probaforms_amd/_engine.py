@@ -353,7 +353,7 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
 
     Single GPU: one rnvp_fit_epoch call per epoch (a fused rnvp_train_step per batch, looped inside the
     library).  With torch.distributed initialised every
-    rank walks the SAME permutation, takes its contiguous share of each global batch, and the
+    rank walks the SAME permutation (rank 0's loader seeds are broadcast), takes its contiguous share of each global batch, and the
     flat [gradient | loss] buffer is all-reduced (SUM) before an identical Adam step on every
     rank -- gradients are scaled by 1/B_global inside the kernel, so the sum is the batch mean.
     Losses stay on the device; one copy per epoch feeds loss_history (one entry per batch, as
@@ -363,6 +363,12 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     bounds = batch_bounds(n, batch_size)
     dev = engine.device
     perms = PermutationPrefetcher(n, n_epochs)
+    if world > 1:
+        # every rank must walk rank 0's shuffle, whatever state its own generator is in (each rank still
+        # consumes its generator exactly like a single process would)
+        t = torch.tensor(perms.seeds, dtype=torch.int64, device=dev)
+        broadcast_(t, src=0)
+        perms.seeds = [int(v) for v in t.cpu()]
     for epoch in range(n_epochs):
         perm = perms.get(epoch).to(dev, non_blocking=False)
         losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)

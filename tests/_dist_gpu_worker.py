@@ -1,0 +1,38 @@
+"""Worker of tests/test_dist_gpu.py: one rank of a data-parallel RealNVP.fit on the HIP kernels.
+Launched by torch.distributed.run; on a 1-GPU box every rank uses cuda:0 (env `device`) and the
+collective runs over gloo -- the code path is the one RCCL serves on a multi-GPU node."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from probaforms_amd.models import RealNVP
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((1000, 5)); C = rng.standard_normal((1000, 3))
+    torch.manual_seed(0 if rank == 0 else 1234 + rank)          # rank 0's init and shuffles must win
+    m = RealNVP(n_layers=4, hidden=(16,), batch_size=96, n_epochs=2, lr=1e-2, weight_decay=0.05)
+    m.fit(X, C)                                                  # 1000 rows, bs 96 -> last batch 40 rows
+    flat = m.nf.engine().flat.detach().clone()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    torch.manual_seed(5)
+    xs = m.sample(C[:64])
+    if rank == 0:
+        np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,7 +80,9 @@ def _data():
 def _fit(world_rank=None):
     realnvp = _install_oracle_backend()
     X, C = _data()
-    torch.manual_seed(0)
+    # ranks other than 0 arrive with a different generator state: parameters and the epoch shuffles must
+    # still be rank 0's (both are broadcast), so the run equals the single-process run seeded with 0
+    torch.manual_seed(0 if not world_rank else 100 + world_rank)
     m = realnvp.RealNVP(n_layers=3, hidden=(6,), batch_size=32, n_epochs=2, lr=0.01, weight_decay=0.1)
     m.fit(X, C)
     flat = torch.cat([p.detach().reshape(-1) for p in m.nf.parameters()]).numpy().copy()
