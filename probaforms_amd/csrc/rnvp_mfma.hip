@@ -41,13 +41,13 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         if (kk < g.NF) col = xcol(feat_cond(g.NF, q, kk, pc));
         else if (kk < g.KS1) col = ccol(q * g.CQ + (kk - g.NF));
         else return 0.f;
-        return kTanhScale * RNVP_W1(net, hid, col);                            // pre-scaled: see tanh4
+        return (k.act == RNVP_ACT_TANH ? kTanhScale : 1.0f) * RNVP_W1(net, hid, col);   // tanh: pre-scaled, see tanh4
     }
     if (idx < g.oA2) {                                     // bias1 [tile][q][4]
         const int j = idx - g.oB1;
         const int e = j & 3, q = (j >> 2) & 3, tile = j >> 4;
         const int net = tile / g.HT, hid = 16 * (tile % g.HT) + 4 * q + e;
-        return hid < h ? kTanhScale * pl[net * k.npn + k.boff[0] + hid] : 0.f;
+        return hid < h ? (k.act == RNVP_ACT_TANH ? kTanhScale : 1.0f) * pl[net * k.npn + k.boff[0] + hid] : 0.f;
     }
     if (idx < g.oB2) {                                     // A2 [tile][otl][lane][4 rho]
         const int j = idx - g.oA2;
@@ -139,7 +139,7 @@ k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
 }
 
 // ---- whole stack: forward (+ log-det + prior) or inverse ---------------------------------------
-template <int NF, int CQ, int R, bool INVERSE>
+template <int NF, int CQ, int R, bool INVERSE, int ACT>
 __global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n,
@@ -167,8 +167,8 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__
         for (int lp = 0; lp < L; ++lp) {
             const int l = INVERSE ? L - 1 - lp : lp;
             const float *W = wp + (size_t)l * g.layer_floats;
-            if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, INVERSE ? 1 : 0>(W, g, lane, xr, cr, ld, nullptr);
-            else layer_forward<NF, CQ, R, 0, INVERSE ? 1 : 0>(W, g, lane, xr, cr, ld, nullptr);
+            if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, INVERSE ? 1 : 0, ACT>(W, g, lane, xr, cr, ld, nullptr);
+            else layer_forward<NF, CQ, R, 0, INVERSE ? 1 : 0, ACT>(W, g, lane, xr, cr, ld, nullptr);
         }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
@@ -217,7 +217,7 @@ size_t packed_bytes(const KShape &k) {
 }
 
 
-template <int NF, int CQ, bool INVERSE, int R = RowTiles<NF, CQ>::value>
+template <int NF, int CQ, bool INVERSE, int ACT, int R = RowTiles<NF, CQ>::value>
 int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
                 const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
                 float *logp_out, float *part, int *grid_out) {
@@ -226,14 +226,14 @@ int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pack
     // 65536 rows up R = 4 wins).  A row's result does not depend on R.
     if constexpr (NF == 2 && R == 4) {
         if (n <= 32768)
-            return launch_flow<NF, CQ, INVERSE, 2>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out,
+            return launch_flow<NF, CQ, INVERSE, ACT, 2>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out,
                                                    part, grid_out);
     }
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
     *grid_out = grid;
-    hipLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE>), dim3(grid), dim3(kWaves * 64), 0, st, packed, g, k.L, k.alt, x,
+    hipLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE, ACT>), dim3(grid), dim3(kWaves * 64), 0, st, packed, g, k.L, k.alt, x,
                        c, row_index, n, out_x, logdet_out, logp_out, part);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -243,10 +243,14 @@ template <bool INVERSE>
 int dispatch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
                   const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
                   float *logp_out, float *part, int *grid_out) {
-#define RNVP_CASE(nf, cq)                                                                                   \
-    if (g.NF == nf && g.CQ == cq)                                                                           \
-        return launch_flow<nf, cq, INVERSE>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out, \
-                                            part, grid_out);
+#define RNVP_CASE(nf, cq)                                                                                       \
+    if (g.NF == nf && g.CQ == cq) {                                                                             \
+        if (k.act == RNVP_ACT_TANH)                                                                             \
+            return launch_flow<nf, cq, INVERSE, 0>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out, \
+                                                   part, grid_out);                                             \
+        return launch_flow<nf, cq, INVERSE, 1>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out,  \
+                                               part, grid_out);                                                 \
+    }
     RNVP_CASE(2, 1) RNVP_CASE(2, 0) RNVP_CASE(4, 2) RNVP_CASE(8, 4)
 #undef RNVP_CASE
     return RNVP_EUNSUPPORTED;
@@ -264,7 +268,7 @@ int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *par
 }
 
 bool supported(const KShape &k) {
-    if (!k.alt || k.nh != 1 || k.act != RNVP_ACT_TANH) return false;
+    if (!k.alt || k.nh != 1) return false;             // tanh and ReLU (realnvp.py:32-37) both run here
     int NF, CQ;
     return pick_tiles(k.d, k.c, &NF, &CQ);       // d <= 64, cdim <= 16; everything else is padding
 }

@@ -74,6 +74,18 @@ __device__ __forceinline__ f4 tanh4(f4 u) {
     return f4{r0[0], r0[1], r1[0], r1[1]};
 }
 
+// Hidden activation of gen_network (realnvp.py:26-37) on a GEMM1 accumulator and its derivative from the
+// activation's OUTPUT.  ACT 0: tanh (accumulator pre-scaled, above); ACT 1: ReLU (no pre-scale: k_pack_weights
+// leaves W1, b1 as they are), derivative 1 where the output is positive, 0 at and below zero like torch.
+template <int ACT> __device__ __forceinline__ f4 act4(f4 u) {
+    if constexpr (ACT == 0) return tanh4(u);
+    return f4{fmaxf(u[0], 0.f), fmaxf(u[1], 0.f), fmaxf(u[2], 0.f), fmaxf(u[3], 0.f)};
+}
+template <int ACT> __device__ __forceinline__ f4 dact4(f4 hv) {
+    if constexpr (ACT == 0) return 1.0f - hv * hv;
+    return f4{hv[0] > 0.f ? 1.f : 0.f, hv[1] > 0.f ? 1.f : 0.f, hv[2] > 0.f ? 1.f : 0.f, hv[3] > 0.f ? 1.f : 0.f};
+}
+
 // hide a fragment address from the optimiser (it would otherwise prove that next iteration's
 // "current" fragment equals this iteration's prefetch and replace the prefetch by a late re-load)
 typedef const __attribute__((address_space(1))) f4 *gf4_ptr;      // keeps the loads global_load (not flat)
@@ -198,7 +210,7 @@ __device__ __forceinline__ f4 gemm1(const f4 (&a1)[FwdDims<NF, CQ>::K4], f4 b1, 
 }
 
 // Tiles [tile0, tile0 + ntiles) of the packed layer feed out tiles OT0 .. OT0 + OTL - 1.
-template <int NF, int CQ, int R, int PC, int OT0>
+template <int NF, int CQ, int R, int PC, int OT0, int ACT>
 __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo &g, int lane, int tile0,
                                           int ntiles, const float (&xr)[R][2 * NF],
                                           const float (&cr)[R][CQ > 0 ? CQ : 1],
@@ -247,7 +259,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
                 for (int u = 0; u < RB; ++u)
                     accn[r0 + u] = mfma16(a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), accn[r0 + u]);
 #pragma unroll
-            for (int u = 0; u < RB; ++u) hv[r0 + u] = tanh4(acc[r0 + u]);
+            for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -268,7 +280,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
     {   // epilogue: the last tile has no successor to overlap with
         f4 hv[R];
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) hv[rt] = tanh4(acc[rt]);
+        for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(acc[rt]);
 #pragma unroll
         for (int o = 0; o < OTL; ++o)
 #pragma unroll
@@ -284,7 +296,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
 // GEMM1 accumulator register, as before) by 4 outputs (A, pre-packed per lane) for rows 4rg..4rg+3.
 // Partial sums over the lane groups q are combined once per layer by a two-step reduce-scatter.
 // Measured on MI355X: 8 x 4x4x1 take 37 ns against 58 ns for the 4 x 16x16x4 they replace.
-template <int CQ, int R, int PC, int NET>
+template <int CQ, int R, int PC, int NET, int ACT>
 __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const Geo &g, int lane, int tile0,
                                              int ntiles, const float (&xr)[R][4],
                                              const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4]) {
@@ -332,7 +344,7 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
                 for (int u = 0; u < RB; ++u)
                     accn[r0 + u] = mfma16(a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), accn[r0 + u]);
 #pragma unroll
-            for (int u = 0; u < RB; ++u) hv[r0 + u] = tanh4(acc[r0 + u]);
+            for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -354,7 +366,7 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
     {
         f4 hv[R];
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) hv[rt] = tanh4(acc[rt]);
+        for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(acc[rt]);
 #pragma unroll
         for (int rho = 0; rho < 4; ++rho)
 #pragma unroll
@@ -381,7 +393,7 @@ __device__ __forceinline__ void reduce_scatter_x4(const f4 (&part)[4], float (&t
 // MODE 0: forward (x*exp(s)+t, log-det)   realnvp.py:99-100
 // MODE 1: inverse ((x-t)*exp(-s))          realnvp.py:128
 // MODE 2: forward, also writing the layer input of the transformed features and exp(s) to scr
-template <int NF, int CQ, int R, int PC, int MODE>
+template <int NF, int CQ, int R, int PC, int MODE, int ACT>
 __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const Geo &g, int lane,
                                               float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                               float (&ld)[R], float *__restrict__ scr) {
@@ -396,8 +408,8 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
-        run_tiles_x4<CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, outx);
-        run_tiles_x4<CQ, R, PC, 1>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+        run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, outx);
+        run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT, g.HT, xr, cr, outx);
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
             float tv[2], sv[2];
@@ -412,10 +424,10 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
         }
         if (NF >= 4) {      // each net feeds its own out tiles
-            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
-            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT, g.HT, xr, cr, out);
         } else {            // t and s share one out tile: one pipelined pass over all 2*HT tiles
-            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, 2 * g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, 0, 2 * g.HT, xr, cr, out);
         }
     }
 #pragma unroll
@@ -445,7 +457,7 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
 // net each (role 0: t, role 1: s).  This wave runs the hidden tiles of its own net, reduces them to its net's
 // output for the features each lane owns, and swaps it with the partner wave through xown / xother in LDS
 // (one __syncthreads per layer; the caller double-buffers the records by layer parity).  MODE as layer_forward.
-template <int NF, int CQ, int R, int PC, int MODE>
+template <int NF, int CQ, int R, int PC, int MODE, int ACT>
 __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
                                                  float *xown, const float *xother, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
@@ -462,7 +474,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (role == 0) {
-            run_tiles_x4<CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, outx);
+            run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, outx);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -472,7 +484,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
                 own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[1];
             }
         } else {
-            run_tiles_x4<CQ, R, PC, 1>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+            run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT, g.HT, xr, cr, outx);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -491,13 +503,13 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
         }
         if (role == 0) {
-            run_tiles<NF, CQ, R, PC, 0>(W, g, lane, 0, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, out);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) own[rt][f] = out[rt][f >> 2][f & 3];
         } else {
-            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0)>(W, g, lane, g.HT, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT, g.HT, xr, cr, out);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt)
 #pragma unroll

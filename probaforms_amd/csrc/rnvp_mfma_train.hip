@@ -92,7 +92,7 @@ template <int NF, int CQ> struct Dims {
 // (role 0: t, role 1: s).  Each runs its own net's hidden tiles and accumulates its own net's weight
 // gradients; the two exchange only the net outputs (forward) and the input-gradient partial sums (here)
 // through xown / xother in LDS, once per layer.
-template <int NF, int CQ, int R, int PC, int NS>
+template <int NF, int CQ, int R, int PC, int NS, int ACT>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
@@ -246,8 +246,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 wave_lds_fence();
 #pragma unroll
                 for (int u = 0; u < RH; ++u) {
-                    const f4 hv = tanh4(acc[u]);
-                    gpv[u] = gh[u] * (1.0f - hv * hv);                                   // tanh'
+                    const f4 hv = act4<ACT>(acc[u]);
+                    gpv[u] = gh[u] * dact4<ACT>(hv);                                     // activation'
                     if (!(kAblate & 1)) {
                         *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
                         *reinterpret_cast<f4 *>(bufH + (2 * u + 1) * 16 * kTS + r * kTS + 4 * q) = gpv[u];
@@ -439,7 +439,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     STAMP_ADD(stp.btail, t0);
 }
 
-template <int NF, int CQ, int R, int NS>
+template <int NF, int CQ, int R, int NS, int ACT>
 __global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
@@ -484,11 +484,11 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
-                else layer_forward_ns<NF, CQ, R, 0, 2>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
             } else {
-                if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2>(W, g, lane, xr, cr, ld, scr);
-                else layer_forward<NF, CQ, R, 0, 2>(W, g, lane, xr, cr, ld, scr);
+                if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT>(W, g, lane, xr, cr, ld, scr);
+                else layer_forward<NF, CQ, R, 0, 2, ACT>(W, g, lane, xr, cr, ld, scr);
             }
         }
         if constexpr (NS) __syncthreads();      // the pair's scratch records (written half by each wave) and the exchange buffers
@@ -518,8 +518,8 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             float *xb = xbuf + (size_t)(l & 1) * NW * XW;
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ kWaves) * XW : nullptr;
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
-            else layer_bwd<NF, CQ, R, 0, NS>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
@@ -664,11 +664,11 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
     return false;
 }
 
-template <int NF, int CQ, int R, int NS>
-int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+template <int NF, int CQ, int R, int NS, int ACT>
+int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
                     float *losspart, float *scratch, int grid, size_t lds_bytes) {
-    auto kern = k_mfma_train<NF, CQ, R, NS>;
+    auto kern = k_mfma_train<NF, CQ, R, NS, ACT>;
     static std::atomic<int> attr_done{0};
     if (!attr_done.load(std::memory_order_relaxed)) {
         RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -682,6 +682,17 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
+}
+
+template <int NF, int CQ, int R, int NS>
+int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
+                    const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
+                    float *losspart, float *scratch, int grid, size_t lds_bytes) {
+    if (k.act == RNVP_ACT_TANH)
+        return launch_train_act<NF, CQ, R, NS, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+                                                  grid, lds_bytes);
+    return launch_train_act<NF, CQ, R, NS, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
+                                              lds_bytes);
 }
 
 #ifndef RNVP_NET_SPLIT

@@ -16,6 +16,7 @@ CASES = {
     "tm_nocond": (8, 5, 0, (10,), "tanh", "torch"),     # tests/test_models.py:23-28
     "reg1d":     (4, 1, 1, (10,), "tanh", "torch"),     # docs/examples/regression.ipynb cell 9
     "relu_mh":   (3, 6, 2, (7, 9), "relu", "torch"),    # G9
+    "relu_sh":   (6, 5, 3, (24,), "relu", "torch"),     # ReLU nets with one hidden layer (realnvp.py:32-37): MFMA path
     "tanh_mh":   (4, 4, 2, (8, 8), "tanh", "torch"),    # G9
     "d8":        (4, 8, 4, (32,), "tanh", "torch"),
     "c2":        (8, 16, 4, (128,), "tanh", "numpy"),   # BASELINE.json configs[1]

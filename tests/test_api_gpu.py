@@ -96,7 +96,7 @@ def test_seeded_fit_matches_reference(L):
     assert len(m.loss_history) == int(f["L%d_loss_history_len_after_refit" % L])
 
 
-@pytest.mark.parametrize("name", ["c1_L8", "tm", "tm_nocond", "reg1d", "relu_mh", "c2"])
+@pytest.mark.parametrize("name", ["c1_L8", "tm", "tm_nocond", "reg1d", "relu_mh", "relu_sh", "c2"])
 def test_load_reference_weights_and_compare_logprob(name):
     """weights travel through state_dict-shaped tensors; per-row log-prob and samples equal the reference's"""
     from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior

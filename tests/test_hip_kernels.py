@@ -235,22 +235,23 @@ def test_fused_train_step_equals_loss_grad_plus_adam():
             assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
+@pytest.mark.parametrize("act", ["tanh", "relu"])
 @pytest.mark.parametrize("L,d,c,h,n", [(3, 16, 4, 48, 37), (1, 32, 8, 16, 5), (2, 64, 16, 32, 100), (5, 16, 0, 16, 1),
                                        (3, 32, 8, 80, 300)])
-def test_mfma_path_edge_shapes_vs_oracle(L, d, c, h, n, oracle32):
+def test_mfma_path_edge_shapes_vs_oracle(L, d, c, h, n, act, oracle32):
     """odd layer counts, hidden sizes that are not a multiple of the flush interval, ragged and tiny
     batches, gathered rows: MFMA kernels (forward, inverse, loss+grad) against the oracle"""
     from oracle import Shape
     from probaforms_amd import _hip
     rng = np.random.default_rng(L * 1000 + d + h)
-    shape = _hip.RnvpShape.make(L, d, c, (h,), "tanh", alt_masks=1)
+    shape = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1)
     assert _hip.kernel_path(shape, None, _hip.OP_TRAIN) == _hip.PATH_MFMA
     P = _hip.param_count(shape)
     params = (rng.uniform(-1, 1, size=P) * 0.12).astype(np.float32)      # ~ the default init range for these widths
     N = 3 * n + 7
     X = rng.normal(size=(N, d)).astype(np.float32); C = rng.normal(size=(N, c)).astype(np.float32) if c else None
     idx = rng.permutation(N)[:n].astype(np.int64)
-    s = Shape.make(L, d, c, (h,), "tanh")
+    s = Shape.make(L, d, c, (h,), act)
     pd, xd, cd, id_ = _dev(params), _dev(X), _dev(C), _dev(idx, torch.int64)
     masks = _dev(((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8), torch.uint8)
     z = torch.empty(n, d, device="cuda"); lp = torch.empty(n, device="cuda"); tot = torch.empty(1, device="cuda")
