@@ -222,72 +222,69 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
     const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
     const float *pA2 = W + g.oA2 + ((size_t)tile0 * OTL * 64 + lane) * 4;
     const int last = ntiles - 1;
-    f4 a1n[K4], b1n, a2c[OTL], acc[R];
+    // The pipeline state {pre-activations of tile t, GEMM1 fragments of tile t+1, GEMM2 fragments of tile t}
+    // alternates between two named register sets, so an iteration ends without the ~30 v_mov that rotating one
+    // set costs (f32 MFMA and VALU share the SIMD: every v_mov is wall time).
+    struct St { f4 a1n[K4], b1n, a2c[OTL], acc[R]; };
+    St s0, s1;
     {   // prologue: GEMM1 of the first tile; fragments of the second
         f4 a1c[K4], b1c;
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) a1c[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
         b1c = *reinterpret_cast<const f4 *>(pB1);
 #pragma unroll
-        for (int o = 0; o < OTL; ++o) a2c[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
+        for (int o = 0; o < OTL; ++o) s0.a2c[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
         const int t1 = last < 1 ? last : 1;
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
-        b1n = *opaque(pB1 + t1 * 16);
+        for (int k4 = 0; k4 < K4; ++k4) s0.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
+        s0.b1n = *opaque(pB1 + t1 * 16);
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
+        for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
     }
-    for (int t = 0; t < last; ++t) {
+    auto gemm2 = [&](const St &c, const f4 (&hv)[R]) {
+#pragma unroll
+        for (int o = 0; o < OTL; ++o)                  // independent accumulators back to back
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) out[rt][OT0 + o] = mfma16(c.a2c[o][rho], hv[rt][rho], out[rt][OT0 + o]);
+    };
+    auto step = [&](const St &c, St &nx, int t) {
         // fragments for the NEXT iteration: GEMM1 of tile t+2, GEMM2 of tile t+1
         const int t2 = (t + 2 < last) ? t + 2 : last;
-        f4 a1f[K4], b1f, a2f[OTL];
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1f[k4] = *opaque(pA1 + ((size_t)t2 * K4 + k4) * 256);
-        b1f = *opaque(pB1 + t2 * 16);
+        for (int k4 = 0; k4 < K4; ++k4) nx.a1n[k4] = *opaque(pA1 + ((size_t)t2 * K4 + k4) * 256);
+        nx.b1n = *opaque(pB1 + t2 * 16);
 #pragma unroll
-        for (int o = 0; o < OTL; ++o) a2f[o] = *opaque(pA2 + ((size_t)(t + 1) * OTL + o) * 256);
+        for (int o = 0; o < OTL; ++o) nx.a2c[o] = *opaque(pA2 + ((size_t)(t + 1) * OTL + o) * 256);
         __builtin_amdgcn_sched_barrier(0);
-        f4 accn[R], hv[R];
+        f4 hv[R];
         constexpr int RB = (R % 2 == 0) ? 2 : 1;       // row tiles per phase-A block (two chains interleave)
 #pragma unroll
-        for (int r0 = 0; r0 < R; r0 += RB) {           // phase A
+        for (int r0 = 0; r0 < R; r0 += RB) {           // phase A: GEMM1 of tile t+1 || activation of tile t
 #pragma unroll
-            for (int u = 0; u < RB; ++u) accn[r0 + u] = b1n;
+            for (int u = 0; u < RB; ++u) nx.acc[r0 + u] = c.b1n;
 #pragma unroll
             for (int kk = 0; kk < NF + CQ; ++kk)
 #pragma unroll
                 for (int u = 0; u < RB; ++u)
-                    accn[r0 + u] = mfma16(a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), accn[r0 + u]);
+                    nx.acc[r0 + u] = mfma16(c.a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), nx.acc[r0 + u]);
 #pragma unroll
-            for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(acc[r0 + u]);
+            for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int o = 0; o < OTL; ++o)                  // phase B: independent accumulators back to back
-#pragma unroll
-            for (int rho = 0; rho < 4; ++rho)
-#pragma unroll
-                for (int rt = 0; rt < R; ++rt) out[rt][OT0 + o] = mfma16(a2c[o][rho], hv[rt][rho], out[rt][OT0 + o]);
+        gemm2(c, hv);                                  // phase B
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) acc[rt] = accn[rt];
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = a1f[k4];
-        b1n = b1f;
-#pragma unroll
-        for (int o = 0; o < OTL; ++o) a2c[o] = a2f[o];
-    }
-    {   // epilogue: the last tile has no successor to overlap with
+    };
+    auto finish = [&](const St &c) {                   // the last tile has no successor to overlap with
         f4 hv[R];
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(acc[rt]);
-#pragma unroll
-        for (int o = 0; o < OTL; ++o)
-#pragma unroll
-            for (int rho = 0; rho < 4; ++rho)
-#pragma unroll
-                for (int rt = 0; rt < R; ++rt) out[rt][OT0 + o] = mfma16(a2c[o][rho], hv[rt][rho], out[rt][OT0 + o]);
-    }
+        for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(c.acc[rt]);
+        gemm2(c, hv);
+    };
+    int t = 0;
+    for (; t + 1 < last; t += 2) { step(s0, s1, t); step(s1, s0, t + 1); }
+    if (t < last) { step(s0, s1, t); finish(s1); } else finish(s0);
 }
 
 // d == 16 (NF == 2): the t and s nets would share ONE 16-row out tile in which every hidden tile
@@ -308,73 +305,66 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
     const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
     const float *pA2 = W + g.oA2X + ((size_t)tile0 * 2 * 64 + lane) * 4;
     const int last = ntiles - 1;
-    f4 a1n[K4], b1n, a2c[2], acc[R];
+    struct St { f4 a1n[K4], b1n, a2c[2], acc[R]; };        // two alternating pipeline states: see run_tiles
+    St s0, s1;
     {
         f4 a1c[K4], b1c;
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) a1c[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
         b1c = *reinterpret_cast<const f4 *>(pB1);
 #pragma unroll
-        for (int o = 0; o < 2; ++o) a2c[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
+        for (int o = 0; o < 2; ++o) s0.a2c[o] = *reinterpret_cast<const f4 *>(pA2 + o * 256);
         const int t1 = last < 1 ? last : 1;
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
-        b1n = *opaque(pB1 + t1 * 16);
+        for (int k4 = 0; k4 < K4; ++k4) s0.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
+        s0.b1n = *opaque(pB1 + t1 * 16);
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
+        for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
     }
-    for (int t = 0; t < last; ++t) {
-        const int t2 = (t + 2 < last) ? t + 2 : last;
-        f4 a1f[K4], b1f, a2f[2];
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1f[k4] = *opaque(pA1 + ((size_t)t2 * K4 + k4) * 256);
-        b1f = *opaque(pB1 + t2 * 16);
-#pragma unroll
-        for (int o = 0; o < 2; ++o) a2f[o] = *opaque(pA2 + ((size_t)(t + 1) * 2 + o) * 256);
-        __builtin_amdgcn_sched_barrier(0);
-        f4 accn[R], hv[R];
-        constexpr int RB = (R % 2 == 0) ? 2 : 1;
-#pragma unroll
-        for (int r0 = 0; r0 < R; r0 += RB) {           // phase A: GEMM1 of tile t+1 || tanh of tile t
-#pragma unroll
-            for (int u = 0; u < RB; ++u) accn[r0 + u] = b1n;
-#pragma unroll
-            for (int kk = 0; kk < NF + CQ; ++kk)
-#pragma unroll
-                for (int u = 0; u < RB; ++u)
-                    accn[r0 + u] = mfma16(a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), accn[r0 + u]);
-#pragma unroll
-            for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(acc[r0 + u]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho)              // phase B: 4x4x1 GEMM2, 2R independent chains
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int rt = 0; rt < R; ++rt)
-                    outx[rt][2 * NET + o] = mfma4(a2c[o][rho], hv[rt][rho], outx[rt][2 * NET + o]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) acc[rt] = accn[rt];
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1n[k4] = a1f[k4];
-        b1n = b1f;
-#pragma unroll
-        for (int o = 0; o < 2; ++o) a2c[o] = a2f[o];
-    }
-    {
-        f4 hv[R];
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(acc[rt]);
+    auto gemm2 = [&](const St &c, const f4 (&hv)[R]) {     // 4x4x1 GEMM2, 2R independent chains
 #pragma unroll
         for (int rho = 0; rho < 4; ++rho)
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt)
-                    outx[rt][2 * NET + o] = mfma4(a2c[o][rho], hv[rt][rho], outx[rt][2 * NET + o]);
-    }
+                    outx[rt][2 * NET + o] = mfma4(c.a2c[o][rho], hv[rt][rho], outx[rt][2 * NET + o]);
+    };
+    auto step = [&](const St &c, St &nx, int t) {
+        const int t2 = (t + 2 < last) ? t + 2 : last;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) nx.a1n[k4] = *opaque(pA1 + ((size_t)t2 * K4 + k4) * 256);
+        nx.b1n = *opaque(pB1 + t2 * 16);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) nx.a2c[o] = *opaque(pA2 + ((size_t)(t + 1) * 2 + o) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        f4 hv[R];
+        constexpr int RB = (R % 2 == 0) ? 2 : 1;
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += RB) {           // phase A: GEMM1 of tile t+1 || activation of tile t
+#pragma unroll
+            for (int u = 0; u < RB; ++u) nx.acc[r0 + u] = c.b1n;
+#pragma unroll
+            for (int kk = 0; kk < NF + CQ; ++kk)
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    nx.acc[r0 + u] = mfma16(c.a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), nx.acc[r0 + u]);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gemm2(c, hv);                                  // phase B
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto finish = [&](const St &c) {
+        f4 hv[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(c.acc[rt]);
+        gemm2(c, hv);
+    };
+    int t = 0;
+    for (; t + 1 < last; t += 2) { step(s0, s1, t); step(s1, s0, t + 1); }
+    if (t < last) { step(s0, s1, t); finish(s1); } else finish(s0);
 }
 
 // partial sums over lane groups -> each lane keeps (net, slot f) of the features it owns:
