@@ -69,11 +69,13 @@ class PermutationPrefetcher:
     few worker threads run them while the GPU trains (randperm releases the GIL).  At n = 1M one
     permutation costs ~9 ms of host time against ~5 ms of GPU time per epoch."""
 
-    def __init__(self, n, n_epochs, workers=4, lookahead=4):
+    def __init__(self, n, n_epochs, workers=None, lookahead=None):
         from concurrent.futures import ThreadPoolExecutor
         self.n, self.n_epochs = n, n_epochs
         self.seeds = [draw_loader_seed() for _ in range(n_epochs)]
-        self.lookahead = max(1, lookahead)
+        if workers is None:          # one serial randperm costs ~11 ns per row: enough of them in flight to keep ahead of the GPU
+            workers = max(1, min(12, (os.cpu_count() or 4) // 2))
+        self.lookahead = max(1, lookahead if lookahead is not None else workers)
         self.pool = ThreadPoolExecutor(max_workers=max(1, min(workers, n_epochs))) if n_epochs > 1 and n >= 65536 else None
         self.futs = {}
         self.next_submit = 0
