@@ -1,6 +1,6 @@
 // rnvp_mfma.h -- geometry of the register-chained f32 MFMA path (gfx950, wave64).
 //
-// Shapes: any d <= 64, cdim <= 16, one hidden layer of any width, tanh, alternating masks; sizes are
+// Shapes: any d <= 64, cdim <= 16, one hidden layer of any width, tanh or ReLU, alternating masks; sizes are
 // padded up to the tile geometry (d -> 16/32/64, cdim -> 0/4/8/16, h -> multiple of 16) with zero
 // weights, so the README shape (d=2, c=1, h=10) and the reference's test shape (d=5, c=3) run here too.
 //

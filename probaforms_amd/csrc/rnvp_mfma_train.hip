@@ -24,6 +24,8 @@
 //     No float atomics anywhere: results are bitwise reproducible.
 //   The tile loops are hand-scheduled in phases (rnvp_mfma_layer.h explains why); for d == 16 the
 //   input-gradient product, like GEMM2 in the forward, runs as 4x4x1 MFMA blocks.
+//   Per launch the host picks the row tiles per wave from the batch size (pick_rows) and, while a batch gives
+//   at most one workgroup per CU, the net-split wave mode (layer_bwd): 8 waves, each pair sharing its row tiles.
 #include <atomic>
 
 #include "rnvp_mfma_layer.h"
