@@ -526,8 +526,12 @@ int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const fl
     if (grad_out) {
         const size_t n4 = (size_t)g.gfloats / 4;
         S = grid < kSeg ? grid : kSeg;
-        hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), S), dim3(256), 0, st, gpart, grid, n4, seg);
-        RNVP_HIP_TRY(hipGetLastError());
+        if (grid > kSeg) {
+            hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), S), dim3(256), 0, st, gpart, grid, n4, seg);
+            RNVP_HIP_TRY(hipGetLastError());
+        } else {
+            seg = gpart;                          // up to kSeg workgroups ARE the segments
+        }
     }
     hipLaunchKernelGGL(k_unpack, dim3(g.P / 256 + 2), dim3(256), 0, st, g, seg, S, losspart, grid * kWaves, inv_B, grad_out,
                        loss_out);

@@ -791,11 +791,15 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     const unsigned blocks = (unsigned)(P / 256 + 2);     // last block's last wave is always past P: it sums the loss
     int NTI = (g.KS1 + 1 + 3) / 4;
     const size_t n4 = (size_t)pl.glayer_floats * k.L / 4;
-    hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), kSeg), dim3(256), 0, st, gpart, grid, n4, seg);
-    RNVP_HIP_TRY(hipGetLastError());
-    RNVP_HIP_TRY(hipGetLastError());
-    // second level (<= kSeg segment sums per parameter) is folded into the scatter to flat order
+    // second level (<= kSeg segment sums per parameter) is folded into the scatter to flat order; up to kSeg
+    // workgroups ARE the segments (small batches: one launch fewer per step)
     const int S = grid < kSeg ? grid : kSeg;
+    if (grid > kSeg) {
+        hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), kSeg), dim3(256), 0, st, gpart, grid, n4, seg);
+        RNVP_HIP_TRY(hipGetLastError());
+    } else {
+        seg = gpart;
+    }
     hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, seg, S, losspart,
                        grid, inv_B, grad_out, loss_out, adam_p, adam_m, adam_v, adam);
     RNVP_HIP_TRY(hipGetLastError());
