@@ -58,13 +58,16 @@ constexpr int kAblate = RNVP_ABLATE;
 #else
 #define BWD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
-struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2, p3, p4, p5; };
+struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2, p3, p4, p5, fb1, fsum; };
 
 #ifndef RNVP_TRAIN_WAVES
 #define RNVP_TRAIN_WAVES 4
 #endif
 constexpr int kWaves = RNVP_TRAIN_WAVES;    // waves per workgroup
-constexpr int kMaxGridTrain = 512;
+#ifndef RNVP_MAX_GRID_TRAIN
+#define RNVP_MAX_GRID_TRAIN 512
+#endif
+constexpr int kMaxGridTrain = RNVP_MAX_GRID_TRAIN;
 
 template <int NF, int CQ> struct Dims {
     static constexpr int KS1 = NF + CQ;
@@ -342,6 +345,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         }
                 }
                 __syncthreads();
+                STAMP_ADD(stp.fb1, t0);
                 if constexpr (NS) {
                     // both nets flush together: threads 0..255 add the slots of waves 0..3 (t net), threads
                     // 256..511 those of waves 4..7 (s net), each in wave order
@@ -351,10 +355,12 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)fr * netblock + (size_t)t0 * TBLK);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)fr * kWaves * SLOT);
                     for (int i = ft; i < nfl4; i += 256) {
+                        f4 old = f4{0.f, 0.f, 0.f, 0.f};
+                        if (!first) old = dst[i];           // in flight while the slots are read
                         f4 v = s0[i];
 #pragma unroll
                         for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
-                        dst[i] = first ? v : dst[i] + v;
+                        dst[i] = first ? v : v + old;
                     }
                     if (last_tile && tid < NT2 * 16) {
                         const int i = kWaves * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
@@ -371,10 +377,12 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds);
                     for (int i = tid; i < nfl4; i += kWaves * 64) {
+                        f4 old = f4{0.f, 0.f, 0.f, 0.f};
+                        if (!first) old = dst[i];           // in flight while the slots are read
                         f4 v = s0[i];
 #pragma unroll
                         for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
-                        dst[i] = first ? v : dst[i] + v;
+                        dst[i] = first ? v : v + old;
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
                         const int i = FT * TBLK + tid;
@@ -385,7 +393,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         *p = first ? v : *p + v;
                     }
                 }
-                __syncthreads();
+                STAMP_ADD(stp.fsum, t0);
+                if (!(kAblate & 128)) __syncthreads();
                 STAMP_ADD(stp.bflush, t0);
             }
 #pragma unroll
@@ -464,7 +473,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + pw) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
     bool first = true;
-    Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0, tk0 = 0; (void)t0; (void)tk0;
     STAMP(tk0);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -531,8 +540,8 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     {
         unsigned long long tk1; STAMP(tk1);
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-            printf("STAMP wg %d wave %d total %llu load %llu fwd %llu bsetup %llu p1 %llu p2 %llu p3 %llu p4 %llu p5 %llu bflush %llu btail %llu\n",
-                   (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.p1, stp.p2, stp.p3, stp.p4, stp.p5, stp.bflush, stp.btail);
+            printf("STAMP wg %d wave %d total %llu load %llu fwd %llu bsetup %llu p1 %llu p2 %llu p3 %llu p4 %llu p5 %llu flush: barrier1 %llu sum+store %llu barrier2 %llu btail %llu\n",
+                   (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.p1, stp.p2, stp.p3, stp.p4, stp.p5, stp.fb1, stp.fsum, stp.bflush, stp.btail);
     }
 #endif
 }
