@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from .._engine import (FlatAdam, broadcast_, default_device, dist_info, fit_epochs, flatten_parameters,
+from .._engine import (FlatAdam, broadcast_, default_device, dist_info, fit_epochs, flatten_parameters, shard_bounds,
                        is_flat, require_hip)
 from .interfaces import GenModel
 from .nflow import InvertibleLayer, NormalizingFlow, StandardNormalPrior
@@ -202,8 +202,17 @@ class RealNVP(GenModel):
         if bar is not None:
             bar.close()
 
-    def sample(self, C=100):
+    def sample(self, C=100, *, distributed=None):
+        """``distributed`` (build-only, keyword-only) matters under torch.distributed only:
+        None -- every rank draws all n rows (the reference's behaviour in each process);
+        'shard' -- this rank draws only its contiguous share of the rows and returns that block;
+        'gather' -- shares are drawn per rank, then all-gathered: every rank returns all n rows.
+        With the host prior the n x d normal draw is made in full on every rank (same generator state ->
+        same stream) and sliced, so the union of the shares is the single-process sample."""
         n = C if type(C) == type(1) else len(C)
+        rank, world = dist_info()
+        if distributed is not None and world > 1:
+            return self._sample_sharded(C, n, rank, world, gather=(distributed == 'gather'))
         if self.nf.pipelined_rows(n):
             # large draws: prior / H2D / inverse kernel / D2H overlapped over row chunks, same values
             return self.nf.sample_to_host(C)
@@ -211,3 +220,27 @@ class RealNVP(GenModel):
             C = _to_device_f32(C, self.nf.engine().device)
         X = self.nf.sample(C).cpu().detach().numpy()
         return X
+
+    def _sample_sharded(self, C, n, rank, world, gather):
+        import torch.distributed as dist
+        eng = self.nf.engine()
+        lo, hi = shard_bounds(0, n, rank, world)
+        if isinstance(self.prior, StandardNormalPrior) and self.prior.host_rng:
+            z = torch.randn((n, self.prior.var_size))[lo:hi].to(eng.device).contiguous()     # the full reference stream, sliced
+        elif getattr(self.prior, "host_rng", True):
+            z = torch.as_tensor(self.prior.sample((n,)), dtype=torch.float32)[lo:hi].to(eng.device).contiguous()
+        else:
+            z = torch.as_tensor(self.prior.sample((hi - lo,)), dtype=torch.float32).to(eng.device).contiguous()
+        Cl = None if type(C) == type(1) else _to_device_f32(C[lo:hi], eng.device)
+        x = eng.inverse(z, Cl, out=z) if hi > lo else z
+        if not gather:
+            return x.cpu().detach().numpy()
+        # equal-size all_gather: pad every share to the largest one
+        width = x.shape[1]
+        cap = -(-n // world)
+        buf = torch.zeros((cap, width), dtype=torch.float32, device=eng.device)
+        buf[:hi - lo] = x
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        rows = [shard_bounds(0, n, r, world) for r in range(world)]
+        return torch.cat([p[:b - a] for p, (a, b) in zip(parts, rows)]).cpu().numpy()

@@ -28,6 +28,13 @@ def main():
     same = all(torch.equal(gathered[0], g) for g in gathered)
     torch.manual_seed(5)
     xs = m.sample(C[:64])
+    smp = {}
+    for mode in ("shard", "gather"):                             # row shares per rank, optional gather
+        torch.manual_seed(5)
+        smp[mode] = m.sample(C[:61], distributed=mode)
+    torch.manual_seed(5)
+    full61 = m.sample(C[:61])
+    np.savez(out + ".rank%d.npz" % rank, shard=smp["shard"], gather=smp["gather"], full=full61)
     if rank == 0:
         np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs)
     dist.barrier()

@@ -87,7 +87,13 @@ def _fit(world_rank=None):
     m.fit(X, C)
     flat = torch.cat([p.detach().reshape(-1) for p in m.nf.parameters()]).numpy().copy()
     hist = np.array([float(v) for v in m.loss_history])
-    return flat, hist
+    # sampling: shares per rank / gathered / replicated, all from the same generator state
+    Cs = C[:37]
+    out = {}
+    for mode in (None, "shard", "gather"):
+        torch.manual_seed(9)
+        out[str(mode)] = m.sample(Cs, distributed=mode) if mode else m.sample(Cs)
+    return flat, hist, out
 
 
 def _worker(rank, world, port, out_dir):
@@ -95,8 +101,8 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        flat, hist = _fit(rank)
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), flat=flat, hist=hist)
+        flat, hist, smp = _fit(rank)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), flat=flat, hist=hist, **{"s_" + k: v for k, v in smp.items()})
     finally:
         dist.destroy_process_group()
 
@@ -111,10 +117,16 @@ def test_two_ranks_match_single_process(tmp_path):
     # reference run in a fresh single process (world size 1 path: fused train_step)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_single, args=(q,)); p.start(); flat1, hist1 = q.get(timeout=240); p.join()
+    p = ctx.Process(target=_single, args=(q,)); p.start(); flat1, hist1, smp1 = q.get(timeout=240); p.join()
     # only the summation order of the two shards differs from the single-process gradient
     np.testing.assert_allclose(r0["hist"], hist1, rtol=2e-5, atol=2e-5)
     assert np.abs(r0["flat"] - flat1).max() < 5e-4 and np.abs(r0["flat"] - flat1).mean() < 2e-5
+    # sampling: the two shares are the two halves of what every rank draws alone; 'gather' returns all of it
+    for r in (r0, r1):
+        assert r["s_None"].shape == (37, 4) and np.array_equal(r["s_gather"], r["s_None"])
+    assert r0["s_shard"].shape == (19, 4) and r1["s_shard"].shape == (18, 4)
+    assert np.array_equal(np.concatenate([r0["s_shard"], r1["s_shard"]]), r0["s_None"])
+    assert smp1["shard"].shape == (37, 4)                            # world size 1: the keyword changes nothing
 
 
 def _single(q):

@@ -50,6 +50,12 @@ def test_two_ranks_on_hip_kernels_match_single_process(tmp_path):
     torch.manual_seed(5)
     xs = m.sample(C[:64])
     assert np.abs(xs - dp["xs"]).max() < 5e-3
+    # sharded sampling: rank shares are consecutive blocks of the replicated draw; 'gather' rebuilds all of it
+    s0, s1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    assert s0["shard"].shape == (31, 5) and s1["shard"].shape == (30, 5)
+    for s_ in (s0, s1):
+        np.testing.assert_array_equal(s_["gather"], s_["full"])
+    np.testing.assert_array_equal(np.concatenate([s0["shard"], s1["shard"]]), s0["full"])
 
 
 @pytest.mark.timeout(900)
