@@ -127,6 +127,16 @@ def main():
     one_gpu = os.environ.get("BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
+    # BENCH_FORCE_DIST=1 (developer aid): a single rank still initialises RCCL and runs the data-parallel step
+    # (unfused loss+grad, all-reduce on RCCL's stream under the sampling kernel, Adam) -- exercises the N > 1
+    # code path, RCCL included, on a 1-GPU box.
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1" and world == 1
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dp = world > 1 or force_dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -148,7 +158,7 @@ def main():
     for p in nf.parameters():
         p.data = p.data.to(dev)
     eng = nf.engine()
-    if world > 1:
+    if dp:
         _engine.broadcast_(eng.flat, 0)
     opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
 
@@ -170,7 +180,7 @@ def main():
         rows = perm[s:e]
         g = eng.loss_grad(X, C, rows, e - s, inv_B)
         c_rows = C[s:e]                                               # conditions of the sampled rows
-        if world > 1:
+        if dp:
             # the gradient all-reduce (RCCL, its own stream) runs under the sampling kernel, which
             # does not depend on it; Adam waits for the reduced gradient
             work = dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM, async_op=True)
@@ -189,7 +199,7 @@ def main():
         eng.train_step(opt, X, C, perm[s:e], e - s, inv_B, losses[i:i + 1])
         eng.inverse(z, C[s:e], out=xs)
 
-    if world == 1:
+    if not dp:
         step = lambda i, timed_idx=None: step1(i)
 
     for i in range(args.warmup):
@@ -198,17 +208,17 @@ def main():
     # HIP events around the dominant kernel (the fused forward+backward launch), recorded by the
     # library on the stream it launches on, for every step of the timed region
     _hip.profile_enable(args.steps)
-    if world > 1:
+    if dp:
         dist.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, k)
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -257,7 +267,7 @@ def main():
                                   "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
                                   "target": 1e-5}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()                      # rank 0 may still be timing the CPU baseline
         dist.destroy_process_group()
 

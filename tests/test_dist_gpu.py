@@ -68,3 +68,15 @@ def test_bench_two_rank_path_prints_one_json_line():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["global_batch"] == 2 * 65536 and j["roofline"]["frac"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_data_parallel_step_over_rccl_single_rank():
+    """the N-rank step of bench.py with the real collective library: one rank, RCCL initialised, gradient
+    all-reduce on RCCL's stream under the sampling kernel (BENCH_FORCE_DIST=1)"""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["frac"] > 0
