@@ -47,13 +47,17 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params,
                    int64_t n_rows, float inv_B, float kl_weight,
                    float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes);
 
-/* x_out [n,d] = Decoder([z || c])                                       cvae.py:108-113, 284-290 */
+/* x_out [n,d] = Decoder([z || c])                                       cvae.py:108-113, 284-290
+ * workspace (nullable; cvae_workspace_bytes) lets shapes on RNVP_PATH_MFMA run the MFMA kernels (the packed
+ * weights live there); NULL runs the generic kernels. */
 int cvae_decode(void *stream, const cvae_shape *shape, const float *params,
-                const float *z, const float *c, int64_t n_rows, float *x_out);
+                const float *z, const float *c, int64_t n_rows, float *x_out,
+                void *workspace, size_t workspace_bytes);
 
-/* mu [n,lat], log_sigma [n,lat] = Encoder([x || c])                     cvae.py:57-64 */
+/* mu [n,lat], log_sigma [n,lat] = Encoder([x || c])                     cvae.py:57-64; workspace as above */
 int cvae_encode(void *stream, const cvae_shape *shape, const float *params,
-                const float *x, const float *c, int64_t n_rows, float *mu_out, float *log_sigma_out);
+                const float *x, const float *c, int64_t n_rows, float *mu_out, float *log_sigma_out,
+                void *workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -106,8 +106,8 @@ _SIGNATURES = {
     "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
     "cvae_force_generic": (None, [C.c_int]),
     "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
-    "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP]),
-    "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP]),
+    "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
+    "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
     "rnvp_profile_enable": (C.c_int, [C.c_int]),
     "rnvp_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
@@ -267,12 +267,15 @@ def cvae_loss_grad(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight
           _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
 
 
-def cvae_decode(shape, params, z, c, n_rows, x_out):
+def cvae_decode(shape, params, z, c, n_rows, x_out, ws=None):
+    """ws (cvae_workspace_bytes) enables the MFMA kernels where the shape allows; None runs the generic ones"""
+    wp, wn = _ws(ws) if ws is not None else (None, 0)
     _call("cvae_decode", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(z, torch.float32, "z"),
-          _ptr(c, torch.float32, "c"), int(n_rows), _ptr(x_out, torch.float32, "x_out")))
+          _ptr(c, torch.float32, "c"), int(n_rows), _ptr(x_out, torch.float32, "x_out"), wp, wn))
 
 
-def cvae_encode(shape, params, x, c, n_rows, mu_out, ls_out):
+def cvae_encode(shape, params, x, c, n_rows, mu_out, ls_out, ws=None):
+    wp, wn = _ws(ws) if ws is not None else (None, 0)
     _call("cvae_encode", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(x, torch.float32, "x"),
           _ptr(c, torch.float32, "c"), int(n_rows), _ptr(mu_out, torch.float32, "mu_out"),
-          _ptr(ls_out, torch.float32, "log_sigma_out")))
+          _ptr(ls_out, torch.float32, "log_sigma_out"), wp, wn))

@@ -255,13 +255,16 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, c
 }
 
 int cvae_decode(void *stream, const cvae_shape *shape, const float *params, const float *z, const float *c,
-                int64_t n_rows, float *x_out) {
+                int64_t n_rows, float *x_out, void *workspace, size_t workspace_bytes) {
     CvaeK k;
     int rc = make_cvae(shape, &k);
     if (rc) return rc;
     if (n_rows < 0) return RNVP_EINVAL;
     if (n_rows == 0) return RNVP_OK;
     if (!params || !z || (k.c > 0 && !c) || !x_out) return RNVP_EINVAL;
+    if (workspace && !g_force_generic.load() && cvae_mfma::supported(shape))
+        return cvae_mfma::forward(static_cast<hipStream_t>(stream), shape, params, false, z, c, n_rows, x_out, nullptr,
+                                  workspace, workspace_bytes);
     int TB; size_t lds;
     const size_t fpr = (size_t)(k.lat + k.c) + 2 * k.dec.hmax + k.d;
     if (!pick_tb(fpr, n_rows, &TB, &lds)) return RNVP_EUNSUPPORTED;
@@ -275,13 +278,16 @@ int cvae_decode(void *stream, const cvae_shape *shape, const float *params, cons
 }
 
 int cvae_encode(void *stream, const cvae_shape *shape, const float *params, const float *x, const float *c,
-                int64_t n_rows, float *mu_out, float *log_sigma_out) {
+                int64_t n_rows, float *mu_out, float *log_sigma_out, void *workspace, size_t workspace_bytes) {
     CvaeK k;
     int rc = make_cvae(shape, &k);
     if (rc) return rc;
     if (n_rows < 0) return RNVP_EINVAL;
     if (n_rows == 0) return RNVP_OK;
     if (!params || !x || (k.c > 0 && !c) || !mu_out || !log_sigma_out) return RNVP_EINVAL;
+    if (workspace && !g_force_generic.load() && cvae_mfma::supported(shape))
+        return cvae_mfma::forward(static_cast<hipStream_t>(stream), shape, params, true, x, c, n_rows, mu_out, log_sigma_out,
+                                  workspace, workspace_bytes);
     int TB; size_t lds;
     const size_t fpr = (size_t)(k.d + k.c) + 2 * k.enc.hmax + 2 * k.lat;
     if (!pick_tb(fpr, n_rows, &TB, &lds)) return RNVP_EUNSUPPORTED;

@@ -430,6 +430,97 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
     if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
 }
 
+// ---- encoder / decoder alone (cvae_encode, cvae_decode): the forward blocks of the step, no LDS -------------
+template <bool ENCODE>
+__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+k_cvae_mfma_mlp(CG g, const float *__restrict__ wp, const float *__restrict__ in, const float *__restrict__ c, int64_t n,
+                float *__restrict__ out0, float *__restrict__ out1) {
+    constexpr int R = kR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int HT = g.HT;
+    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
+        if (base >= n) continue;
+        float xr[R][4], cr[R][1];
+        bool valid[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const int64_t row = base + rt * 16 + r;
+            valid[rt] = row < n;
+            const int64_t src = valid[rt] ? row : 0;
+            if (ENCODE) {
+                mfma::load_row<2, 1>(in, c, src, g.d, g.c, (g.d == 16) && (g.c == 4), q, xr[rt], cr[rt]);
+            } else {
+                xr[rt][0] = (q < g.lat) ? in[src * g.lat + q] : 0.f;                          // z[q]
+                cr[rt][0] = (q < g.c) ? c[src * g.c + q] : 0.f;
+            }
+        }
+        if (ENCODE) {
+            const f4 bh = *reinterpret_cast<const f4 *>(wp + g.oBH + q * 4);
+            f4 outE[R][2];
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) { outE[rt][0] = f4{0.f, 0.f, 0.f, 0.f}; outE[rt][1] = f4{0.f, 0.f, 0.f, 0.f}; }
+            const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2 = wp + g.oA2E + lane * 4;
+            for (int t = 0; t < HT; ++t) {
+                const f4 a10 = *opaque(pA1 + (size_t)(2 * t) * 256), a11 = *opaque(pA1 + (size_t)(2 * t + 1) * 256);
+                const f4 b1 = *opaque(pB1 + t * 16);
+                const f4 a20 = *opaque(pA2 + (size_t)(2 * t) * 256), a21 = *opaque(pA2 + (size_t)(2 * t + 1) * 256);
+                f4 hv[R];
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) {
+                    f4 acc = b1;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = mfma16(a10[kk], xr[rt][kk], acc);
+                    acc = mfma16(a11[0], cr[rt][0], acc);
+                    hv[rt] = tanh4(acc);
+                }
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) {
+                        outE[rt][0] = mfma4(a20[rho], hv[rt][rho], outE[rt][0]);
+                        outE[rt][1] = mfma4(a21[rho], hv[rt][rho], outE[rt][1]);
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                const float mu = reduce_scatter4(outE[rt][0]) + bh[0], ls = reduce_scatter4(outE[rt][1]) + bh[1];
+                const int64_t row = base + rt * 16 + r;
+                if (valid[rt] && q < g.lat) { out0[row * g.lat + q] = mu; out1[row * g.lat + q] = ls; }
+            }
+        } else {
+            const f4 b2d = *reinterpret_cast<const f4 *>(wp + g.oB2D + q * 4);
+            f4 xrec[R];
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) xrec[rt] = b2d;
+            const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4, *pA2 = wp + g.oA2D + lane * 4;
+            for (int t = 0; t < HT; ++t) {
+                const f4 a1 = *opaque(pA1 + (size_t)t * 256), b1 = *opaque(pB1 + t * 16), a2 = *opaque(pA2 + (size_t)t * 256);
+                f4 hv[R];
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) {
+                    f4 acc = mfma16(a1[0], xr[rt][0], b1);
+                    acc = mfma16(a1[1], cr[rt][0], acc);
+                    hv[rt] = tanh4(acc);
+                }
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) xrec[rt] = mfma16(a2[rho], hv[rt][rho], xrec[rt]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                const int64_t row = base + rt * 16 + r;
+                const float v[4] = {xrec[rt][0], xrec[rt][1], xrec[rt][2], xrec[rt][3]};
+                if (valid[rt]) mfma::store_row<2>(out0, row, g.d, g.d == 16, q, v);
+            }
+        }
+    }
+}
+
 // D-layout location of (row i of the 16-row M tile = hid & 15, column j) inside a 256-float block
 __device__ __forceinline__ int dloc(int hid, int col) { const int i = hid & 15; return (16 * (i >> 2) + col) * 4 + (i & 3); }
 
@@ -535,6 +626,24 @@ int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const fl
     }
     hipLaunchKernelGGL(k_unpack, dim3(g.P / 256 + 2), dim3(256), 0, st, g, seg, S, losspart, grid * kWaves, inv_B, grad_out,
                        loss_out);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+// encoder (mu, log_sigma) or decoder (x_rec) alone on the MFMA blocks; the packed weights go to the caller's workspace
+int forward(hipStream_t st, const cvae_shape *s, const float *params, bool encode, const float *in, const float *c,
+            int64_t n, float *out0, float *out1, void *ws, size_t ws_bytes) {
+    const CG g = make_cg(s);
+    if (!ws || ws_bytes < align_up((size_t)g.packed_floats * 4, 256)) return RNVP_EWORKSPACE;
+    float *packed = static_cast<float *>(ws);
+    hipLaunchKernelGGL(k_pack, dim3((g.packed_floats + 255) / 256), dim3(256), 0, st, g, params, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    const int64_t rows_per_wg = (int64_t)kWaves * kR * 16, ngroups = (n + rows_per_wg - 1) / rows_per_wg;
+    const int grid = (int)(ngroups < 2048 ? ngroups : 2048);
+    if (encode)
+        hipLaunchKernelGGL(k_cvae_mfma_mlp<true>, dim3(grid), dim3(kWaves * 64), 0, st, g, packed, in, c, n, out0, out1);
+    else
+        hipLaunchKernelGGL(k_cvae_mfma_mlp<false>, dim3(grid), dim3(kWaves * 64), 0, st, g, packed, in, c, n, out0, out1);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }

@@ -77,6 +77,8 @@ size_t workspace_bytes(const ::cvae_shape *s);
 int loss_grad(hipStream_t st, const ::cvae_shape *s, const float *params, const float *x, const float *c,
               const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
               float *loss_out, void *ws, size_t ws_bytes);
+int forward(hipStream_t st, const ::cvae_shape *s, const float *params, bool encode, const float *in, const float *c,
+            int64_t n, float *out0, float *out1, void *ws, size_t ws_bytes);
 }  // namespace cvae_mfma
 
 // ---- Adam arithmetic shared by k_adam (rnvp_adam.hip) and the fused reduce+Adam kernel ------------

@@ -86,7 +86,7 @@ class Encoder(nn.Module):
         X, C = _dev(X, core.device), _dev(C, core.device)
         n = X.shape[0]
         mu = torch.empty(n, core.shape.lat, device=core.device); ls = torch.empty_like(mu)
-        _hip.cvae_encode(core.shape, core.sync(), X, C, n, mu, ls)
+        _hip.cvae_encode(core.shape, core.sync(), X, C, n, mu, ls, core.workspace(n))
         return mu, ls
 
 
@@ -105,7 +105,7 @@ class Decoder(nn.Module):
             raise RuntimeError("Decoder must belong to a CVAE (its weights live in the CVAE's flat HIP buffer)")
         Z, C = _dev(X, core.device), _dev(C, core.device)
         out = torch.empty(Z.shape[0], core.shape.d, device=core.device)
-        _hip.cvae_decode(core.shape, core.sync(), Z, C, Z.shape[0], out)
+        _hip.cvae_decode(core.shape, core.sync(), Z, C, Z.shape[0], out, core.workspace(Z.shape[0]))
         return out
 
 

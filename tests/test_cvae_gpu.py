@@ -27,17 +27,19 @@ def _load(name):
     return _hip, g, shape, klw, (g["C"] if c else None)
 
 
+@pytest.mark.parametrize("with_ws", [False, True])           # NULL workspace: generic kernels; with one: MFMA where supported
 @pytest.mark.parametrize("name", list(CASES))
-def test_encode_decode(name):
+def test_encode_decode(name, with_ws):
     _hip, g, shape, klw, C = _load(name)
     n = g["X"].shape[0]
     p = _dev(g["init_params"])
+    ws = torch.empty(_hip.cvae_workspace_bytes(shape, n), dtype=torch.uint8, device="cuda") if with_ws else None
     mu = torch.empty(n, shape.lat, device="cuda"); ls = torch.empty_like(mu)
-    _hip.cvae_encode(shape, p, _dev(g["X"]), _dev(C), n, mu, ls)
+    _hip.cvae_encode(shape, p, _dev(g["X"]), _dev(C), n, mu, ls, ws)
     np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(ls.cpu().numpy(), g["log_sigma"], rtol=2e-6, atol=2e-6)
     x = torch.empty(n, shape.d, device="cuda")
-    _hip.cvae_decode(shape, p, _dev(g["Z"]), _dev(C), n, x)
+    _hip.cvae_decode(shape, p, _dev(g["Z"]), _dev(C), n, x, ws)
     np.testing.assert_allclose(x.cpu().numpy(), g["decoded"], rtol=2e-6, atol=2e-6)
 
 
@@ -89,6 +91,14 @@ def test_mfma_step_shapes_vs_oracle(d, c, lat, h, n):
     g2 = torch.empty_like(grad)                                     # deterministic: run-to-run bit-identical
     _hip.cvae_loss_grad(shape, _dev(p), _dev(X), _dev(C), None, _dev(eps), n, 1.0 / n, 0.3, g2, loss, ws)
     assert torch.equal(grad, g2)
+    # encoder / decoder alone on the MFMA blocks (workspace given) against the float64 oracle
+    o = CvaeOracle(64); so = CvaeShape.make(d, c, lat, (h,), "tanh")
+    mu = torch.empty(n, lat, device="cuda"); ls = torch.empty_like(mu); xr = torch.empty(n, d, device="cuda")
+    _hip.cvae_encode(shape, _dev(p), _dev(X), _dev(C), n, mu, ls, ws)
+    _hip.cvae_decode(shape, _dev(p), _dev(eps), _dev(C), n, xr, ws)
+    mu_o, ls_o = o.encode(so, p, X, C); x_o = o.decode(so, p, eps, C)
+    for got, want in ((mu, mu_o), (ls, ls_o), (xr, x_o)):
+        assert np.abs(got.cpu().numpy() - want).max() < 3e-6 * max(1.0, np.abs(want).max())
 
 
 @pytest.mark.parametrize("name", list(CASES))
