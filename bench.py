@@ -3,23 +3,36 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): n = 1M rows per GPU of make_moons-shaped tabular
-data, d=16, cond=4, 8 coupling layers, hidden=(128,), float32.  One STEP = one pass of the hot
-path over one batch: a training step (loss + gradient + Adam, realnvp.py:246-251) on a batch of
-65 536 shuffled rows per GPU, plus sampling (inverse pass, realnvp.py:279-282) of 65 536 rows per
-GPU.  Inputs are resident in HBM before the timed region.  With N > 1 every rank processes its
-own 65 536-row shard of a global batch of N x 65 536 (weak scaling) and the flat
-[gradient | loss] buffer is all-reduced over RCCL before Adam.
+Workload (BASELINE.json configs[1], "C2"): n = 1M rows per GPU of make_moons-shaped tabular data, d=16,
+cond=4, 8 coupling layers, hidden=(128,).  One STEP = one pass of the hot path over the rank's data set:
+  fit    -- one epoch of RealNVP.fit's batch loop (realnvp.py:235-254): 16 batches of the epoch's shuffled
+            rows (15 x 65 536 + the ragged 16 960), each loss + gradient + Adam;
+  sample -- RealNVP.sample for the same 1M conditions (realnvp.py:279-282; nflow.py:141-143): the prior
+            draw (counter-based device prior, made inside the inverse kernel) + the inverse pass.
+X, C and the epoch permutations are resident in HBM before the timed region.  With N > 1 every rank owns
+its own 1M rows (weak scaling): per batch each rank computes the gradient of its 65 536-row shard of the
+global batch of N x 65 536, the flat [gradient | loss] buffer is all-reduced over RCCL, every rank applies
+the same Adam step; sampling shards the global N x 1M rows with no collective.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks (child processes
+of `python -m torch.distributed.run`; nothing in the parent touches the GPU) and relays their output.
 
 `value` = rows (fit rows + sampled rows) per second over all GPUs.  The JSON line also carries
-  roofline     -- the dominant kernel (fused loss+gradient) against the f32 MFMA peak, from HIP
-                  events around each launch inside the timed region;
-  cpu_baseline -- the CPU oracle (oracle/, a C port of the reference's algorithm) on all host cores
-                  of rank 0's box, on a bounded sample of the same workload.
+  roofline        -- the dominant kernel (fused forward+backward) against the f32 MFMA peak, from HIP events
+                     around every one of its launches inside the timed region;
+  roofline_kernels-- the same for the sampling kernel (timed region) and the log-prob kernel (measured after it);
+  cpu_baseline    -- the CPU oracle (oracle/, a C port of the reference's algorithm) on the host cores of
+                     rank 0's box, on a bounded sample of the same workload;
+  api_level       -- numpy in -> numpy out rates of RealNVP.fit / .sample on the same data (N = 1 only);
+  logprob_mae     -- second half of the metric: per-row log-prob of the HIP path against the oracle.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +45,7 @@ sys.path.insert(0, ROOT)
 N_ROWS, D, CDIM, LAYERS, HIDDEN = 1_000_000, 16, 4, 8, (128,)
 BATCH = 65_536
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")
 
 
 def moons_block(n, rng, noise=0.1):
@@ -67,16 +81,29 @@ def useful_flops_per_row(d, c, hidden, L, passes):
     return 4 * hidden[0] * (d + c) * L * passes
 
 
+def csrc_hash():
+    """identifies the kernel sources a PMC profile was taken with (no .git on the GPU box)"""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "probaforms_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "probaforms_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
-    command (scripts/gpu_traffic.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE
-    doubled per MI355X_MICROARCH.md).  bench.py cannot collect counters itself; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    """HBM bytes per launch of a kernel from the committed PMC profile of this same command
+    (scripts/gpu_traffic.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  bench.py cannot collect counters itself; the file's number is reported only while
+    it was taken with exactly these kernel sources (csrc_hash) and names this kernel, else None."""
     try:
-        d = json.load(open(path))
-    except OSError:
+        d = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
         return None
-    for k, v in d.items():
+    if d.get("csrc_hash") != csrc_hash():
+        return None
+    for k, v in d.get("kernels", {}).items():
         if k.startswith(kernel_prefix):
             return float(v["hbm_bytes_per_launch"])
     return None
@@ -85,8 +112,8 @@ def pmc_traffic(kernel_prefix):
 def cpu_baseline(X, C, params, rows_per_thread=16384):
     """The oracle (C port of the reference's algorithm) on the host cores: one training step
     (loss + gradient, shards summed, Adam) + sampling, on rows_per_thread rows per core -- the same
-    mix as one GPU step.  Threads call into the C library concurrently (ctypes releases the GIL);
-    each computes the gradient of its shard exactly like a data-parallel rank would."""
+    1:1 mix of fit rows and sampled rows as one GPU step.  Threads call into the C library concurrently
+    (ctypes releases the GIL); each computes the gradient of its shard like a data-parallel rank would."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import Oracle, Shape
     cores = max(1, min(os.cpu_count() or 1, 64))
@@ -105,17 +132,62 @@ def cpu_baseline(X, C, params, rows_per_thread=16384):
         list(ex.map(lambda ab: o.sample(s, p, z[ab[0]:ab[1]], C[ab[0]:ab[1]]), chunks))
     dt = time.perf_counter() - t0
     return dict(value=2 * rows / dt, unit="rows/s", cores=cores, kind="port",
-                sample="oracle/rnvp_oracle.c (float32, gcc -O2) on %d threads: 1 training step on %d rows + sampling "
-                       "%d rows of the C2 workload, %.1f s" % (cores, rows, rows, dt))
+                sample="oracle/rnvp_oracle.c (float32, gcc -O2, scalar) on %d threads: 1 training step on %d rows + "
+                       "sampling %d rows of the C2 workload, %.1f s; the eager-PyTorch reference itself reaches 72.7 k "
+                       "(fit) / 199 k (sample) rows/s on 8 cores of the build container (BASELINE.md)" % (cores, rows, rows, dt))
+
+
+def api_level(Xh, Ch, dev):
+    """numpy -> numpy through the reference's class API: fit (upload, cast, host shuffles, epochs, loss history)
+    and sample (prior draw, inverse, download).  Never `value`."""
+    import torch
+    from probaforms_amd.models import RealNVP
+    out = {}
+    epochs = 3
+    for prior in ("host", "device"):
+        torch.manual_seed(0)
+        m = RealNVP(n_layers=LAYERS, hidden=HIDDEN, batch_size=BATCH, n_epochs=1, lr=1e-3, prior_rng=prior)
+        m.fit(Xh, Ch)                                     # first call: model build, allocations
+        m.n_epochs = epochs
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); m.fit(Xh, Ch); torch.cuda.synchronize(dev); t_fit = time.perf_counter() - t0
+        m.sample(Ch)
+        t0 = time.perf_counter(); xs = m.sample(Ch); t_s = time.perf_counter() - t0
+        assert xs.shape == (N_ROWS, D) and np.isfinite(xs).all()
+        if prior == "host":
+            out["fit_rows_per_s"] = N_ROWS * epochs / t_fit
+            out["fit_epochs"] = epochs
+        out["sample_rows_per_s_%s_prior" % prior] = N_ROWS / t_s
+    out["note"] = ("RealNVP(batch_size=65536).fit(X, C) / .sample(C) on the C2 arrays, numpy in -> numpy out; 'host' prior = "
+                   "the reference's CPU randn stream, 'device' = counter-based draw inside the inverse kernel")
+    return out
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as children (never exec: the parent has not touched
+    the GPU and stays alive only to relay the exit code)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-level", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -128,8 +200,7 @@ def main():
     if one_gpu:
         local = 0
     # BENCH_FORCE_DIST=1 (developer aid): a single rank still initialises RCCL and runs the data-parallel step
-    # (unfused loss+grad, all-reduce on RCCL's stream under the sampling kernel, Adam) -- exercises the N > 1
-    # code path, RCCL included, on a 1-GPU box.
+    # (unfused loss+grad, all-reduce, Adam) -- exercises the N > 1 code path, RCCL included, on a 1-GPU box.
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1" and world == 1
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
@@ -144,7 +215,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -154,7 +225,7 @@ def main():
     # model: random init of the C2 architecture (same seed on every rank -> identical replicas)
     torch.manual_seed(0)
     layers = [RealNVPLayer(D, CDIM, (torch.arange(D) + i) % 2, HIDDEN, "tanh") for i in range(LAYERS)]
-    nf = NormalizingFlow(layers, StandardNormalPrior(D, dev))
+    nf = NormalizingFlow(layers, StandardNormalPrior(D, dev, host_rng=False))
     for p in nf.parameters():
         p.data = p.data.to(dev)
     eng = nf.engine()
@@ -165,54 +236,41 @@ def main():
     # data: resident in HBM before timing; each rank owns its own n rows (weak scaling)
     Xh, Ch = make_data(N_ROWS, D, CDIM, seed=rank)
     X = torch.from_numpy(Xh).to(dev); C = torch.from_numpy(Ch).to(dev)
-    torch.manual_seed(1 + rank)
-    perm = _engine.loader_permutation(N_ROWS).to(dev)
+    n_steps = args.steps + args.warmup
     bounds = _engine.batch_bounds(N_ROWS, BATCH)
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    z = torch.randn(BATCH, D, device=dev, generator=gen)             # prior draws for the sampling leg
-    xs = torch.empty_like(z)
-    losses = torch.zeros(args.steps + args.warmup, device=dev)
-    inv_B = 1.0 / (BATCH * world)
+    nb = len(bounds)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    perms = [torch.randperm(N_ROWS, device=dev, generator=gen) for _ in range(n_steps)]    # one shuffle per epoch
+    xs = torch.empty(N_ROWS, D, dtype=torch.float32, device=dev)
+    losses = torch.zeros(n_steps, nb, device=dev)
     P = eng.P
 
-    def step(i, timed_idx=None):
-        s, e = bounds[i % (len(bounds) - 1)]                          # full batches only
-        rows = perm[s:e]
-        g = eng.loss_grad(X, C, rows, e - s, inv_B)
-        c_rows = C[s:e]                                               # conditions of the sampled rows
-        if dp:
-            # the gradient all-reduce (RCCL, its own stream) runs under the sampling kernel, which
-            # does not depend on it; Adam waits for the reduced gradient
-            work = dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM, async_op=True)
-            eng.inverse(z, c_rows, out=xs)
-            work.wait()
-            losses[i:i + 1].copy_(g[P:P + 1])
-            eng.adam(opt)
-        else:
-            losses[i:i + 1].copy_(g[P:P + 1])
-            eng.adam(opt)
-            eng.inverse(z, c_rows, out=xs)
+    def step_dp(i):
+        perm = perms[i]
+        for k, (s, e) in enumerate(bounds):
+            g = eng.loss_grad(X, C, perm[s:e], e - s, 1.0 / ((e - s) * world))
+            dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM)
+            eng.finish_dp_step(opt, losses[i, k:k + 1])            # loss read-out + Adam, one launch
+        eng.sample(N_ROWS, C, 1000 + i, row_offset=rank * N_ROWS, out=xs)
 
-    def step1(i):
-        """single GPU: the fused rnvp_train_step (loss + gradient + Adam), as RealNVP.fit uses it"""
-        s, e = bounds[i % (len(bounds) - 1)]
-        eng.train_step(opt, X, C, perm[s:e], e - s, inv_B, losses[i:i + 1])
-        eng.inverse(z, C[s:e], out=xs)
+    def step_1(i):
+        """single GPU: rnvp_fit_epoch (a fused loss + gradient + Adam step per batch, looped in the library),
+        then the fused prior draw + inverse, as RealNVP.fit / .sample(prior_rng='device') issue them"""
+        eng.fit_epoch(opt, X, C, perms[i], BATCH, losses[i])
+        eng.sample(N_ROWS, C, 1000 + i, row_offset=0, out=xs)
 
-    if not dp:
-        step = lambda i, timed_idx=None: step1(i)
-
+    step = step_dp if dp else step_1
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    # HIP events around the dominant kernel (the fused forward+backward launch), recorded by the
-    # library on the stream it launches on, for every step of the timed region
-    _hip.profile_enable(args.steps)
+    # HIP events around the hot kernels, recorded by the library on the stream it launches on, for every
+    # launch of the timed region
+    _hip.profile_enable(args.steps * nb + 8)
     if dp:
         dist.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k, k)
+        step(args.warmup + k)
     torch.cuda.synchronize()
     if dp:
         dist.barrier()
@@ -222,36 +280,62 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    n_timed, tot_ms = _hip.profile_read()
-    _hip.profile_enable(0)
-    assert n_timed == args.steps, (n_timed, args.steps)
-    kern_ms = tot_ms / n_timed
-    final_loss = float(losses[args.warmup + args.steps - 1].item())
+    n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
+    n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
+    assert n_train == args.steps * nb and n_inv == args.steps, (n_train, n_inv, args.steps)
+    final_loss = float(losses[n_steps - 1, nb - 1].item())
     assert np.isfinite(final_loss), "training diverged"
 
     if rank == 0:
-        rows_per_step = 2 * BATCH * world
-        fl = useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 3) * BATCH      # fwd + dgrad + wgrad
-        achieved = fl / (kern_ms * 1e-3) / 1e12
+        # log-prob kernel (not part of fit+sample): measured here, after the timed region
+        for _ in range(2):
+            eng.forward(X, C, want_z=False, want_logp=True)
+        torch.cuda.synchronize()
+        _hip.profile_read(_hip.PROFILE_FORWARD)
+        for _ in range(5):
+            eng.forward(X, C, want_z=False, want_logp=True)
+        torch.cuda.synchronize()
+        n_fwd, fwd_ms = _hip.profile_read(_hip.PROFILE_FORWARD)
+    _hip.profile_enable(0)
+
+    if rank == 0:
+        rows_per_step = 2 * N_ROWS * world
+        f1 = useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 1)
+        train_tf = 3 * f1 * N_ROWS * args.steps / (train_ms * 1e-3) / 1e12          # fwd + dgrad + wgrad
+        inv_tf = f1 * N_ROWS * args.steps / (inv_ms * 1e-3) / 1e12
+        fwd_tf = f1 * N_ROWS * n_fwd / (fwd_ms * 1e-3) / 1e12
         path = _hip.kernel_path(eng.shape, eng.masks_host, _hip.OP_TRAIN)
+        kname = "k_mfma_train" if path == _hip.PATH_MFMA else "k_generic_train"
         out = {
             "metric": "RealNVP samples/sec (fit+sample)", "value": rows_per_step * args.steps / dt,
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: RealNVP n=1M/GPU d=16 cond=4 L=8 hidden=(128,), per-GPU batch 65536: "
-                                   "1 train step (loss+grad+Adam) + 65536 sampled rows per step",
+            "config": {"workload": "C2: RealNVP n=1M/GPU d=16 cond=4 L=8 hidden=(128,); one step = one fit epoch over the "
+                                   "rank's 1M rows (16 batches of 65536 incl. the ragged one: loss+grad+Adam each) + "
+                                   "sampling 1M rows (counter-based prior draw inside the inverse kernel)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("k_mfma_train" if path == _hip.PATH_MFMA else "k_generic_train"),
-                         "kernel": "k_mfma_train / k_generic_train (fused forward+backward), %.3f ms avg over %d launches, "
-                                   "%d useful flop/row x %d rows" % (kern_ms, args.steps,
-                                                                     useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 3), BATCH)},
+            "roofline": {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": train_tf / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(kname),
+                         "kernel": "%s (fused forward+backward): %d launches in the timed region, %.3f ms avg (15 of every 16 "
+                                   "on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch"
+                                   % (kname, n_train, train_ms / n_train, 3 * f1, N_ROWS)},
+            "roofline_kernels": {
+                "sample (k_mfma_flow inverse, prior drawn in-kernel)": {
+                    "bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": inv_ms / n_inv, "rows_per_launch": N_ROWS,
+                    "launches": n_inv, "where": "timed region"},
+                "log_prob (k_mfma_flow forward)": {
+                    "bound": "mfma", "achieved": fwd_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fwd_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": fwd_ms / n_fwd, "rows_per_launch": N_ROWS,
+                    "launches": n_fwd, "where": "after the timed region"}},
+            "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / n_inv * 1e-3),
+                                "note": "sample: kernel time only; fit: see ms_per_step minus the sampling launch"},
         }
+        out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / n_inv * 1e-3, 1e-9)
+        params = eng.params.detach().cpu().numpy()
         if not args.no_cpu_baseline:
-            params = eng.params.detach().cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(Xh, Ch, params)
             # second half of BASELINE.json's metric: per-row log-prob MAE of the HIP path against the
             # CPU restatement of the reference (float32 oracle, and its float64 referee) on the
@@ -266,6 +350,8 @@ def main():
                                   "vs_oracle_f64": float(np.abs(lp - lp64).mean()),
                                   "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
                                   "target": 1e-5}
+        if world == 1 and not force_dist and not args.no_api_level:
+            out["api_level"] = api_level(Xh, Ch, dev)
         print(json.dumps(out), flush=True)
     if dp:
         dist.barrier()                      # rank 0 may still be timing the CPU baseline

@@ -15,8 +15,8 @@
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call
  *     returns without synchronising; safe to capture into a hipGraph;
  *   - return value: 0 ok; <0 argument error (RNVP_E*); >0 a hipError_t;
- *   - no global mutable state other than one-time kernel attribute setup => thread-safe
- *     per stream.
+ *   - no global mutable state other than one-time kernel attribute setup (per device) and the
+ *     mutex-guarded event table of rnvp_profile_* => thread-safe per stream.
  *
  * Data layout
  *   x, z : [n, d] float32 row-major;  c : [n, cdim] float32 row-major (NULL iff cdim==0)
@@ -114,6 +114,28 @@ int rnvp_inverse(void *stream, const rnvp_shape *shape,
                  void *workspace, size_t workspace_bytes);
 
 /*
+ * Prior draw of NormalizingFlow.sample (nflow.py:141, `X = self.prior.sample((n,))`; the prior is
+ * MultivariateNormal(0, I), realnvp.py:189-191) as a counter-based stream: z_out[r][j] is a pure function
+ * of (seed, row_offset + r, j) -- Philox4x32-10 keyed by `seed`, counter (row, j / 4), Box-Muller -- so any
+ * split of the rows over calls, chunks or ranks (each passing its first global row as row_offset)
+ * reproduces the single-call draw bit for bit.  This is the build's 'device' prior; it is NOT the
+ * reference's CPU generator stream (the host supplies that one as `z` to rnvp_inverse).
+ *   z_out [n_rows, d]
+ */
+int rnvp_prior_normal(void *stream, uint64_t seed, int64_t row_offset, int64_t n_rows, int32_t d,
+                      float *z_out);
+
+/*
+ * rnvp_prior_normal fused into rnvp_inverse: x_out = g(z(seed, row_offset + r, .), c[r]) for the n_rows
+ * rows of this call; on the MFMA path z is drawn in registers and never written to memory.
+ * Replaces nflow.py:141-143 as a whole.  Same workspace as RNVP_OP_INVERSE.
+ */
+int rnvp_sample(void *stream, const rnvp_shape *shape,
+                const float *params, const uint8_t *masks, const float *c,
+                int64_t n_rows, uint64_t seed, int64_t row_offset, float *x_out,
+                void *workspace, size_t workspace_bytes);
+
+/*
  * loss = -(sum_rows logp) * inv_B and d(loss)/d(params) for one (shard of a) batch.
  * Replaces `loss = -nf.log_prob(X, C); opt.zero_grad(); loss.backward()`
  * (realnvp.py:246-250).  inv_B = 1 / (global batch size) so that shards from several GPUs
@@ -136,6 +158,18 @@ int rnvp_adam_step(void *stream, float *params, const float *grad,
                    float *exp_avg, float *exp_avg_sq, int64_t n_params,
                    double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step);
+
+/*
+ * Second half of a DATA-PARALLEL training step (the reference has no distributed code): after
+ * every rank's rnvp_loss_grad wrote its shard's gradient and loss share into one [P + 1] buffer and the caller
+ * all-reduced (SUM) that buffer over RCCL, this single launch reads the batch loss out of grad_loss[P] into
+ * loss_out[0] (the value realnvp.py:254 appends to loss_history) and applies rnvp_adam_step with
+ * grad_loss[0..P) -- identical arithmetic on every rank, so the replicas stay bit-identical.
+ */
+int rnvp_dp_finish_step(void *stream, float *params, const float *grad_loss,
+                        float *exp_avg, float *exp_avg_sq, int64_t n_params,
+                        double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int64_t step, float *loss_out);
 
 /*
  * rnvp_loss_grad followed by rnvp_adam_step on the same stream (single-GPU training step,
@@ -169,15 +203,20 @@ int rnvp_fit_epoch(void *stream, const rnvp_shape *shape,
                    int64_t first_step, void *workspace, size_t workspace_bytes);
 
 /*
- * Measurement aid (bench.py): while enabled, the DOMINANT kernel of each rnvp_loss_grad /
- * rnvp_train_step call (the fused forward+backward kernel) is bracketed by a pair of HIP events
- * recorded on the caller's stream.  rnvp_profile_read synchronises on them and returns the
- * number of bracketed launches and their summed duration in milliseconds, then resets.
- * At most `capacity` launches are bracketed between two reads (later ones run un-timed).
- * Not thread-safe; has no equivalent in the reference.
+ * Measurement aid (bench.py): while enabled, the hot kernel of each call -- the fused forward+backward
+ * kernel of rnvp_loss_grad / rnvp_train_step (RNVP_PROFILE_TRAIN), the stack kernel of
+ * rnvp_forward_logprob (RNVP_PROFILE_FORWARD) and of rnvp_inverse / rnvp_sample (RNVP_PROFILE_INVERSE) --
+ * is bracketed by a pair of HIP events recorded on the caller's stream.  rnvp_profile_read synchronises
+ * on the events of one kind and returns the number of bracketed launches and their summed duration in
+ * milliseconds, then resets that kind.  At most `capacity` launches per kind are bracketed between two
+ * reads (later ones run un-timed).  The event table is guarded by a mutex; has no equivalent in the
+ * reference.
  */
+#define RNVP_PROFILE_TRAIN   0
+#define RNVP_PROFILE_FORWARD 1
+#define RNVP_PROFILE_INVERSE 2
 int rnvp_profile_enable(int capacity);          /* capacity <= 0 disables and frees the events */
-int rnvp_profile_read(int *n_launches, float *total_ms);
+int rnvp_profile_read(int kind, int *n_launches, float *total_ms);
 
 #ifdef __cplusplus
 }

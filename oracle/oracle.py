@@ -137,6 +137,19 @@ class Oracle:
                                     C.c_int64(n), self._p(x))
         return x
 
+    # -- the build's counter-based prior (include/rnvp_hip.h rnvp_prior_normal) -------
+    def philox4x32_10(self, ctr, key):
+        c = (C.c_uint32 * 4)(*[int(v) for v in ctr]); k = (C.c_uint32 * 2)(*[int(v) for v in key])
+        out = (C.c_uint32 * 4)()
+        self.lib.rnvp_oracle_philox4x32_10(c, k, out)
+        return [int(v) for v in out]
+
+    def prior_normal(self, seed, row0, n, d):
+        z = np.empty((n, d), self.dtype)
+        self.lib.rnvp_oracle_prior_normal(C.c_uint64(int(seed)), C.c_int64(int(row0)), C.c_int64(int(n)),
+                                          C.c_int32(int(d)), self._p(z))
+        return z
+
     # -- loss + gradient, Adam ---------------------------------------------------
     def loss_grad(self, shape, params, x, c=None, masks=None, inv_B=None):
         """returns (loss, grad [P]) for loss = -mean log_prob (realnvp.py:246)."""

@@ -385,3 +385,45 @@ void rnvp_oracle_default_masks(int L, int d, uint8_t *masks) {
 }
 
 int rnvp_oracle_real_bytes(void) { return (int)sizeof(real); }
+
+/* ---- the build's counter-based 'device' prior (no counterpart in the reference, whose prior draw is
+ * torch's CPU generator: nflow.py:141) --------------------------------------------------------------------
+ * Restates include/rnvp_hip.h `rnvp_prior_normal`: Philox4x32-10 (Salmon et al., "Parallel random numbers:
+ * as easy as 1, 2, 3", SC'11; constants of the Random123 library) keyed by the seed, counter
+ * (row_lo, row_hi, j / 4, 0); words (0,1) and (2,3) of the output give two Box-Muller pairs = the normals of
+ * features 4*(j/4) .. +3.  Pinned by the published known-answer vectors (tests/test_oracle_golden.py).
+ * Box-Muller is evaluated in double and rounded, so the HIP kernels (float logf / sincospif) agree to ~1e-7. */
+void rnvp_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void box_muller_ref(uint32_t a, uint32_t b, real *z0, real *z1) {
+    const float u1 = (float)(a >> 9) * 1.1920928955078125e-07f + 5.9604644775390625e-08f;
+    const float f = (float)(b >> 8) * 5.9604644775390625e-08f;
+    const double rad = sqrt(-2.0 * log((double)u1)), ang = 6.283185307179586476925286766559 * (double)f;
+    *z0 = (real)(rad * cos(ang));
+    *z1 = (real)(rad * sin(ang));
+}
+
+void rnvp_oracle_prior_normal(uint64_t seed, int64_t row0, int64_t n, int32_t d, real *z) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int64_t r = 0; r < n; ++r) {
+        const uint64_t row = (uint64_t)(row0 + r);
+        for (int blk = 0; 4 * blk < d; ++blk) {
+            const uint32_t ctr[4] = {(uint32_t)row, (uint32_t)(row >> 32), (uint32_t)blk, 0u};
+            uint32_t w[4];
+            real v[4];
+            rnvp_oracle_philox4x32_10(ctr, key, w);
+            box_muller_ref(w[0], w[1], &v[0], &v[1]);
+            box_muller_ref(w[2], w[3], &v[2], &v[3]);
+            for (int e = 0; e < 4 && 4 * blk + e < d; ++e) z[r * d + 4 * blk + e] = v[e];
+        }
+    }
+}

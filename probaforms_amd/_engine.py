@@ -287,6 +287,18 @@ class FlowEngine:
         _hip.inverse(self.shape, self.params, self.masks, z, c, n, x, self.workspace(_hip.OP_INVERSE, n))
         return x
 
+    def sample(self, n, c, seed, row_offset=0, out=None):
+        """x[r] = g(z(seed, row_offset + r), c[r]) for r < n: the counter-based prior drawn inside the inverse
+        kernel (rnvp_sample); `out` [n, d] optional."""
+        self.sync_params()
+        n = int(n)
+        c = self._cond(c, n)
+        x = torch.empty(n, self.d, dtype=torch.float32, device=self.device) if out is None else out
+        if tuple(x.shape) != (n, self.d):
+            raise RuntimeError("out must have shape (%d, %d), got %s" % (n, self.d, tuple(x.shape)))
+        _hip.sample(self.shape, self.params, self.masks, c, n, seed, row_offset, x, self.workspace(_hip.OP_INVERSE, n))
+        return x
+
     def ensure_gbuf(self):
         if self.gbuf is None or self.gbuf.device != self.device:
             pad = (-(self.P + 1)) % 4
@@ -307,6 +319,14 @@ class FlowEngine:
         g = self.ensure_gbuf()
         _hip.adam_step(self.params, g[:self.P], opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], self.P,
                        lr, b1, b2, eps, wd, opt.step_count)
+
+    def finish_dp_step(self, opt, loss_out):
+        """data parallel, after the all-reduce of gbuf[:P+1]: batch loss -> loss_out[0:1] and Adam, one launch"""
+        lr, b1, b2, eps, wd = opt.hyper
+        opt.step_count += 1
+        g = self.ensure_gbuf()
+        _hip.dp_finish_step(self.params, g, opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], self.P,
+                            lr, b1, b2, eps, wd, opt.step_count, loss_out)
 
     def fit_epoch(self, opt, x, c, perm, batch_size, losses):
         """single-GPU: all batches of one epoch in ONE library call (rnvp_fit_epoch)"""
@@ -364,13 +384,27 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     n = X.shape[0]
     bounds = batch_bounds(n, batch_size)
     dev = engine.device
+    # the module parameters may have been re-allocated since the last call (nf.cpu(), .float(),
+    # load_state_dict(assign=True)): train what the modules hold now, not a stale flat buffer
+    old = engine.flat
+    if engine.sync_params() is not old and world > 1:
+        broadcast_(engine.flat, src=0)
     perms = PermutationPrefetcher(n, n_epochs)
-    if world > 1:
-        # every rank must walk rank 0's shuffle, whatever state its own generator is in (each rank still
-        # consumes its generator exactly like a single process would)
-        t = torch.tensor(perms.seeds, dtype=torch.int64, device=dev)
-        broadcast_(t, src=0)
-        perms.seeds = [int(v) for v in t.cpu()]
+    try:
+        if world > 1:
+            # every rank must walk rank 0's shuffle, whatever state its own generator is in (each rank still
+            # consumes its generator exactly like a single process would)
+            t = torch.tensor(perms.seeds, dtype=torch.int64, device=dev)
+            broadcast_(t, src=0)
+            perms.seeds = [int(v) for v in t.cpu()]
+        _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world)
+    finally:
+        perms.close()
+    return loss_history
+
+
+def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world):
+    dev = engine.device
     for epoch in range(n_epochs):
         perm = perms.get(epoch).to(dev, non_blocking=False)
         losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
@@ -381,11 +415,8 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
                 lo, hi = shard_bounds(s, e, rank, world)
                 g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
                 all_reduce_sum(g[:engine.P + 1])
-                losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
-                engine.adam(opt)
+                engine.finish_dp_step(opt, losses[k:k + 1])
         host = losses.cpu()
         loss_history.extend(host[i].clone() for i in range(host.numel()))
         if epoch_hook is not None:
             epoch_hook(epoch, float(host[-1]))
-    perms.close()
-    return loss_history

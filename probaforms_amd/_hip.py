@@ -13,6 +13,7 @@ import torch
 
 MAX_HIDDEN = 8
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
+PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -84,7 +85,7 @@ class HipLibraryMissing(RuntimeError):
 _lib = None
 _lock = threading.Lock()
 
-_VP, _I64, _F, _D, _SZ = C.c_void_p, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_VP, _I64, _U64, _F, _D, _SZ = C.c_void_p, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 _SP = C.POINTER(RnvpShape)
 
 _SIGNATURES = {
@@ -95,8 +96,11 @@ _SIGNATURES = {
     "rnvp_kernel_path": (C.c_int, [_SP, _VP, C.c_int]),
     "rnvp_forward_logprob": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_inverse": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
+    "rnvp_prior_normal": (C.c_int, [_VP, _U64, _I64, _I64, C.c_int32, _VP]),
+    "rnvp_sample": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _I64, _U64, _I64, _VP, _VP, _SZ]),
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
+    "rnvp_dp_finish_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64, _VP]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "rnvp_fit_epoch": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
@@ -109,7 +113,7 @@ _SIGNATURES = {
     "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
     "rnvp_profile_enable": (C.c_int, [C.c_int]),
-    "rnvp_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "rnvp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -170,10 +174,10 @@ def profile_enable(capacity):
     check(lib().rnvp_profile_enable(int(capacity)), "rnvp_profile_enable")
 
 
-def profile_read():
-    """-> (launches, total_ms) of the dominant kernel since the last read"""
+def profile_read(kind=PROFILE_TRAIN):
+    """-> (launches, total_ms) of the hot kernel of `kind` (PROFILE_*) since the last read"""
     n, ms = C.c_int(0), C.c_float(0.0)
-    check(lib().rnvp_profile_read(C.byref(n), C.byref(ms)), "rnvp_profile_read")
+    check(lib().rnvp_profile_read(int(kind), C.byref(n), C.byref(ms)), "rnvp_profile_read")
     return n.value, ms.value
 
 
@@ -205,6 +209,20 @@ def inverse(shape, params, masks, z, c, n_rows, x_out, ws):
         _ptr(x_out, torch.float32, "x_out"), wp, wn))
 
 
+def prior_normal(seed, row_offset, n_rows, d, z_out):
+    """z_out[r][j] = N(0,1)(seed, row_offset + r, j): the counter-based 'device' prior (rnvp_prior_normal)"""
+    _call("rnvp_prior_normal", (int(seed) & 0xFFFFFFFFFFFFFFFF, int(row_offset), int(n_rows), int(d),
+                                _ptr(z_out, torch.float32, "z_out")))
+
+
+def sample(shape, params, masks, c, n_rows, seed, row_offset, x_out, ws):
+    """prior draw fused into the inverse (rnvp_sample)"""
+    wp, wn = _ws(ws)
+    _call("rnvp_sample", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(c, torch.float32, "c"), int(n_rows), int(seed) & 0xFFFFFFFFFFFFFFFF, int(row_offset),
+        _ptr(x_out, torch.float32, "x_out"), wp, wn))
+
+
 def loss_grad(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out, ws):
     wp, wn = _ws(ws)
     _call("rnvp_loss_grad", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
@@ -217,6 +235,13 @@ def adam_step(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weigh
     _call("rnvp_adam_step", (_ptr(params, torch.float32, "params"), _ptr(grad, torch.float32, "grad"),
         _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), int(n),
         float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step)))
+
+
+def dp_finish_step(params, grad_loss, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, loss_out):
+    _call("rnvp_dp_finish_step", (_ptr(params, torch.float32, "params"), _ptr(grad_loss, torch.float32, "grad_loss"),
+        _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), int(n),
+        float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+        _ptr(loss_out, torch.float32, "loss_out")))
 
 
 def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, loss_out, exp_avg, exp_avg_sq,

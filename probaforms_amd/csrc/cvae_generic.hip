@@ -170,13 +170,9 @@ bool pick_tb(size_t fpr, int64_t n, int *TB, size_t *lds) {
     return false;
 }
 
-std::atomic<int> g_attr_train{0}, g_attr_enc{0}, g_attr_dec{0};
-template <typename K> int allow(K kern, std::atomic<int> &done) {
-    if (!done.load(std::memory_order_relaxed)) {
-        RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard));
-        done.store(1, std::memory_order_relaxed);
-    }
-    return RNVP_OK;
+std::atomic<uint64_t> g_attr_train{0}, g_attr_enc{0}, g_attr_dec{0};
+template <typename K> int allow(K kern, std::atomic<uint64_t> &done) {
+    return allow_big_lds(reinterpret_cast<const void *>(kern), (int)kLdsHard, done);
 }
 
 }  // namespace
@@ -246,7 +242,7 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, c
     const int G = (int)(ntiles < kMaxGridTrain ? ntiles : kMaxGridTrain);
     const int threads = TB < 64 ? 64 : TB;
     {
-        KernelTimer timer(st);
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
         hipLaunchKernelGGL(k_cvae_train, dim3(G), dim3(threads), lds, st, k, params, x, c, row_index, eps, n_rows, inv_B,
                            kl_weight, gpart, losspart, TB, TB + 1, grad_out ? 1 : 0);
     }

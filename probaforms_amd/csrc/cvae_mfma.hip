@@ -599,16 +599,15 @@ int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const fl
     float *losspart = reinterpret_cast<float *>(w);
     hipLaunchKernelGGL(k_pack, dim3((g.packed_floats + 255) / 256), dim3(256), 0, st, g, params, packed);
     RNVP_HIP_TRY(hipGetLastError());
-    static std::atomic<int> attr{0};
-    if (!attr.load(std::memory_order_relaxed)) {
-        RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvae_mfma),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr.store(1, std::memory_order_relaxed);
+    static std::atomic<uint64_t> attr{0};
+    {
+        const int arc = allow_big_lds(reinterpret_cast<const void *>(k_cvae_mfma), 160 * 1024, attr);
+        if (arc) return arc;
     }
     const int64_t rows_per_wg = (int64_t)kWaves * kR * 16, ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
     {
-        KernelTimer timer(st);
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
         hipLaunchKernelGGL(k_cvae_mfma, dim3(grid), dim3(kWaves * 64), lds_bytes(), st, g, packed, x, c, row_index, eps, n,
                            inv_B, klw, gpart, losspart, grad_out ? 1 : 0);
     }

@@ -11,7 +11,9 @@ namespace {
 
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-       int64_t n, AdamK a) {
+       int64_t n, AdamK a, const float *__restrict__ loss_in, float *__restrict__ loss_out) {
+    // data-parallel step: the all-reduced [gradient | loss] message also carries the batch loss; read it out here
+    if (loss_out && blockIdx.x == 0 && threadIdx.x == 0) loss_out[0] = loss_in[0];
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -50,7 +52,10 @@ AdamK make_adam(double lr, double beta1, double beta2, double eps, double wd, in
 }
 
 int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
-              double lr, double beta1, double beta2, double eps, double wd, int64_t step) {
+              double lr, double beta1, double beta2, double eps, double wd, int64_t step,
+              const float *loss_in, float *loss_out) {
+    if ((loss_in == nullptr) != (loss_out == nullptr)) return RNVP_EINVAL;
+    if (n == 0 && loss_out) return (int)hipMemcpyAsync(loss_out, loss_in, sizeof(float), hipMemcpyDeviceToDevice, st);
     if (n == 0) return RNVP_OK;
     if (!p || !g || !m || !v || n < 0 || step < 1) return RNVP_EINVAL;
     const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v;
@@ -60,7 +65,7 @@ int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int6
     int64_t blocks = ((n >> 2) + threads - 1) / threads;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(threads), 0, st, p, g, m, v, n, a);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(threads), 0, st, p, g, m, v, n, a, loss_in, loss_out);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }

@@ -1,6 +1,7 @@
 // rnvp_api.hip -- extern "C" entry points of librnvp_hip.so (declared in include/rnvp_hip.h)
 // and the dispatch between the kernel families.
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "rnvp_common.h"
@@ -16,22 +17,26 @@ bool bad_ptrs(const KShape &k, const float *params, const uint8_t *masks, const 
 
 }  // namespace
 
-// ---- rnvp_profile_*: event pairs around the dominant kernel ------------------------------------
+// ---- rnvp_profile_*: event pairs around the hot kernels ------------------------------------------
 namespace rnvp {
 namespace {
-std::vector<hipEvent_t> g_ev;      // start0, stop0, start1, stop1, ...
-int g_ev_used = 0;                 // pairs recorded since the last read
+constexpr int kKinds = 3;
+std::mutex g_ev_mu;
+std::vector<hipEvent_t> g_ev[kKinds];   // per kind: start0, stop0, start1, stop1, ...
+int g_ev_used[kKinds] = {0, 0, 0};      // pairs recorded since the last read
 }  // namespace
 
-KernelTimer::KernelTimer(hipStream_t s) : st(s), on(false) {
-    if (!g_ev.empty() && (size_t)(2 * g_ev_used + 1) < g_ev.size()) {
-        on = hipEventRecord(g_ev[2 * g_ev_used], st) == hipSuccess;
+KernelTimer::KernelTimer(hipStream_t s, int kind_) : st(s), kind(kind_), slot(-1) {
+    if (kind < 0 || kind >= kKinds) return;
+    std::lock_guard<std::mutex> lk(g_ev_mu);
+    if (!g_ev[kind].empty() && (size_t)(2 * g_ev_used[kind] + 1) < g_ev[kind].size()) {
+        if (hipEventRecord(g_ev[kind][2 * g_ev_used[kind]], st) == hipSuccess) slot = g_ev_used[kind]++;
     }
 }
 KernelTimer::~KernelTimer() {
-    if (on) {
-        (void)hipEventRecord(g_ev[2 * g_ev_used + 1], st);
-        ++g_ev_used;
+    if (slot >= 0) {
+        std::lock_guard<std::mutex> lk(g_ev_mu);
+        if ((size_t)(2 * slot + 1) < g_ev[kind].size()) (void)hipEventRecord(g_ev[kind][2 * slot + 1], st);
     }
 }
 }  // namespace rnvp
@@ -39,32 +44,37 @@ KernelTimer::~KernelTimer() {
 extern "C" {
 
 int rnvp_profile_enable(int capacity) {
-    for (hipEvent_t e : rnvp::g_ev) (void)hipEventDestroy(e);
-    rnvp::g_ev.clear();
-    rnvp::g_ev_used = 0;
-    for (int i = 0; i < 2 * capacity; ++i) {
-        hipEvent_t e;
-        RNVP_HIP_TRY(hipEventCreate(&e));
-        rnvp::g_ev.push_back(e);
+    std::lock_guard<std::mutex> lk(rnvp::g_ev_mu);
+    for (int kd = 0; kd < rnvp::kKinds; ++kd) {
+        for (hipEvent_t e : rnvp::g_ev[kd]) (void)hipEventDestroy(e);
+        rnvp::g_ev[kd].clear();
+        rnvp::g_ev_used[kd] = 0;
+        for (int i = 0; i < 2 * capacity; ++i) {
+            hipEvent_t e;
+            RNVP_HIP_TRY(hipEventCreate(&e));
+            rnvp::g_ev[kd].push_back(e);
+        }
     }
     return RNVP_OK;
 }
 
-int rnvp_profile_read(int *n_launches, float *total_ms) {
+int rnvp_profile_read(int kind, int *n_launches, float *total_ms) {
+    if (kind < 0 || kind >= rnvp::kKinds) return RNVP_EINVAL;
+    std::lock_guard<std::mutex> lk(rnvp::g_ev_mu);
     float tot = 0.f;
-    for (int i = 0; i < rnvp::g_ev_used; ++i) {
-        RNVP_HIP_TRY(hipEventSynchronize(rnvp::g_ev[2 * i + 1]));
+    for (int i = 0; i < rnvp::g_ev_used[kind]; ++i) {
+        RNVP_HIP_TRY(hipEventSynchronize(rnvp::g_ev[kind][2 * i + 1]));
         float ms = 0.f;
-        RNVP_HIP_TRY(hipEventElapsedTime(&ms, rnvp::g_ev[2 * i], rnvp::g_ev[2 * i + 1]));
+        RNVP_HIP_TRY(hipEventElapsedTime(&ms, rnvp::g_ev[kind][2 * i], rnvp::g_ev[kind][2 * i + 1]));
         tot += ms;
     }
-    if (n_launches) *n_launches = rnvp::g_ev_used;
+    if (n_launches) *n_launches = rnvp::g_ev_used[kind];
     if (total_ms) *total_ms = tot;
-    rnvp::g_ev_used = 0;
+    rnvp::g_ev_used[kind] = 0;
     return RNVP_OK;
 }
 
-int rnvp_version(void) { return 100; }
+int rnvp_version(void) { return 200; }
 
 const char *rnvp_status_string(int status) {
     switch (status) {
@@ -140,6 +150,31 @@ int rnvp_inverse(void *stream, const rnvp_shape *shape, const float *params, con
     return generic_inverse(static_cast<hipStream_t>(stream), k, params, masks, z, c, n_rows, x_out);
 }
 
+int rnvp_prior_normal(void *stream, uint64_t seed, int64_t row_offset, int64_t n_rows, int32_t d, float *z_out) {
+    if (n_rows < 0 || d < 1 || row_offset < 0) return RNVP_EINVAL;
+    if (n_rows == 0) return RNVP_OK;
+    if (!z_out) return RNVP_EINVAL;
+    return prior_normal(static_cast<hipStream_t>(stream), seed, row_offset, n_rows, d, z_out);
+}
+
+int rnvp_sample(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks, const float *c,
+                int64_t n_rows, uint64_t seed, int64_t row_offset, float *x_out, void *workspace,
+                size_t workspace_bytes) {
+    KShape k;
+    int rc = make_kshape(shape, &k);
+    if (rc) return rc;
+    if (n_rows < 0 || row_offset < 0) return RNVP_EINVAL;
+    if (n_rows == 0) return RNVP_OK;
+    if (!params || (!masks && !k.alt) || (k.c > 0 && !c) || !x_out) return RNVP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mfma::supported(k)) return mfma::sample(st, k, params, c, n_rows, seed, row_offset, x_out, workspace, workspace_bytes);
+    if (!masks) return RNVP_EINVAL;
+    // generic kernels: the same draws written to x_out, then the inverse in place
+    rc = prior_normal(st, seed, row_offset, n_rows, k.d, x_out);
+    if (rc) return rc;
+    return generic_inverse(st, k, params, masks, x_out, c, n_rows, x_out);
+}
+
 int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
                    const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
                    float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
@@ -168,6 +203,14 @@ int rnvp_adam_step(void *stream, float *params, const float *grad, float *exp_av
                    double weight_decay, int64_t step) {
     return adam_step(static_cast<hipStream_t>(stream), params, grad, exp_avg, exp_avg_sq, n_params, lr,
                      beta1, beta2, eps, weight_decay, step);
+}
+
+int rnvp_dp_finish_step(void *stream, float *params, const float *grad_loss, float *exp_avg, float *exp_avg_sq,
+                        int64_t n_params, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        int64_t step, float *loss_out) {
+    if (!grad_loss || !loss_out || n_params < 0) return RNVP_EINVAL;
+    return adam_step(static_cast<hipStream_t>(stream), params, grad_loss, exp_avg, exp_avg_sq, n_params, lr, beta1,
+                     beta2, eps, weight_decay, step, grad_loss + n_params, loss_out);
 }
 
 int rnvp_train_step(void *stream, const rnvp_shape *shape, float *params, const uint8_t *masks,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <cstring>
 
 #include "../../include/rnvp_hip.h"
@@ -114,13 +115,18 @@ AdamK make_adam(double lr, double beta1, double beta2, double eps, double wd, in
 
 // ---- optimizer: rnvp_adam.hip -----------------------------------------------------------
 int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
-              double lr, double beta1, double beta2, double eps, double wd, int64_t step);
+              double lr, double beta1, double beta2, double eps, double wd, int64_t step,
+              const float *loss_in = nullptr, float *loss_out = nullptr);
 
-// ---- optional event bracket around the dominant kernel (rnvp_profile_*, rnvp_api.hip) ------------
+// ---- prior draws: rnvp_prior.hip ------------------------------------------------------------
+int prior_normal(hipStream_t st, uint64_t seed, int64_t row0, int64_t n, int d, float *z);
+
+// ---- optional event bracket around the hot kernels (rnvp_profile_*, rnvp_api.hip) ---------------
+// kind: RNVP_PROFILE_TRAIN (fused forward+backward), _FORWARD (log-prob), _INVERSE (sampling)
 struct KernelTimer {
     hipStream_t st;
-    bool on;
-    explicit KernelTimer(hipStream_t s);   // records the start event if profiling is enabled
+    int kind, slot;
+    KernelTimer(hipStream_t s, int kind);  // records the start event if profiling is enabled
     ~KernelTimer();                        // records the stop event
 };
 
@@ -129,5 +135,18 @@ struct KernelTimer {
         hipError_t e__ = (expr);                   \
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device and per kernel): `done`
+// keeps one bit per device id of the calling thread's current device.
+inline int allow_big_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    RNVP_HIP_TRY(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev > 63 || !(done.load(std::memory_order_relaxed) & bit)) {
+        RNVP_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+    return RNVP_OK;
+}
 
 }  // namespace rnvp

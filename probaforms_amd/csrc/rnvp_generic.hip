@@ -276,16 +276,12 @@ bool pick_tiling(const KShape &k, int op, int64_t n, Tiling *tl) {
 }
 
 template <typename K>
-int allow_lds(K kernel, size_t bytes, std::atomic<size_t> &seen) {
-    if (bytes > 48 * 1024 && bytes > seen.load(std::memory_order_relaxed)) {
-        RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard));
-        seen.store(kLdsHard, std::memory_order_relaxed);
-    }
-    return RNVP_OK;
+int allow_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done) {
+    if (bytes <= 48 * 1024) return RNVP_OK;
+    return allow_big_lds(reinterpret_cast<const void *>(kernel), (int)kLdsHard, done);
 }
 
-std::atomic<size_t> g_lds_fwd{0}, g_lds_inv{0}, g_lds_train{0};
+std::atomic<uint64_t> g_lds_fwd{0}, g_lds_inv{0}, g_lds_train{0};
 
 int grid_for(int64_t n, int TB, int cap) {
     const int64_t ntiles = (n + TB - 1) / TB;
@@ -379,7 +375,7 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
     int rc = allow_lds(k_generic_train, tl.lds, g_lds_train);
     if (rc) return rc;
     {
-        KernelTimer timer(st);      // rnvp_profile_*: brackets exactly this launch when enabled
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
         hipLaunchKernelGGL(k_generic_train, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,
                            row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP);
     }

@@ -90,6 +90,8 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
             float *logp_sum, void *ws, size_t ws_bytes);
 int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c,
             int64_t n, float *x_out, void *ws, size_t ws_bytes);
+int sample(hipStream_t st, const KShape &k, const float *params, const float *c, int64_t n, uint64_t seed,
+           int64_t row0, float *x_out, void *ws, size_t ws_bytes);
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
               void *ws, size_t ws_bytes);

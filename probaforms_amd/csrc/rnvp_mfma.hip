@@ -4,6 +4,7 @@
 // 91-101,120-129; nflow.py:107-117,141-145) for d <= 64, cdim <= 16 (padded up to the tile
 // geometry), one hidden layer, tanh, and the reference's alternating masks.
 #include "rnvp_mfma_layer.h"
+#include "rnvp_prior.h"
 
 // amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE): with at most 256 registers per wave hipcc keeps MFMA
 // results in VGPRs (above that it allocates AGPRs and pays a v_accvgpr_read per value the VALU
@@ -141,16 +142,20 @@ k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
 // ---- whole stack: forward (+ log-det + prior) or inverse ---------------------------------------
 template <int NF, int CQ, int R, bool INVERSE, int ACT>
 __global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
-k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *x,
             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n,
-            float *out_x, float *logdet_out, float *logp_out, float *part) {
+            float *out_x, float *logdet_out, float *logp_out, float *part, uint64_t seed, int64_t row0) {
+    // x carries no __restrict__: the inverse may run in place (out_x == x, include/rnvp_hip.h).
+    // x == nullptr (inverse only): the rows are prior draws made here, z(seed, row0 + row, feature) of rnvp_prior.h.
     constexpr int D = 8 * NF, CD = 4 * CQ;               // padded sizes; g.d / g.c are the caller's
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, r = lane & 15;
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
-    const bool full = (g.d == D) && (g.c == CD);        // exact fit: vector row loads / stores
+    // exact fit and 16-byte aligned rows: vector row loads / stores; otherwise the guarded scalar path
+    const bool full = (g.d == D) && (g.c == CD) && (((uintptr_t)x | (uintptr_t)out_x) & 15) == 0;
+    const bool gen = INVERSE && x == nullptr;
     float wave_sum = 0.f;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
@@ -161,7 +166,18 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *__
             const int64_t row = base + rt * 16 + r;
             const bool valid = row < n;
             const int64_t src = valid ? (row_index ? row_index[row] : row) : 0;
-            load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
+            if (gen) {
+                load_row<NF, CQ, false>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
+#pragma unroll
+                for (int b = 0; b < 2 * NF / 4; ++b) {
+                    float z4[4];
+                    prior_normal4(seed, row0 + row, (q * 2 * NF) / 4 + b, z4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[rt][4 * b + e] = (q * 2 * NF + 4 * b + e < g.d) ? z4[e] : 0.f;
+                }
+            } else {
+                load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
+            }
             ld[rt] = 0.f;
         }
         for (int lp = 0; lp < L; ++lp) {
@@ -220,21 +236,24 @@ size_t packed_bytes(const KShape &k) {
 template <int NF, int CQ, bool INVERSE, int ACT, int R = RowTiles<NF, CQ>::value>
 int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
                 const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
-                float *logp_out, float *part, int *grid_out) {
+                float *logp_out, float *part, int *grid_out, uint64_t seed = 0, int64_t row0 = 0) {
     // Small calls: 4 row tiles per wave would leave CUs idle and one wave per SIMD; halve the tile
     // count so twice as many workgroups are in flight (measured on C2: 32768 rows 88 -> 63 us; from
     // 65536 rows up R = 4 wins).  A row's result does not depend on R.
     if constexpr (NF == 2 && R == 4) {
         if (n <= 32768)
             return launch_flow<NF, CQ, INVERSE, ACT, 2>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out,
-                                                   part, grid_out);
+                                                   part, grid_out, seed, row0);
     }
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
     *grid_out = grid;
-    hipLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE, ACT>), dim3(grid), dim3(kWaves * 64), 0, st, packed, g, k.L, k.alt, x,
-                       c, row_index, n, out_x, logdet_out, logp_out, part);
+    {
+        KernelTimer timer(st, INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
+        hipLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE, ACT>), dim3(grid), dim3(kWaves * 64), 0, st, packed, g, k.L, k.alt, x,
+                           c, row_index, n, out_x, logdet_out, logp_out, part, seed, row0);
+    }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }
@@ -242,14 +261,14 @@ int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pack
 template <bool INVERSE>
 int dispatch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
                   const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
-                  float *logp_out, float *part, int *grid_out) {
+                  float *logp_out, float *part, int *grid_out, uint64_t seed = 0, int64_t row0 = 0) {
 #define RNVP_CASE(nf, cq)                                                                                       \
     if (g.NF == nf && g.CQ == cq) {                                                                             \
         if (k.act == RNVP_ACT_TANH)                                                                             \
             return launch_flow<nf, cq, INVERSE, 0>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out, \
-                                                   part, grid_out);                                             \
+                                                   part, grid_out, seed, row0);                                 \
         return launch_flow<nf, cq, INVERSE, 1>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out,  \
-                                               part, grid_out);                                                 \
+                                               part, grid_out, seed, row0);                                     \
     }
     RNVP_CASE(2, 1) RNVP_CASE(2, 0) RNVP_CASE(4, 2) RNVP_CASE(8, 4)
 #undef RNVP_CASE
@@ -307,6 +326,19 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const float *z
     if (rc) return rc;
     int grid = 0;
     return dispatch_flow<true>(st, k, g, packed, z, c, nullptr, n, x_out, nullptr, nullptr, nullptr, &grid);
+}
+
+// prior draw fused into the inverse: x_out = g(z(seed, row0 + row, .), c); z is never written to memory
+int sample(hipStream_t st, const KShape &k, const float *params, const float *c, int64_t n, uint64_t seed,
+           int64_t row0, float *x_out, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
+    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    float *packed = static_cast<float *>(ws);
+    int rc = pack_weights(st, k, g, params, packed);
+    if (rc) return rc;
+    int grid = 0;
+    return dispatch_flow<true>(st, k, g, packed, nullptr, c, nullptr, n, x_out, nullptr, nullptr, nullptr, &grid, seed,
+                               row0);
 }
 
 }  // namespace mfma

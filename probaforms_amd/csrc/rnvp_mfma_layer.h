@@ -97,16 +97,19 @@ __device__ __forceinline__ gf4_ptr opaque(const float *p) {
 // Row I/O of lane group q: features q*2NF .. q*2NF + 2NF - 1 and conditions q*CQ .. q*CQ + CQ - 1.
 // `full` (sizes equal to the padded tile sizes): float4 loads, 1 KiB per wave; otherwise guarded scalar
 // loads that fill the padded slots with zeros.
-template <int NF, int CQ>
-__device__ __forceinline__ void load_row(const float *__restrict__ x, const float *__restrict__ c, int64_t src,
+// WITH_X = false loads the conditions only (the caller fills xr: prior draws made in the kernel).
+template <int NF, int CQ, bool WITH_X = true>
+__device__ __forceinline__ void load_row(const float *x, const float *__restrict__ c, int64_t src,
                                          int d, int cd, bool full, int q, float (&xr)[2 * NF],
                                          float (&cr)[CQ > 0 ? CQ : 1]) {
     if (full) {
-        const float *xp = x + src * (8 * NF) + q * 2 * NF;
+        if constexpr (WITH_X) {
+            const float *xp = x + src * (8 * NF) + q * 2 * NF;
 #pragma unroll
-        for (int v = 0; v < 2 * NF; v += 4) {
-            const f4 t = *reinterpret_cast<const f4 *>(xp + v);
-            xr[v] = t[0]; xr[v + 1] = t[1]; xr[v + 2] = t[2]; xr[v + 3] = t[3];
+            for (int v = 0; v < 2 * NF; v += 4) {
+                const f4 t = *reinterpret_cast<const f4 *>(xp + v);
+                xr[v] = t[0]; xr[v + 1] = t[1]; xr[v + 2] = t[2]; xr[v + 3] = t[3];
+            }
         }
         if (CQ > 0) {
             const float *cp = c + src * (4 * CQ) + q * CQ;
@@ -116,10 +119,12 @@ __device__ __forceinline__ void load_row(const float *__restrict__ x, const floa
             cr[0] = 0.f;
         }
     } else {
+        if constexpr (WITH_X) {
 #pragma unroll
-        for (int v = 0; v < 2 * NF; ++v) {
-            const int j = q * 2 * NF + v;
-            xr[v] = (j < d) ? x[src * d + j] : 0.f;
+            for (int v = 0; v < 2 * NF; ++v) {
+                const int j = q * 2 * NF + v;
+                xr[v] = (j < d) ? x[src * d + j] : 0.f;
+            }
         }
 #pragma unroll
         for (int v = 0; v < (CQ > 0 ? CQ : 1); ++v) {

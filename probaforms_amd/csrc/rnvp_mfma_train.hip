@@ -468,7 +468,7 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
-    const bool full = (g.d == D) && (g.c == CD);
+    const bool full = (g.d == D) && (g.c == CD) && ((uintptr_t)x & 15) == 0;     // else: guarded scalar row loads
     float *gp = gpart + (size_t)blockIdx.x * glayer_floats * L;
     float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + pw) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
@@ -680,14 +680,11 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
                     float *losspart, float *scratch, int grid, size_t lds_bytes) {
     auto kern = k_mfma_train<NF, CQ, R, NS, ACT>;
-    static std::atomic<int> attr_done{0};
-    if (!attr_done.load(std::memory_order_relaxed)) {
-        RNVP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done.store(1, std::memory_order_relaxed);
-    }
+    static std::atomic<uint64_t> attr_done{0};          // per kernel instance; one bit per device
+    const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
+    if (arc) return arc;
     {
-        KernelTimer timer(st);      // rnvp_profile_*: brackets exactly this launch when enabled
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, packed, g, k.L, k.alt, x, c,
                            row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
     }

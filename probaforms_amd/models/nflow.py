@@ -11,6 +11,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import _hip
 from .._engine import FlowEngine, default_device, require_hip
 
 DEVICE = default_device()
@@ -38,7 +39,13 @@ class StandardNormalPrior:
     ``MultivariateNormal(zeros(d), eye(d))`` (realnvp.py:189-191).  ``log_prob`` is the closed
     form -0.5 (d ln 2pi + |z|^2) and ``sample`` is ``randn`` on the global CPU generator -- both
     bit-equal to the reference's distribution object (tests/golden/prior.npz) --
-    which lets the kernels fold the prior term into the forward pass."""
+    which lets the kernels fold the prior term into the forward pass.
+
+    ``host_rng=False`` (RealNVP(prior_rng='device')) is the build's throughput option: a counter-based stream
+    (include/rnvp_hip.h rnvp_prior_normal) in which z[row][j] depends only on (seed, GLOBAL row, j).  One 63-bit
+    seed per draw comes from the global CPU generator (``torch.manual_seed`` still controls it); chunks and
+    ranks that pass their first global row reproduce the one-shot draw bit for bit, and the flow's inverse
+    kernel makes the draws in registers (rnvp_sample).  Not the reference's random stream."""
 
     def __init__(self, var_size, device, host_rng=True):
         self.var_size = int(var_size)
@@ -50,10 +57,21 @@ class StandardNormalPrior:
     def log_prob(self, z):
         return -0.5 * ((z * z).sum(-1) + self.var_size * math.log(2.0 * math.pi))
 
-    def sample(self, sample_shape=()):
+    @staticmethod
+    def next_seed():
+        """seed of one counter-based draw: a single int64 from the global CPU generator"""
+        return int(torch.empty((), dtype=torch.int64).random_().item())
+
+    def sample(self, sample_shape=(), *, seed=None, row_offset=0):
         shape = tuple(sample_shape) + (self.var_size,)
         if not self.host_rng:
-            return torch.randn(shape, device=self.device)  # throughput option: not the reference's stream
+            require_hip(self.device)
+            n = 1
+            for v in tuple(sample_shape):
+                n *= int(v)
+            z = torch.empty((n, self.var_size), dtype=torch.float32, device=self.device)
+            _hip.prior_normal(self.next_seed() if seed is None else seed, row_offset, n, self.var_size, z)
+            return z.reshape(shape)
         return torch.randn(shape).to(self.device)          # host generator: the reference's CPU stream
 
 
@@ -130,6 +148,8 @@ class NormalizingFlow(nn.Module):
         else:
             n = len(C)
             C = self._on_device(C, eng)
+        if self._fused_prior() and not self.prior.host_rng:
+            return eng.sample(n, C, self.prior.next_seed())       # prior drawn inside the inverse kernel
         z = self.prior.sample((n,))
         z = torch.as_tensor(z, dtype=torch.float32).to(eng.device).contiguous()
         return eng.inverse(z, C, out=z)
@@ -168,6 +188,7 @@ class NormalizingFlow(nn.Module):
         d = self.prior.var_size
         cdim = 0 if type(C) == type(1) else C.shape[1]
         host_rng = self.prior.host_rng
+        seed = None if host_rng else self.prior.next_seed()     # one counter-based stream for all chunks
         NB, cap = 3, rows + 15
         out = torch.empty((n, d), dtype=torch.float32, pin_memory=True)
         zdev = [torch.empty((cap, d), dtype=torch.float32, device=dev) for _ in range(NB)]
@@ -199,10 +220,11 @@ class NormalizingFlow(nn.Module):
                     cdev[i][:m].copy_(cpin[i][:m], non_blocking=True)
                 ev_in[i].record(h2d)
             cur.wait_event(ev_in[i])
-            if not host_rng:
-                zdev[i][:m].normal_()
             cc = None if cdim == 0 else (cdev[i][:m] if stage_c else Cd[lo:lo + m])
-            eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
+            if host_rng:
+                eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
+            else:
+                eng.sample(m, cc, seed, row_offset=lo, out=zdev[i][:m])   # chunk lo..lo+m of the one-shot draw
             ev_k[i].record(cur)
             d2h.wait_event(ev_k[i])
             with torch.cuda.stream(d2h):

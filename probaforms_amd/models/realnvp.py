@@ -208,7 +208,11 @@ class RealNVP(GenModel):
         'shard' -- this rank draws only its contiguous share of the rows and returns that block;
         'gather' -- shares are drawn per rank, then all-gathered: every rank returns all n rows.
         With the host prior the n x d normal draw is made in full on every rank (same generator state ->
-        same stream) and sliced, so the union of the shares is the single-process sample."""
+        same stream; torch's CPU generator cannot skip ahead) and sliced, so the union of the shares is the
+        single-process sample but the draw itself does not speed up with more ranks.  With
+        prior_rng='device' rank 0's seed is broadcast and each rank draws only its own rows of the
+        counter-based stream inside the inverse kernel: the shares concatenate to the single-process device
+        draw bit for bit, whatever the ranks' generator states -- use it for large sharded draws (C4)."""
         n = C if type(C) == type(1) else len(C)
         rank, world = dist_info()
         if distributed is not None and world > 1:
@@ -225,14 +229,18 @@ class RealNVP(GenModel):
         import torch.distributed as dist
         eng = self.nf.engine()
         lo, hi = shard_bounds(0, n, rank, world)
-        if isinstance(self.prior, StandardNormalPrior) and self.prior.host_rng:
-            z = torch.randn((n, self.prior.var_size))[lo:hi].to(eng.device).contiguous()     # the full reference stream, sliced
-        elif getattr(self.prior, "host_rng", True):
-            z = torch.as_tensor(self.prior.sample((n,)), dtype=torch.float32)[lo:hi].to(eng.device).contiguous()
-        else:
-            z = torch.as_tensor(self.prior.sample((hi - lo,)), dtype=torch.float32).to(eng.device).contiguous()
         Cl = None if type(C) == type(1) else _to_device_f32(C[lo:hi], eng.device)
-        x = eng.inverse(z, Cl, out=z) if hi > lo else z
+        if isinstance(self.prior, StandardNormalPrior) and not self.prior.host_rng:
+            # counter-based prior: every rank uses rank 0's seed and its own global rows
+            t = torch.tensor([self.prior.next_seed()], dtype=torch.int64, device=eng.device)
+            broadcast_(t, src=0)
+            x = eng.sample(hi - lo, Cl, int(t.item()), row_offset=lo)
+        else:
+            if isinstance(self.prior, StandardNormalPrior):
+                z = torch.randn((n, self.prior.var_size))[lo:hi].to(eng.device).contiguous()     # the full reference stream, sliced
+            else:
+                z = torch.as_tensor(self.prior.sample((n,)), dtype=torch.float32)[lo:hi].to(eng.device).contiguous()
+            x = eng.inverse(z, Cl, out=z) if hi > lo else z
         if not gather:
             return x.cpu().detach().numpy()
         # equal-size all_gather: pad every share to the largest one

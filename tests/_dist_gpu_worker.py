@@ -34,7 +34,15 @@ def main():
         smp[mode] = m.sample(C[:61], distributed=mode)
     torch.manual_seed(5)
     full61 = m.sample(C[:61])
-    np.savez(out + ".rank%d.npz" % rank, shard=smp["shard"], gather=smp["gather"], full=full61)
+    # counter-based device prior with the SAME seed on both ranks (the usual data-parallel convention): the shares
+    # must tile the single-process draw and contain no repeated rows
+    m.prior.host_rng = False
+    dev = {}
+    for mode in ("shard", "gather", "full"):
+        torch.manual_seed(5)
+        dev[mode] = m.sample(C[:61], distributed=mode) if mode != "full" else m.sample(C[:61])
+    np.savez(out + ".rank%d.npz" % rank, shard=smp["shard"], gather=smp["gather"], full=full61,
+             dev_shard=dev["shard"], dev_gather=dev["gather"], dev_full=dev["full"])
     if rank == 0:
         np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs)
     dist.barrier()

@@ -64,8 +64,20 @@ def _install_oracle_backend():
             train_step(shape, params, masks, x, c, perm[s0:s0 + rows], rows, 1.0 / rows, grad_buf, loss_hist[k:k + 1],
                        m, v, lr, b1, b2, eps, wd, first_step + k, ws)
 
+    def dp_finish_step(params, grad_loss, m, v, n, lr, b1, b2, eps, wd, step, loss_out):
+        loss_out[0] = float(grad_loss[n])
+        adam_step(params, grad_loss[:n], m, v, n, lr, b1, b2, eps, wd, step)
+
+    def prior_normal(seed, row_offset, n_rows, d, z_out):
+        z_out.copy_(torch.from_numpy(o.prior_normal(seed, row_offset, n_rows, d)))
+
+    def sample(shape, params, masks, c, n_rows, seed, row_offset, x_out, ws):
+        z = torch.empty(n_rows, shape.d)
+        prior_normal(seed, row_offset, n_rows, shape.d, z)
+        inverse(shape, params, masks, z, c, n_rows, x_out, ws)
+
     _hip.loss_grad, _hip.adam_step, _hip.train_step, _hip.inverse = loss_grad, adam_step, train_step, inverse
-    _hip.fit_epoch = fit_epoch
+    _hip.fit_epoch, _hip.dp_finish_step, _hip.prior_normal, _hip.sample = fit_epoch, dp_finish_step, prior_normal, sample
     _hip.workspace_bytes = lambda shape, op, rows: 16
     for mod in (_engine, nflow, realnvp):
         mod.require_hip = lambda device: None
@@ -93,6 +105,12 @@ def _fit(world_rank=None):
     for mode in (None, "shard", "gather"):
         torch.manual_seed(9)
         out[str(mode)] = m.sample(Cs, distributed=mode) if mode else m.sample(Cs)
+    # counter-based 'device' prior: ranks arrive with DIFFERENT generator states (rank 0's seed is broadcast) and
+    # each draws only its own global rows; the shares must still tile the single-process draw seeded like rank 0
+    m.prior.host_rng = False
+    for mode in (None, "shard", "gather"):
+        torch.manual_seed(9 if not world_rank else 77 + world_rank)
+        out["dev_" + str(mode)] = m.sample(Cs, distributed=mode) if mode else m.sample(Cs)
     return flat, hist, out
 
 
@@ -127,6 +145,13 @@ def test_two_ranks_match_single_process(tmp_path):
     assert r0["s_shard"].shape == (19, 4) and r1["s_shard"].shape == (18, 4)
     assert np.array_equal(np.concatenate([r0["s_shard"], r1["s_shard"]]), r0["s_None"])
     assert smp1["shard"].shape == (37, 4)                            # world size 1: the keyword changes nothing
+    # device prior: shares of the two ranks (seeded differently) tile the single-process draw, no duplicated rows
+    dev_full = r0["s_dev_None"]                                      # rank 0 drawing all rows alone (same weights)
+    shares = np.concatenate([r0["s_dev_shard"], r1["s_dev_shard"]])
+    assert np.array_equal(shares, dev_full) and np.array_equal(r1["s_dev_gather"], dev_full)
+    np.testing.assert_allclose(dev_full, smp1["dev_None"], atol=5e-3)   # single process: same draw, weights differ by summation order
+    assert len({row.tobytes() for row in shares}) == 37
+    assert np.abs(dev_full - r0["s_None"]).max() > 0.1               # and it is a different stream from the host prior
 
 
 def _single(q):

@@ -56,18 +56,37 @@ def test_two_ranks_on_hip_kernels_match_single_process(tmp_path):
     for s_ in (s0, s1):
         np.testing.assert_array_equal(s_["gather"], s_["full"])
     np.testing.assert_array_equal(np.concatenate([s0["shard"], s1["shard"]]), s0["full"])
+    # device prior, both ranks seeded alike: the shares tile the single-process device draw bit for bit; no row repeats
+    shares = np.concatenate([s0["dev_shard"], s1["dev_shard"]])
+    np.testing.assert_array_equal(shares, s0["dev_full"])
+    np.testing.assert_array_equal(s1["dev_gather"], s0["dev_full"])
+    assert len({row.tobytes() for row in shares}) == 61
+    assert not np.array_equal(s0["dev_shard"][:30], s1["dev_shard"])
 
 
 @pytest.mark.timeout(900)
-def test_bench_two_rank_path_prints_one_json_line():
-    r = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                {"BENCH_ONE_GPU": "1"})
+def test_bench_self_launches_two_ranks_and_prints_one_json_line():
+    """`python3 bench.py --gpus 2` with NO launcher (the driver's form): the script starts its own ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["global_batch"] == 2 * 65536 and j["roofline"]["frac"] > 0
+    assert len(j["roofline_kernels"]) == 2 and all(v["frac"] > 0 for v in j["roofline_kernels"].values())
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_an_external_launcher():
+    r = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                {"BENCH_ONE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
 
 
 @pytest.mark.timeout(900)
@@ -75,7 +94,7 @@ def test_bench_data_parallel_step_over_rccl_single_rank():
     """the N-rank step of bench.py with the real collective library: one rank, RCCL initialised, gradient
     all-reduce on RCCL's stream under the sampling kernel (BENCH_FORCE_DIST=1)"""
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])

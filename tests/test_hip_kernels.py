@@ -353,3 +353,160 @@ def test_calls_can_be_captured_in_a_hip_graph():
     graph.replay(); torch.cuda.synchronize()
     for a, b in zip(ref, cap):
         assert torch.equal(a, b)
+
+
+# ---- counter-based device prior (rnvp_prior_normal / rnvp_sample; nflow.py:141) ------------------------------
+@pytest.mark.parametrize("d", [1, 5, 16, 64, 80])
+def test_prior_normal_vs_oracle_and_row_offsets(d, oracle64):
+    from probaforms_amd import _hip
+    n, seed = 3001, 0x1234567890ABCDEF
+    z = torch.empty(n, d, device="cuda")
+    _hip.prior_normal(seed, 0, n, d, z)
+    want = oracle64.prior_normal(seed, 0, n, d)
+    assert np.abs(z.cpu().numpy() - want).max() < 2e-6            # same Philox words, Box-Muller to float rounding
+    part = torch.empty(1000, d, device="cuda")
+    _hip.prior_normal(seed, 2001, 1000, d, part)                  # rows 2001.. of the same stream: bit-identical
+    assert torch.equal(part, z[2001:])
+    big = torch.empty(7, d, device="cuda")
+    _hip.prior_normal(seed, (1 << 33) + 5, 7, d, big)             # 64-bit row counters
+    assert np.abs(big.cpu().numpy() - oracle64.prior_normal(seed, (1 << 33) + 5, 7, d)).max() < 2e-6
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "tm", "tm_nocond", "reg1d", "relu_mh"])
+def test_fused_sample_equals_prior_then_inverse(name, path, oracle32):
+    """rnvp_sample (prior drawn inside the inverse kernel) == rnvp_inverse(rnvp_prior_normal) bit for bit, for any
+    split of the rows; and matches the oracle's sample() on the oracle's own draw"""
+    from oracle import Shape
+    _hip, cs, shape, params, masks = _setup(name, path)
+    if path == "declared" and cs["wsrc"] != "torch" and len(cs["hidden"]) > 1:
+        pytest.skip("same kernels as the table path")
+    n, d, cdim, seed = 777, cs["d"], cs["c"], 99
+    rng = np.random.default_rng(5)
+    Cn = rng.standard_normal((n, cdim)).astype(np.float32) if cdim else None
+    c = _dev(Cn)
+    ws = _ws(_hip, shape, _hip.OP_INVERSE, n)
+    z = torch.empty(n, d, device="cuda")
+    _hip.prior_normal(seed, 0, n, d, z)
+    ref = torch.empty_like(z)
+    _hip.inverse(shape, params, masks, z, c, n, ref, ws)
+    x = torch.empty_like(z)
+    _hip.sample(shape, params, masks, c, n, seed, 0, x, ws)
+    assert torch.equal(x, ref)
+    lo = 300                                                       # two chunks with global row offsets
+    xa = torch.empty(lo, d, device="cuda"); xb = torch.empty(n - lo, d, device="cuda")
+    _hip.sample(shape, params, masks, None if c is None else c[:lo].contiguous(), lo, seed, 0, xa, ws)
+    _hip.sample(shape, params, masks, None if c is None else c[lo:].contiguous(), n - lo, seed, lo, xb, ws)
+    assert torch.equal(torch.cat([xa, xb]), ref)
+    so = Shape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
+    want = oracle32.sample(so, cs["params"], oracle32.prior_normal(seed, 0, n, d), Cn, cs["masks"])
+    err = np.abs(x.cpu().numpy() - want)
+    assert err.mean() < 5e-6 * max(1.0, np.abs(want).mean()), err.mean()
+
+
+# ---- user masks, wide shapes, run-to-run determinism (SURVEY 8(f) rank 4) -----------------------------------------
+def _rand_flow(L, d, c, hidden, act, seed, scale=0.3):
+    from probaforms_amd import _hip
+    sh = _hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=0)
+    rng = np.random.default_rng(seed)
+    P = _hip.param_count(sh)
+    return sh, (rng.uniform(-1, 1, P) * scale).astype(np.float32), rng
+
+
+@pytest.mark.parametrize("kind", ["blocks", "all_ones_layer", "random", "wide_d80_c20"])
+def test_user_masks_and_wide_shapes_vs_oracle(kind, oracle32, oracle64):
+    """RealNVPLayer(mask=...) accepts any {0,1} mask (realnvp.py:65-68): non-alternating tables, a layer whose mask is
+    all ones (identity, log-det 0), and d > 64 / cdim > 16 run on the generic kernels -- forward, inverse, gradient"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    if kind == "wide_d80_c20":
+        L, d, c, hidden, act, n = 3, 80, 20, (24,), "tanh", 301
+    else:
+        L, d, c, hidden, act, n = 4, 6, 2, (9,), "relu" if kind == "random" else "tanh", 203
+    sh, p, rng = _rand_flow(L, d, c, hidden, act, 11)
+    if kind == "blocks":
+        masks = np.array([[1, 1, 0, 0, 1, 0], [0, 0, 1, 1, 0, 1], [1, 0, 0, 0, 0, 1], [0, 1, 1, 1, 1, 0]], np.uint8)
+    elif kind == "all_ones_layer":
+        masks = np.array([[1, 0, 1, 0, 1, 0], [1, 1, 1, 1, 1, 1], [0, 1, 0, 1, 0, 1], [0, 0, 0, 0, 0, 0]], np.uint8)
+    elif kind == "random":
+        masks = rng.integers(0, 2, (L, d)).astype(np.uint8)
+    else:
+        masks = ((np.arange(d)[None] // 3 + np.arange(L)[:, None]) % 2).astype(np.uint8)
+    assert _hip.RnvpShape.classify_masks(masks) == 0
+    assert _hip.kernel_path(sh, masks, _hip.OP_TRAIN) == _hip.PATH_GENERIC
+    X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
+    so = Shape.make(L, d, c, hidden, act)
+    params, mk, x, cc = _dev(p), _dev(masks, torch.uint8), _dev(X), _dev(C)
+    z = torch.empty(n, d, device="cuda"); lp = torch.empty(n, device="cuda"); ld = torch.empty(n, device="cuda")
+    _hip.forward_logprob(sh, params, mk, x, cc, None, n, z, ld, lp, None, _ws(_hip, sh, _hip.OP_FORWARD, n))
+    z32, lp32, _ = oracle32.log_prob(so, p, X, C, masks)
+    _, lp64, _ = oracle64.log_prob(so, p, X, C, masks)
+    assert np.abs(z.cpu().numpy() - z32).max() < 2e-5
+    assert np.abs(lp.cpu().numpy() - lp64).mean() < max(3 * np.abs(lp32 - lp64).mean(), 1e-5)
+    xb = torch.empty_like(z)
+    _hip.inverse(sh, params, mk, z, cc, n, xb, _ws(_hip, sh, _hip.OP_INVERSE, n))
+    assert (xb - x).abs().max().item() < 2e-4
+    assert np.abs(xb.cpu().numpy() - oracle32.sample(so, p, z.cpu().numpy(), C, masks)).max() < 2e-5
+    P = p.size
+    g = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.loss_grad(sh, params, mk, x, cc, None, n, 1.0 / n, g, loss, _ws(_hip, sh, _hip.OP_TRAIN, n))
+    lo, go = Oracle64Grad(oracle64, so, p, X, C, masks)
+    assert abs(loss.item() - lo) < 1e-5 * max(1.0, abs(lo))
+    assert np.abs(g.cpu().numpy() - go).max() < 3e-6 * np.abs(go).max() + 1e-9
+    if kind == "all_ones_layer":     # nets of an identity layer get no gradient (exactly zero, as autograd gives)
+        npl = P // L
+        assert not g[npl:2 * npl].any().item()
+
+
+def Oracle64Grad(oracle64, so, p, X, C, masks):
+    lo, go = oracle64.loss_grad(so, p.astype(np.float64), X.astype(np.float64), C.astype(np.float64), masks)
+    return float(lo), np.asarray(go, dtype=np.float64)
+
+
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_train_step_is_bitwise_reproducible_at_bench_sizes(n):
+    """no float atomics anywhere: the same rnvp_train_step twice gives identical bits (C2 shape; 65 536 rows runs the
+    net-split kernel, 262 144 rows the four-wave one with several row groups per workgroup)"""
+    from probaforms_amd import _hip
+    L, d, c, hidden = 8, 16, 4, (128,)
+    shape = _hip.RnvpShape.make(L, d, c, hidden, "tanh", alt_masks=1)
+    P = _hip.param_count(shape)
+    g0 = torch.Generator(device="cuda").manual_seed(3)
+    p0 = (torch.rand(P, device="cuda", generator=g0) - 0.5) * 0.3
+    x = torch.randn(n, d, device="cuda", generator=g0); cc = torch.randn(n, c, device="cuda", generator=g0)
+    perm = torch.randperm(n, device="cuda", generator=g0)
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    outs = []
+    for _ in range(2):
+        p = p0.clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+        g = torch.empty(P, device="cuda"); loss = torch.empty(2, device="cuda")
+        for step in (1, 2):
+            _hip.train_step(shape, p, None, x, cc, perm, n, 1.0 / n, g, loss[step - 1:step], m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, ws)
+        outs.append((p, m, v, g, loss))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][4]).all()
+
+
+def test_unaligned_rows_take_the_guarded_path():
+    """x / out at an odd float offset (a contiguous view that is not 16-byte aligned) must not fault: the kernels
+    fall back to scalar row I/O and give the same values"""
+    _hip, cs, shape, params, masks = _setup("c2")
+    n, d = cs["X"].shape
+    x, c = _dev(cs["X"]), _dev(cs["C"])
+    buf = torch.zeros(n * d + 1, device="cuda"); xu = buf[1:].view(n, d); xu.copy_(x)
+    assert xu.data_ptr() % 16 == 4 and xu.is_contiguous()
+    z = torch.empty(n, d, device="cuda"); zu = torch.empty(n * d + 1, device="cuda")[1:].view(n, d)
+    ws = _ws(_hip, shape, _hip.OP_FORWARD, n)
+    _hip.forward_logprob(shape, params, masks, x, c, None, n, z, None, None, None, ws)
+    _hip.forward_logprob(shape, params, masks, xu, c, None, n, zu, None, None, None, ws)
+    assert torch.equal(z, zu)
+    back = torch.empty(n * d + 1, device="cuda")[1:].view(n, d)
+    _hip.inverse(shape, params, masks, zu, c, n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
+    assert (back - x).abs().max().item() < 1e-4
+    P = cs["params"].size
+    g1 = torch.empty(P, device="cuda"); g2 = torch.empty(P, device="cuda"); l1 = torch.empty(1, device="cuda"); l2 = torch.empty(1, device="cuda")
+    wt = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    _hip.loss_grad(shape, params, masks, x, c, None, n, 1.0 / n, g1, l1, wt)
+    _hip.loss_grad(shape, params, masks, xu, c, None, n, 1.0 / n, g2, l2, wt)
+    assert torch.equal(g1, g2) and torch.equal(l1, l2)

@@ -124,3 +124,22 @@ def test_prior_closed_form():
         z = f["logprob_in_d%d" % d]
         lp = -0.5 * (d * np.log(2 * np.pi) + (z.astype(np.float64) ** 2).sum(1))
         np.testing.assert_allclose(lp, f["logprob_out_d%d" % d], rtol=1e-6, atol=1e-6)
+
+
+def test_philox_known_answers_and_normal_moments(oracle32, oracle64):
+    """the oracle's restatement of the build's counter-based prior (include/rnvp_hip.h rnvp_prior_normal):
+    Philox4x32-10 against the published Random123 known-answer vectors; Box-Muller output moments; the
+    draw is a function of the GLOBAL row only (row offsets tile)."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert oracle32.philox4x32_10(ctr, key) == want
+    z = oracle64.prior_normal(1234, 0, 100000, 6)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3 and abs((z ** 3).mean()) < 2e-2
+    assert abs((z ** 4).mean() - 3) < 5e-2 and np.abs(np.corrcoef(z.T) - np.eye(6)).max() < 1e-2
+    a = oracle32.prior_normal(77, 0, 50, 5); b = oracle32.prior_normal(77, 20, 30, 5)
+    np.testing.assert_array_equal(a[20:], b)
+    assert not np.array_equal(oracle32.prior_normal(78, 0, 50, 5), a)
+    assert np.abs(oracle32.prior_normal(77, 0, 50, 5) - oracle64.prior_normal(77, 0, 50, 5)).max() < 1e-6
