@@ -150,6 +150,21 @@ int rnvp_loss_grad(void *stream, const rnvp_shape *shape,
                    void *workspace, size_t workspace_bytes);
 
 /*
+ * rnvp_loss_grad for a flow whose prior is NOT N(0, I): the reference trains whatever object the user put in
+ * `self.prior` (realnvp.py:189 builds the default only `if self.prior is None`; nflow.py:115 calls its log_prob).
+ * The caller evaluates the prior on z = f(x) (rnvp_forward_logprob) and passes
+ *   gz [n_rows, d] = d loss / d z = -inv_B * d prior.log_prob(z) / d z     (row r of the BATCH, not row_index[r]);
+ * this call seeds the hand-derived backward with it.  loss_out[0] = -(sum_rows log_det) * inv_B only: the caller
+ * adds -(sum_rows prior.log_prob(z)) * inv_B.  grad_out as rnvp_loss_grad.
+ */
+int rnvp_loss_grad_zseed(void *stream, const rnvp_shape *shape,
+                         const float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *row_index,
+                         int64_t n_rows, float inv_B, const float *gz,
+                         float *grad_out, float *loss_out,
+                         void *workspace, size_t workspace_bytes);
+
+/*
  * torch.optim.Adam step over the flat parameter buffer (realnvp.py:205-207,251):
  * betas/eps as given, amsgrad off, L2 weight decay folded into the gradient.
  * `step` is the 1-based step number of THIS update.

@@ -313,6 +313,25 @@ class FlowEngine:
                        g[:self.P], g[self.P:self.P + 1], ws)
         return g
 
+    def loss_grad_prior(self, prior, x, c, rows, n_rows, inv_B):
+        """loss_grad for a prior other than the fused N(0, I) (realnvp.py:189 keeps a user-assigned prior; nflow.py:115
+        calls its log_prob): z from the forward kernel, the prior's log-density and its gradient w.r.t. z from torch
+        autograd, then the hand-derived backward seeded with d loss / d z (rnvp_loss_grad_zseed)."""
+        g = self.ensure_gbuf()
+        if n_rows == 0:
+            g[:self.P + 1].zero_()
+            return g
+        z, _, _, _ = self.forward(x, c, rows=rows, want_z=True, want_logp=False)
+        z = z.detach().requires_grad_(True)
+        with torch.enable_grad():
+            lp_sum = prior.log_prob(z).sum()
+            (gz,) = torch.autograd.grad(-inv_B * lp_sum, z)
+        ws = self.workspace(_hip.OP_TRAIN, max(n_rows, 1))
+        _hip.loss_grad_zseed(self.shape, self.params, self.masks, x, c, rows, n_rows, inv_B, gz.contiguous().float(),
+                             g[:self.P], g[self.P:self.P + 1], ws)
+        g[self.P:self.P + 1] -= inv_B * lp_sum.detach().float()
+        return g
+
     def adam(self, opt):
         lr, b1, b2, eps, wd = opt.hyper
         opt.step_count += 1
@@ -370,7 +389,7 @@ def broadcast_(t, src=0):
     return t
 
 
-def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None):
+def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None, prior=None):
     """The batch loop of RealNVP.fit (realnvp.py:235-262) on device-resident X [n,d], C [n,c].
 
     Single GPU: one rnvp_fit_epoch call per epoch (a fused rnvp_train_step per batch, looped inside the
@@ -397,23 +416,32 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
             t = torch.tensor(perms.seeds, dtype=torch.int64, device=dev)
             broadcast_(t, src=0)
             perms.seeds = [int(v) for v in t.cpu()]
-        _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world)
+        _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world, prior)
     finally:
         perms.close()
     return loss_history
 
 
-def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world):
+def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world,
+                     prior=None):
+    """prior: None for the fused N(0, I); otherwise the user's prior object (log_prob differentiable by torch)"""
     dev = engine.device
     for epoch in range(n_epochs):
         perm = perms.get(epoch).to(dev, non_blocking=False)
         losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
-        if world == 1:
+        if world == 1 and prior is None:
             engine.fit_epoch(opt, X, C, perm, batch_size, losses)       # every batch, one library call
         else:
             for k, (s, e) in enumerate(bounds):
                 lo, hi = shard_bounds(s, e, rank, world)
-                g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+                if prior is None:
+                    g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+                else:
+                    g = engine.loss_grad_prior(prior, X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+                if world == 1:
+                    losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
+                    engine.adam(opt)
+                    continue
                 all_reduce_sum(g[:engine.P + 1])
                 engine.finish_dp_step(opt, losses[k:k + 1])
         host = losses.cpu()

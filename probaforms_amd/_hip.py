@@ -99,6 +99,7 @@ _SIGNATURES = {
     "rnvp_prior_normal": (C.c_int, [_VP, _U64, _I64, _I64, C.c_int32, _VP]),
     "rnvp_sample": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _I64, _U64, _I64, _VP, _VP, _SZ]),
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
+    "rnvp_loss_grad_zseed": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
     "rnvp_dp_finish_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64, _VP]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
@@ -228,6 +229,14 @@ def loss_grad(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_out, lo
     _call("rnvp_loss_grad", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
         _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
         int(n_rows), float(inv_B), _ptr(grad_out, torch.float32, "grad_out"),
+        _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
+
+
+def loss_grad_zseed(shape, params, masks, x, c, row_index, n_rows, inv_B, gz, grad_out, loss_out, ws):
+    wp, wn = _ws(ws)
+    _call("rnvp_loss_grad_zseed", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
+        int(n_rows), float(inv_B), _ptr(gz, torch.float32, "gz"), _ptr(grad_out, torch.float32, "grad_out"),
         _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
 
 

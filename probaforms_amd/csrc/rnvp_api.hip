@@ -175,9 +175,28 @@ int rnvp_sample(void *stream, const rnvp_shape *shape, const float *params, cons
     return generic_inverse(st, k, params, masks, x_out, c, n_rows, x_out);
 }
 
+static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
+                         const float *gz, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes);
+
 int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
                    const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
                    float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
+    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, nullptr, grad_out, loss_out,
+                         workspace, workspace_bytes);
+}
+
+int rnvp_loss_grad_zseed(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
+                         const float *gz, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
+    if (!gz && n_rows > 0) return RNVP_EINVAL;
+    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, gz, grad_out, loss_out,
+                         workspace, workspace_bytes);
+}
+
+static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
+                         const float *gz, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
     KShape k;
     int rc = make_kshape(shape, &k);
     if (rc) return rc;
@@ -192,10 +211,10 @@ int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, c
     if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
     if (mfma::train_supported(k))
         return mfma::loss_grad(st, k, params, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
-                               workspace_bytes);
+                               workspace_bytes, gz);
     if (!masks) return RNVP_EINVAL;
     return generic_loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out,
-                             workspace, workspace_bytes);
+                             workspace, workspace_bytes, gz);
 }
 
 int rnvp_adam_step(void *stream, float *params, const float *grad, float *exp_avg, float *exp_avg_sq,

@@ -66,7 +66,8 @@ int generic_inverse(hipStream_t st, const KShape &k, const float *params, const 
                     const float *z, const float *c, int64_t n, float *x_out);
 int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *row_index, int64_t n,
-                      float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes);
+                      float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
+                      const float *gz = nullptr);
 
 int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
                             float loss_scale, float *grad_out, float *loss_out);

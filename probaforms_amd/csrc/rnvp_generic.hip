@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256)
 k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__restrict__ masks,
                 const float *__restrict__ x, const float *__restrict__ c,
                 const int64_t *__restrict__ row_index, int64_t n, float inv_B,
-                float *gpart, float *losspart, float *xsave, int TB, int TBP) {
+                float *gpart, float *losspart, float *xsave, int TB, int TBP, const float *__restrict__ gz) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, d = s.d, cd = s.c, nthreads = blockDim.x;
     float *xcur = lds;
@@ -192,9 +192,10 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
             }
             float ss = 0.f;
             for (int j = 0; j < d; ++j) { const float zv = xcur[j * TBP + t]; ss = fmaf(zv, zv, ss); }
-            lp = ld + (-0.5f * ss - prior_c);
-            // seed: d(-mean logp)/dz = z / B   (zero for padding rows)
-            for (int j = 0; j < d; ++j) gy[j * TBP + t] = valid ? xcur[j * TBP + t] * inv_B : 0.f;
+            lp = gz ? ld : ld + (-0.5f * ss - prior_c);
+            // seed: d(-mean logp)/dz = z / B   (zero for padding rows); with gz the caller's d loss / d z (another prior)
+            for (int j = 0; j < d; ++j)
+                gy[j * TBP + t] = valid ? (gz ? gz[row * d + j] : xcur[j * TBP + t] * inv_B) : 0.f;
         }
         red[t] = valid ? lp : 0.f;
         __syncthreads();
@@ -360,7 +361,7 @@ int generic_inverse(hipStream_t st, const KShape &k, const float *params, const 
 
 int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *row_index, int64_t n,
-                      float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes) {
+                      float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes, const float *gz) {
     Tiling tl;
     if (!pick_tiling(k, RNVP_OP_TRAIN, n, &tl)) return RNVP_EUNSUPPORTED;
     if (!ws || ws_bytes < generic_workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
@@ -377,7 +378,7 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
         hipLaunchKernelGGL(k_generic_train, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,
-                           row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP);
+                           row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP, gz);
     }
     RNVP_HIP_TRY(hipGetLastError());
     const int rb = 256;

@@ -94,7 +94,7 @@ int sample(hipStream_t st, const KShape &k, const float *params, const float *c,
            int64_t row0, float *x_out, void *ws, size_t ws_bytes);
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes);
+              void *ws, size_t ws_bytes, const float *gz = nullptr);
 
 int train_step(hipStream_t st, const KShape &k, float *params, const float *x, const float *c,
                const int64_t *row_index, int64_t n, float inv_B, float *grad_buf, float *loss_out,

@@ -129,14 +129,22 @@ k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restr
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(1024)
 k_sum_partials(const float *__restrict__ part, int G, float scale, float *out) {
-    // one wave: lane i adds part[i], part[i + 64], ... in order, then a fixed butterfly: deterministic
-    const int lane = threadIdx.x;
+    // one workgroup, fixed order: thread t adds part[t], part[t + 1024], ...; wave butterflies; wave sums added in
+    // wave order by lane 0 -- deterministic (a single wave walking 8192 partials took 32 us of dependent loads)
+    __shared__ float wsum[16];
+    const int t = threadIdx.x;
     float a = 0.f;
-    for (int i = lane; i < G; i += 64) a += part[i];
+    for (int i = t; i < G; i += 1024) a += part[i];
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if (lane == 0) out[0] = a * scale;
+    if ((t & 63) == 0) wsum[t >> 6] = a;
+    __syncthreads();
+    if (t == 0) {
+        float r = 0.f;
+        for (int w = 0; w < 16; ++w) r += wsum[w];
+        out[0] = r * scale;
+    }
 }
 
 // ---- whole stack: forward (+ log-det + prior) or inverse ---------------------------------------
@@ -311,7 +319,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
                               logp_sum ? part : nullptr, &grid);
     if (rc) return rc;
     if (logp_sum) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, part, grid * kWaves, 1.0f, logp_sum);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, part, grid * kWaves, 1.0f, logp_sum);
         RNVP_HIP_TRY(hipGetLastError());
     }
     return RNVP_OK;

@@ -454,7 +454,9 @@ template <int NF, int CQ, int R, int NS, int ACT>
 __global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
-             float *gpart, float *losspart, float *scratch, int glayer_floats) {
+             float *gpart, float *losspart, float *scratch, int glayer_floats, const float *__restrict__ gz) {
+    // gz != nullptr (a prior other than N(0, I), rnvp_loss_grad_zseed): the backward is seeded with the caller's
+    // d loss / d z rows and the loss partial carries the log-det term only
     using DM = Dims<NF, CQ>;
     constexpr int D = 8 * NF, CD = 4 * CQ;
     constexpr int NW = kWaves * (1 + NS);                 // waves in the workgroup
@@ -511,14 +513,23 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             float l1 = ld[rt];
             l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
             ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-            const float lp = l1 + (-0.5f * ss - prior_c);
+            const float lp = gz ? l1 : l1 + (-0.5f * ss - prior_c);
             float v = (valid[rt] && q == 0) ? lp : 0.f;
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
             wave_sum += v;
             // seed of the backward: d(-mean logp)/dz = z / B; padding rows contribute nothing
             const float sc = valid[rt] ? inv_B : 0.f;
+            if (gz) {
+                const int64_t row = base + rt * 16 + r;
 #pragma unroll
-            for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
+                for (int u = 0; u < 2 * NF; ++u) {
+                    const int j = q * 2 * NF + u;
+                    gy[rt][u] = (valid[rt] && j < g.d) ? gz[row * g.d + j] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
+            }
             gld[rt] = -sc;
         }
         STAMP_ADD(stp.fwd, t0);
@@ -678,7 +689,7 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
 template <int NF, int CQ, int R, int NS, int ACT>
 int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                    float *losspart, float *scratch, int grid, size_t lds_bytes) {
+                    float *losspart, float *scratch, int grid, size_t lds_bytes, const float *gz) {
     auto kern = k_mfma_train<NF, CQ, R, NS, ACT>;
     static std::atomic<uint64_t> attr_done{0};          // per kernel instance; one bit per device
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
@@ -686,7 +697,7 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, packed, g, k.L, k.alt, x, c,
-                           row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats);
+                           row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -695,12 +706,12 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
 template <int NF, int CQ, int R, int NS>
 int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                    float *losspart, float *scratch, int grid, size_t lds_bytes) {
+                    float *losspart, float *scratch, int grid, size_t lds_bytes, const float *gz) {
     if (k.act == RNVP_ACT_TANH)
         return launch_train_act<NF, CQ, R, NS, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
-                                                  grid, lds_bytes);
+                                                  grid, lds_bytes, gz);
     return launch_train_act<NF, CQ, R, NS, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                              lds_bytes);
+                                              lds_bytes, gz);
 }
 
 #ifndef RNVP_NET_SPLIT
@@ -710,7 +721,7 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 template <int NF, int CQ, int R>
 int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                    const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                   float *losspart, float *scratch, int *grid_out) {
+                   float *losspart, float *scratch, int *grid_out, const float *gz) {
     using DM = Dims<NF, CQ>;
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
@@ -722,22 +733,22 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     const size_t lds_ns = (2 * kWaves * per_wave + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float);
     if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024)
         return launch_train_ns<NF, CQ, R, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
-                                             grid, lds_ns);
+                                             grid, lds_ns, gz);
     return launch_train_ns<NF, CQ, R, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                         kWaves * per_wave * sizeof(float));
+                                         kWaves * per_wave * sizeof(float), gz);
 }
 
 template <int NF, int CQ>
 int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                  const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                 float *losspart, float *scratch, int *grid_out) {
+                 float *losspart, float *scratch, int *grid_out, const float *gz) {
     constexpr int RMAX = TrainRows<NF, CQ>::value;
     const int R = pick_rows(RMAX, n);
 #define RNVP_ROWS(r)                                                                                              \
     if constexpr (RMAX >= r) {                                                                                    \
         if (R == r)                                                                                               \
             return launch_train_r<NF, CQ, r>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, \
-                                             grid_out);                                                           \
+                                             grid_out, gz);                                                       \
     }
     RNVP_ROWS(4) RNVP_ROWS(2) RNVP_ROWS(1)
 #undef RNVP_ROWS
@@ -769,7 +780,8 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
 
 static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
                           const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-                          void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
+                          void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam,
+                          const float *gz = nullptr) {
     if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     TrainPlan pl;
@@ -787,10 +799,10 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
     int grid = 0;
-    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
-    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
-    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
-    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid);
+    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
+    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
+    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
+    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
     const size_t P = (size_t)2 * k.npn * k.L;
@@ -814,9 +826,9 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes) {
+              void *ws, size_t ws_bytes, const float *gz) {
     return loss_grad_impl(st, k, params, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, nullptr,
-                          nullptr, nullptr, AdamK{});
+                          nullptr, nullptr, AdamK{}, gz);
 }
 
 // loss + gradient + Adam with the optimizer fused into the final scatter kernel (one launch and one

@@ -184,9 +184,9 @@ class RealNVP(GenModel):
         # the device (same round-to-nearest as the host cast, without a host-side pass over the data)
         Xd = _to_device_f32(X, eng.device)
         Cd = None if C is None else _to_device_f32(C, eng.device)
-        if not self.nf._fused_prior():
-            raise NotImplementedError("fit() fuses the N(0, I) prior into the loss kernel; custom priors are "
-                                      "supported for log_prob/sample only")
+        # a prior the user assigned before fit() is kept and trained against, as in the reference (realnvp.py:189-191):
+        # its log_prob / gradient come from torch, the flow's backward from the HIP kernel (rnvp_loss_grad_zseed)
+        prior = None if self.nf._fused_prior() else self.nf.prior
         eng._cond(Cd, Xd.shape[0])
         bar = None
         if self.verbose >= 1:
@@ -198,7 +198,7 @@ class RealNVP(GenModel):
                 bar.update(1)
                 bar.set_description("loss: %.4f" % last_loss)
 
-        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook)
+        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook, prior=prior)
         if bar is not None:
             bar.close()
 

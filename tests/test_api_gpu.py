@@ -204,3 +204,53 @@ def test_device_prior_sample_vs_oracle_draw(oracle32):
     z = nf.prior.sample((n,), seed=seed).cpu().numpy()            # the prior object alone: same stream
     assert np.abs(z - oracle32.prior_normal(seed, 0, n, d)).max() < 2e-6
     assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+
+
+def _eager_log_prob_terms(nf, X, C):
+    """plain PyTorch fp32 restatement of nflow.py:109-114 on the modules' own nn.Linear layers (autograd reference)"""
+    x, ld = X, torch.zeros(X.shape[0], device=X.device)
+    for layer in nf.layers:
+        mask = layer.mask.to(x.device).to(x.dtype)
+        xc = torch.cat([x * mask, C], dim=1) if C is not None else x * mask
+        T, S = layer.nn_t(xc), layer.nn_s(xc)
+        x = (x * torch.exp(S) + T) * (1 - mask) + x * mask
+        ld = ld + (S * (1 - mask)).sum(-1)
+    return x, ld
+
+
+@pytest.mark.parametrize("shape", [(5, 3, (12,)), (16, 4, (32,)), (6, 0, (7, 9))])
+def test_fit_with_user_assigned_prior(shape):
+    """a prior assigned before fit() is kept and trained against (realnvp.py:189-191; nflow.py:115): loss and gradient
+    of the z-seeded HIP backward equal torch autograd through the same modules; fit() runs and sample() draws from it"""
+    from torch.distributions import MultivariateNormal
+    from probaforms_amd.models import RealNVP
+    d, c, hidden = shape
+    n = 200
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    C = rng.standard_normal((n, c)).astype(np.float32) if c else None
+    prior = MultivariateNormal(torch.full((d,), 0.3, device="cuda"),
+                               covariance_matrix=torch.diag(torch.linspace(0.5, 2.0, d)).cuda())
+    torch.manual_seed(2)
+    m = RealNVP(n_layers=3, hidden=hidden, batch_size=64, n_epochs=2, lr=1e-2)
+    m.prior = prior
+    m.fit(X, C)
+    assert m.prior is prior and m.nf.prior is prior
+    assert len(m.loss_history) == 8 and all(np.isfinite(float(v)) for v in m.loss_history)
+    assert float(m.loss_history[-1]) < float(m.loss_history[0])
+    eng = m.nf.engine()
+    Xd = torch.from_numpy(X).cuda(); Cd = None if C is None else torch.from_numpy(C).cuda()
+    g = eng.loss_grad_prior(prior, Xd, Cd, None, n, 1.0 / n).clone()
+    for p in m.nf.parameters():
+        p.grad = None
+    z, ld = _eager_log_prob_terms(m.nf, Xd, Cd)
+    loss = -(ld + prior.log_prob(z)).mean()
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in m.nf.parameters()])
+    assert abs(g[eng.P].item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    assert (g[:eng.P] - ref).abs().max().item() < 5e-6 * ref.abs().max().item() + 1e-8
+    # the mean log-prob API and sampling use the same object
+    assert abs(float(m.nf.log_prob(Xd, Cd)) + loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    torch.manual_seed(3)
+    xs = m.sample(C if C is not None else 50)
+    assert xs.shape == ((n if C is not None else 50), d) and np.isfinite(xs).all()

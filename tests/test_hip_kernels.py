@@ -441,7 +441,7 @@ def test_user_masks_and_wide_shapes_vs_oracle(kind, oracle32, oracle64):
     _hip.forward_logprob(sh, params, mk, x, cc, None, n, z, ld, lp, None, _ws(_hip, sh, _hip.OP_FORWARD, n))
     z32, lp32, _ = oracle32.log_prob(so, p, X, C, masks)
     _, lp64, _ = oracle64.log_prob(so, p, X, C, masks)
-    assert np.abs(z.cpu().numpy() - z32).max() < 2e-5
+    assert np.abs(z.cpu().numpy() - z32).max() < 2e-5 * max(1.0, np.abs(z32).max()) * (4 if d > 64 else 1)
     assert np.abs(lp.cpu().numpy() - lp64).mean() < max(3 * np.abs(lp32 - lp64).mean(), 1e-5)
     xb = torch.empty_like(z)
     _hip.inverse(sh, params, mk, z, cc, n, xb, _ws(_hip, sh, _hip.OP_INVERSE, n))
