@@ -66,7 +66,15 @@ typedef struct rnvp_shape {
                                              from an odd layer, e.g. one RealNVPLayer on its own).
                                          1/2 let the library skip the masked-out (dead) columns and
                                          pick the MFMA path; the masks pointer is then not read.   */
+    int32_t precision;                /* RNVP_PREC_*: arithmetic of the first Linear of the s/t nets in the forward /
+                                         inverse / sampling kernels of the MFMA path (the reference computes in
+                                         float32 throughout, realnvp.py:226-228; both settings meet its 1e-5 bar) */
 } rnvp_shape;
+
+#define RNVP_PREC_AUTO 0         /* the faster of the two for the shape: BX3 for d > 16 (measured 1.3-1.4x), F32 else */
+#define RNVP_PREC_F32  1         /* f32-input MFMA (v_mfma_f32_16x16x4_f32): bitwise an fmaf chain          */
+#define RNVP_PREC_BX3  2         /* operands split into three bf16 terms, six bf16 MFMA products per pair:
+                                    float32-level accuracy (every dropped product < 2^-24), weights staged in LDS */
 
 /* operations, for rnvp_workspace_bytes */
 #define RNVP_OP_FORWARD  0

@@ -193,7 +193,7 @@ class FlowEngine:
     layers: list of RealNVPLayer with identical (var_size, cond_size, hidden, activation).
     """
 
-    def __init__(self, layers, device):
+    def __init__(self, layers, device, precision=None):
         require_hip(device)
         self.device = torch.device(device)
         l0 = layers[0]
@@ -202,7 +202,7 @@ class FlowEngine:
         for l in layers:
             if (l.var_size, l.cond_size, tuple(l.hidden), l.activation) != (self.d, self.c, self.hidden, self.activation):
                 raise ValueError("all coupling layers of a flow must share var_size, cond_size, hidden and activation")
-        self.shape = _hip.RnvpShape.make(self.L, self.d, self.c, self.hidden, self.activation)
+        self.shape = _hip.RnvpShape.make(self.L, self.d, self.c, self.hidden, self.activation, precision=precision)
         self.param_list = [p for l in layers for p in l.parameters()]
         self.P = sum(p.numel() for p in self.param_list)
         if self.P != _hip.param_count(self.shape):

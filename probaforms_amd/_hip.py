@@ -15,6 +15,11 @@ MAX_HIDDEN = 8
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA = 0, 1
+# arithmetic of the first Linear of the s/t nets in the forward / inverse / sampling kernels (rnvp_shape.precision):
+# 'f32' = f32-input MFMA; 'bx3' = three-term bf16 split, six products (float32-level accuracy, see rnvp_bx3.h)
+# 'auto' lets the library take the faster one for the shape (bx3 for d > 16)
+PRECISIONS = {"auto": 0, "f32": 1, "bx3": 2}
+DEFAULT_PRECISION = os.environ.get("RNVP_PRECISION", "auto")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RNVP_HIP_LIB lets a developer A/B an experimental build of the same C ABI (still a HIP library:
@@ -26,10 +31,10 @@ class RnvpShape(C.Structure):
     """mirror of `rnvp_shape` (include/rnvp_hip.h)"""
     _fields_ = [("L", C.c_int32), ("d", C.c_int32), ("c", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
-                ("act", C.c_int32), ("alt_masks", C.c_int32)]
+                ("act", C.c_int32), ("alt_masks", C.c_int32), ("precision", C.c_int32)]
 
     @classmethod
-    def make(cls, L, d, c, hidden, activation, alt_masks=0):
+    def make(cls, L, d, c, hidden, activation, alt_masks=0, precision=None):
         hidden = tuple(int(h) for h in hidden)
         if not 1 <= len(hidden) <= MAX_HIDDEN:
             raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
@@ -39,6 +44,7 @@ class RnvpShape(C.Structure):
             s.hidden[i] = h
         s.act = 0 if activation == "tanh" else 1     # anything else is ReLU, realnvp.py:32-37
         s.alt_masks = int(alt_masks)
+        s.precision = PRECISIONS[DEFAULT_PRECISION if precision is None else precision]
         return s
 
     @staticmethod

@@ -19,6 +19,7 @@ constexpr float kLog2Pi = 1.8378770664093453f;   // ln(2*pi)
 struct KShape {
     int L, d, c, nh, act;
     int alt;                           // rnvp_shape::alt_masks (0 arbitrary, 1/2 alternating)
+    int prec;                          // rnvp_shape::precision (RNVP_PREC_*)
     int nin[kMaxLin], nout[kMaxLin];   // Linear k: [nout, nin]
     int woff[kMaxLin], boff[kMaxLin];  // float offsets inside one net's parameter block
     int npn;                           // parameters per net
@@ -34,6 +35,8 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     k->act = (s->act == RNVP_ACT_TANH) ? RNVP_ACT_TANH : RNVP_ACT_RELU;
     if (s->alt_masks < 0 || s->alt_masks > 2) return RNVP_EINVAL;
     k->alt = s->alt_masks;
+    if (s->precision < RNVP_PREC_AUTO || s->precision > RNVP_PREC_BX3) return RNVP_EINVAL;
+    k->prec = s->precision == RNVP_PREC_AUTO ? (s->d > 16 ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;
     for (int i = 0; i <= s->n_hidden; ++i) {

@@ -3,6 +3,7 @@
 // loops of NormalizingFlow.log_prob / .sample (/root/reference/probaforms/models/realnvp.py:
 // 91-101,120-129; nflow.py:107-117,141-145) for d <= 64, cdim <= 16 (padded up to the tile
 // geometry), one hidden layer, tanh, and the reference's alternating masks.
+#include "rnvp_bx3.h"
 #include "rnvp_mfma_layer.h"
 #include "rnvp_prior.h"
 
@@ -300,9 +301,16 @@ bool supported(const KShape &k) {
     return pick_tiles(k.d, k.c, &NF, &CQ);       // d <= 64, cdim <= 16; everything else is padding
 }
 
+// forward / inverse: [packed weights of either kernel family | per-wave log-prob partials]
+static size_t flow_packed_bytes(const KShape &k) {
+    const size_t a = packed_bytes(k), b = bx3::packed_bytes(k);
+    return a > b ? a : b;
+}
+static_assert(kMaxGrid * kWaves >= bx3::kMaxGridBx3 * bx3::kWavesBx3, "partials buffer is sized for both kernel families");
+
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
     if (op == RNVP_OP_TRAIN) return train_workspace_bytes(k, max_rows);
-    return packed_bytes(k) + align_up((size_t)kMaxGrid * kWaves * sizeof(float), 256);
+    return flow_packed_bytes(k) + align_up((size_t)kMaxGrid * kWaves * sizeof(float), 256);
 }
 
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
@@ -311,15 +319,20 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_FORWARD, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     float *packed = static_cast<float *>(ws);
-    float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + packed_bytes(k));
-    int rc = pack_weights(st, k, g, params, packed);
-    if (rc) return rc;
-    int grid = 0;
-    rc = dispatch_flow<false>(st, k, g, packed, x, c, row_index, n, z_out, logdet_out, logp_out,
-                              logp_sum ? part : nullptr, &grid);
+    float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + flow_packed_bytes(k));
+    int grid = 0, waves = kWaves, rc;
+    if (k.prec == RNVP_PREC_BX3) {
+        waves = bx3::kWavesBx3;
+        rc = bx3::forward(st, k, params, x, c, row_index, n, z_out, logdet_out, logp_out, logp_sum ? part : nullptr, &grid, ws);
+    } else {
+        rc = pack_weights(st, k, g, params, packed);
+        if (rc) return rc;
+        rc = dispatch_flow<false>(st, k, g, packed, x, c, row_index, n, z_out, logdet_out, logp_out,
+                                  logp_sum ? part : nullptr, &grid);
+    }
     if (rc) return rc;
     if (logp_sum) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, part, grid * kWaves, 1.0f, logp_sum);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, part, grid * waves, 1.0f, logp_sum);
         RNVP_HIP_TRY(hipGetLastError());
     }
     return RNVP_OK;
@@ -328,6 +341,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
 int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c,
             int64_t n, float *x_out, void *ws, size_t ws_bytes) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
+    if (k.prec == RNVP_PREC_BX3) return bx3::inverse(st, k, params, z, c, n, x_out, 0, 0, ws);
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     float *packed = static_cast<float *>(ws);
     int rc = pack_weights(st, k, g, params, packed);
@@ -340,6 +354,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const float *z
 int sample(hipStream_t st, const KShape &k, const float *params, const float *c, int64_t n, uint64_t seed,
            int64_t row0, float *x_out, void *ws, size_t ws_bytes) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
+    if (k.prec == RNVP_PREC_BX3) return bx3::inverse(st, k, params, nullptr, c, n, x_out, seed, row0, ws);
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
     float *packed = static_cast<float *>(ws);
     int rc = pack_weights(st, k, g, params, packed);

@@ -95,10 +95,13 @@ class NormalizingFlow(nn.Module):
     log_prob_samples(X, C) -> [n] per-row log-density (build-only addition).
     """
 
-    def __init__(self, layers, prior):
+    def __init__(self, layers, prior, *, precision=None):
         super().__init__()
         self.layers = nn.ModuleList(layers)
         self.prior = prior
+        # build-only, keyword-only: arithmetic of the s/t nets' first Linear in the forward / inverse kernels --
+        # None / 'auto' (library picks per shape), 'f32', 'bx3' (_hip.PRECISIONS; both meet the 1e-5 parity bar)
+        self.precision = precision
         self._engine_obj = None
 
     # -- engine ------------------------------------------------------------------------------
@@ -112,7 +115,7 @@ class NormalizingFlow(nn.Module):
         require_hip(dev)
         if self._engine_obj is None or self._engine_obj.device != torch.device(dev) \
                 or len(self._engine_obj.layers) != len(self.layers):
-            self._engine_obj = FlowEngine(list(self.layers), dev)
+            self._engine_obj = FlowEngine(list(self.layers), dev, precision=self.precision)
         return self._engine_obj
 
     def _fused_prior(self):

@@ -18,12 +18,20 @@ def _dev(a, dtype=torch.float32):
 PATHS = ["declared", "table"]     # masks declared alternating (MFMA path where it applies) / read from the table (generic path)
 
 
+# "declared/bx3": same masks declaration, GEMM1 of the forward / inverse kernels on the split-bf16 path with
+# LDS-staged weights (rnvp_shape.precision = RNVP_PREC_BX3); "declared" pins RNVP_PREC_F32
+FLOW_PATHS = ["declared", "declared/bx3", "table"]
+
+
 def _setup(name, path="declared"):
     from probaforms_amd import _hip
     cs = load_case(name)
     alt = _hip.RnvpShape.classify_masks(cs["masks"])
     assert alt == 1
-    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=alt if path == "declared" else 0)
+    prec = "bx3" if path.endswith("/bx3") else "f32"
+    path = path.split("/")[0]
+    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=alt if path == "declared" else 0,
+                                precision=prec)
     assert _hip.param_count(shape) == cs["params"].size
     if path == "table":
         assert _hip.kernel_path(shape, cs["masks"], _hip.OP_TRAIN) == _hip.PATH_GENERIC
@@ -35,7 +43,7 @@ def _ws(_hip, shape, op, n):
     return torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", FLOW_PATHS)
 @pytest.mark.parametrize("name", ALL)
 def test_forward_vs_golden_and_oracle(name, path, oracle32, oracle64):
     from oracle import Shape
@@ -84,7 +92,7 @@ def test_single_layer_f_and_g(name, oracle32):
         np.testing.assert_allclose(y.cpu().numpy(), g["G3_layer_out"][k], rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", FLOW_PATHS)
 @pytest.mark.parametrize("name", ALL)
 def test_inverse_and_roundtrip(name, path):
     _hip, cs, shape, params, masks = _setup(name, path)
@@ -193,14 +201,15 @@ def test_adam_kernel_matches_oracle_bit_exact(oracle32):
         assert np.array_equal(pd.cpu().numpy(), p)
 
 
-def test_large_batch_properties():
-    """Size-independent checks at a benchmark-sized batch (C2 shape): round trip and the
-    log-prob identity logp == logdet - 0.5 (d ln 2pi + |z|^2), tiles spanning many blocks."""
+@pytest.mark.parametrize("name,prec", [("c2", "f32"), ("c2", "bx3"), ("c3", "bx3"), ("c4", "bx3"), ("c4", "f32")])
+def test_large_batch_properties(name, prec):
+    """Size-independent checks at a benchmark-sized batch: round trip and the log-prob identity
+    logp == logdet - 0.5 (d ln 2pi + |z|^2), tiles spanning many blocks (both kernel families of the MFMA path)."""
     from probaforms_amd import _hip
     from cases import numpy_params
-    L, d, c, hidden, act, _ = CASES["c2"]
-    shape = _hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=1)
-    params = _dev(numpy_params("c2")); masks = _dev(load_case("c2")["masks"], torch.uint8)
+    L, d, c, hidden, act, _ = CASES[name]
+    shape = _hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=1, precision=prec)
+    params = _dev(numpy_params(name)); masks = _dev(load_case(name)["masks"], torch.uint8)
     n = 200_003                                                    # ragged on purpose
     gen = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(n, d, device="cuda", generator=gen); cc = torch.randn(n, c, device="cuda", generator=gen)
@@ -208,11 +217,11 @@ def test_large_batch_properties():
     tot = torch.empty(1, device="cuda")
     _hip.forward_logprob(shape, params, masks, x, cc, None, n, z, ld, lp, tot, _ws(_hip, shape, _hip.OP_FORWARD, n))
     ident = ld - 0.5 * (d * np.log(2 * np.pi) + (z.double() ** 2).sum(1)).float()
-    assert (lp - ident).abs().max().item() < 2e-4
+    assert (lp - ident).abs().max().item() < 2e-4 * (d / 16)
     assert abs(tot.item() - lp.double().sum().item()) < 1e-5 * abs(lp.double().sum().item())
     back = torch.empty_like(x)
     _hip.inverse(shape, params, masks, z, cc, n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
-    assert (back - x).abs().max().item() < 5e-4 and (back - x).abs().mean().item() < 2e-6
+    assert (back - x).abs().max().item() < 5e-4 * (d / 16) and (back - x).abs().mean().item() < 2e-6 * (d / 16)
 
 
 def test_fused_train_step_equals_loss_grad_plus_adam():
@@ -235,16 +244,17 @@ def test_fused_train_step_equals_loss_grad_plus_adam():
             assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bx3"])
 @pytest.mark.parametrize("act", ["tanh", "relu"])
 @pytest.mark.parametrize("L,d,c,h,n", [(3, 16, 4, 48, 37), (1, 32, 8, 16, 5), (2, 64, 16, 32, 100), (5, 16, 0, 16, 1),
-                                       (3, 32, 8, 80, 300)])
-def test_mfma_path_edge_shapes_vs_oracle(L, d, c, h, n, act, oracle32):
+                                       (3, 32, 8, 80, 300), (2, 7, 3, 200, 129), (2, 40, 9, 144, 513), (3, 24, 5, 272, 70)])
+def test_mfma_path_edge_shapes_vs_oracle(L, d, c, h, n, act, prec, oracle32):
     """odd layer counts, hidden sizes that are not a multiple of the flush interval, ragged and tiny
     batches, gathered rows: MFMA kernels (forward, inverse, loss+grad) against the oracle"""
     from oracle import Shape
     from probaforms_amd import _hip
     rng = np.random.default_rng(L * 1000 + d + h)
-    shape = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1)
+    shape = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1, precision=prec)     # bx3: chunked stages (h = 144..272)
     assert _hip.kernel_path(shape, None, _hip.OP_TRAIN) == _hip.PATH_MFMA
     P = _hip.param_count(shape)
     params = (rng.uniform(-1, 1, size=P) * 0.12).astype(np.float32)      # ~ the default init range for these widths
@@ -372,15 +382,15 @@ def test_prior_normal_vs_oracle_and_row_offsets(d, oracle64):
     assert np.abs(big.cpu().numpy() - oracle64.prior_normal(seed, (1 << 33) + 5, 7, d)).max() < 2e-6
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", FLOW_PATHS)
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "tm", "tm_nocond", "reg1d", "relu_mh"])
 def test_fused_sample_equals_prior_then_inverse(name, path, oracle32):
     """rnvp_sample (prior drawn inside the inverse kernel) == rnvp_inverse(rnvp_prior_normal) bit for bit, for any
     split of the rows; and matches the oracle's sample() on the oracle's own draw"""
     from oracle import Shape
     _hip, cs, shape, params, masks = _setup(name, path)
-    if path == "declared" and cs["wsrc"] != "torch" and len(cs["hidden"]) > 1:
-        pytest.skip("same kernels as the table path")
+    if path != "table" and len(cs["hidden"]) > 1:
+        pytest.skip("several hidden layers: same (generic) kernels as the table path")
     n, d, cdim, seed = 777, cs["d"], cs["c"], 99
     rng = np.random.default_rng(5)
     Cn = rng.standard_normal((n, cdim)).astype(np.float32) if cdim else None
