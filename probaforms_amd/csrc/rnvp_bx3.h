@@ -7,8 +7,11 @@
 //   * the weights of one (layer, net, chunk of hidden tiles) STAGED IN LDS once per workgroup by LDS-DMA
 //     (global_load_lds_dwordx4, double buffered) and read from there by all 8 waves, instead of every wave
 //     streaming its own fragments through the 64 B/clk vector L1.
-// The second Linear (hidden -> s/t) keeps the f32 MFMA forms of rnvp_mfma_layer.h: its B operand is the tanh
-// output of this very tile, and splitting that on the fly costs the VALU what the matrix pipe would save.
+// The second Linear (hidden -> s/t) keeps the f32 MFMA forms of rnvp_mfma_layer.h: its B operand is the tanh output
+// of this very tile, and splitting that on the fly costs the VALU what the matrix pipe would save.  Measured with
+// GEMM2 on the same six-product scheme (g2b, RNVP_BX3_G2B_MIN_NF; kept as a build switch): C4 2.51 -> 2.35-2.46 ms
+// per 1M rows but log-prob MAE vs float64 9e-6 -> 1.6e-5 (the activations' third term is truncated); C3 slower.
+// Not worth the accuracy margin: off.
 //
 // K slots of GEMM1 (both operands): input value k of lane group q (k < NF: conditioning feature slot k;
 // k >= NF: condition k - NF) owns dwords 3k .. 3k+2 of the lane's slot list, each dword two bf16 slots:
@@ -26,7 +29,9 @@ struct Geo3 {
     int d, c, h;
     int NF, CQ, HT, KS1;
     int NI;        // 16x16x32 MFMAs per GEMM1 tile
-    int NA2;       // f4 fragments of GEMM2 per hidden tile (2 for the 4x4x1 form at NF == 2, else OTL)
+    int NA2;       // f4 fragments of GEMM2 per hidden tile (2 for the 4x4x1 form at NF == 2; OTL f32 fragments, or
+                   // 3 * OTL split-bf16 ones where the second Linear runs on bf16 MFMA too: g2b)
+    int g2b;       // second Linear on split-bf16 MFMA (wide outputs: the f32 MFMA time exceeds the split's VALU time)
     int NT2;       // out tiles (as mfma::Geo)
     int TC;        // hidden tiles per stage
     int NCH;       // stages per net: ceil(HT / TC)
@@ -35,6 +40,11 @@ struct Geo3 {
     int NP;        // 1 KiB pieces per stage (SD / 256)
     int b2_floats; // per layer: NT2 * 16
 };
+
+#ifndef RNVP_BX3_G2B_MIN_NF
+#define RNVP_BX3_G2B_MIN_NF 1000
+#endif
+__host__ __device__ constexpr bool g2b_for(int NF) { return NF >= RNVP_BX3_G2B_MIN_NF; }
 
 __host__ __device__ inline Geo3 make_geo3(int d, int c, int h) {
     Geo3 g;
@@ -45,7 +55,8 @@ __host__ __device__ inline Geo3 make_geo3(int d, int c, int h) {
     g.KS1 = g.NF + g.CQ;
     g.NI = (3 * g.KS1 + 3) / 4;
     const int OTL = g.NF >= 4 ? g.NF / 4 : 1;
-    g.NA2 = g.NF == 2 ? 2 : OTL;
+    g.g2b = g2b_for(g.NF);
+    g.NA2 = g.NF == 2 ? 2 : (g.g2b ? 3 * OTL : OTL);
     g.NT2 = g.NF >= 4 ? 2 * OTL : 1;
     g.tile_dw = (g.NI + g.NA2) * 256;
     int tc = 8;

@@ -81,6 +81,17 @@ k_pack_bx3(KShape k, Geo3 g, const float *__restrict__ params, uint32_t *__restr
                     split3_rne(sc * pn[k.woff[0] + hid * nin + col], a1, a2, a3);
                     out = p == 0 ? (a1 | (a1 << 16)) : (p == 1 ? (a2 | (a1 << 16)) : (a2 | (a3 << 16)));
                 }
+            } else if (g.g2b) {                              // GEMM2 fragments, split bf16: [otl][3][lane][4 dwords]
+                const int j = o2 - g.NI * 256;
+                const int fi = j >> 8, lane = (j & 255) >> 2, e = j & 3;
+                const int otl = fi / 3, D = 4 * (fi % 3) + e, v = D / 3, p = D % 3;
+                const int q = lane >> 4, i = lane & 15, hid = 16 * tile + 4 * q + v;
+                const int feat = mfma::feat_trans(NF, i >> 2, 4 * otl + (i & 3), pc);
+                if (tile < g.HT && hid < h && feat < k.d) {
+                    uint32_t a1, a2, a3;
+                    split3_rne(pn[k.woff[1] + feat * h + hid], a1, a2, a3);
+                    out = p == 0 ? (a1 | (a1 << 16)) : (p == 1 ? (a2 | (a1 << 16)) : (a2 | (a3 << 16)));
+                }
             } else {                                         // GEMM2 fragments (f32), as rnvp_mfma.hip packs them
                 const int j = o2 - g.NI * 256;
                 const int ai = j >> 8, lane = (j & 255) >> 2, rho = j & 3;
@@ -111,9 +122,31 @@ template <int NF, int CQ> struct D3 {
     static constexpr int KS1 = NF + CQ;
     static constexpr int NI = (3 * KS1 + 3) / 4;
     static constexpr int OTL = NF >= 4 ? NF / 4 : 1;
-    static constexpr int NA2 = NF == 2 ? 2 : OTL;
+    static constexpr bool G2B = g2b_for(NF);
+    static constexpr int NA2 = NF == 2 ? 2 : (G2B ? 3 * OTL : OTL);
     static constexpr int NT2 = NF >= 4 ? 2 * OTL : 1;
 };
+
+// the three bf16 terms of an accumulator (4 values) as the B fragments of the next MFMA: value v owns dwords
+// 3v .. 3v+2 = (b1, b2), (b1, b3), (b2, b1), the slot order of rnvp_bx3.h
+__device__ __forceinline__ void split_acc(f4 hv, f4 (&fr)[3]) {
+    uint32_t dw[12];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const uint32_t u = __float_as_uint(hv[v]);
+        const float r1 = hv[v] - __uint_as_float(u & 0xffff0000u);
+        const uint32_t u1 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        const uint32_t u2 = __float_as_uint(r2);
+        dw[3 * v + 0] = __builtin_amdgcn_perm(u1, u, 0x07060302u);
+        dw[3 * v + 1] = __builtin_amdgcn_perm(u2, u, 0x07060302u);
+        dw[3 * v + 2] = __builtin_amdgcn_perm(u, u1, 0x07060302u);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        fr[i] = f4{__uint_as_float(dw[4 * i]), __uint_as_float(dw[4 * i + 1]), __uint_as_float(dw[4 * i + 2]),
+                   __uint_as_float(dw[4 * i + 3])};
+}
 
 // B operand of GEMM1 for the whole layer: the three bf16 terms of every input value, in the slot order of rnvp_bx3.h
 template <int NF, int CQ, int PC, int R>
@@ -132,7 +165,8 @@ __device__ __forceinline__ void build_bin(const float (&xr)[R][2 * NF], const fl
             const float r1 = v - __uint_as_float(u & 0xffff0000u);
             const uint32_t u1 = __float_as_uint(r1);
             const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-            const uint32_t u2 = __float_as_uint(r2);
+            uint32_t u2 = __float_as_uint(r2);
+            u2 += 0x7fffu + ((u2 >> 16) & 1u);                                // third term rounded to nearest-even
             dw[3 * kk + 0] = __builtin_amdgcn_perm(u1, u, 0x07060302u);      // (b1, b2)
             dw[3 * kk + 1] = __builtin_amdgcn_perm(u2, u, 0x07060302u);      // (b1, b3)
             dw[3 * kk + 2] = __builtin_amdgcn_perm(u, u1, 0x07060302u);      // (b2, b1)
@@ -167,6 +201,7 @@ __device__ __forceinline__ void run_stage(const uint32_t *sb, const Geo3 &g, int
         for (int i = 1; i < NI; ++i) acc = mfma32(a[i], bin[rt][i], acc);
         return acc;
     };
+    static_assert(!D::G2B || NI > kPipeMaxNI, "the split-bf16 GEMM2 lives in the read-before-use loop");
     if constexpr (NI > kPipeMaxNI) {
         // wide inputs (many GEMM1 fragments per tile): holding two pipeline states in registers would spill; read each
         // tile's fragments from LDS right before use and let the SIMD's other wave cover the latency
@@ -183,13 +218,26 @@ __device__ __forceinline__ void run_stage(const uint32_t *sb, const Geo3 &g, int
             f4 a2c[NA2];
 #pragma unroll
             for (int o = 0; o < NA2; ++o) a2c[o] = lds_f4(pT + t * tdw + (NI + o) * 256);
+            if constexpr (D::G2B) {
 #pragma unroll
-            for (int o = 0; o < OTL; ++o)
+                for (int rt = 0; rt < R; ++rt) {
+                    f4 hb[3];
+                    split_acc(hv[rt], hb);
 #pragma unroll
-                for (int rho = 0; rho < 4; ++rho)
+                    for (int o = 0; o < OTL; ++o)
 #pragma unroll
-                    for (int rt = 0; rt < R; ++rt)
-                        out[rt][NET * OTL + o] = mfma::mfma16(a2c[o][rho], hv[rt][rho], out[rt][NET * OTL + o]);
+                        for (int i3 = 0; i3 < 3; ++i3)
+                            out[rt][NET * OTL + o] = mfma32(a2c[3 * o + i3], hb[i3], out[rt][NET * OTL + o]);
+                }
+            } else {
+#pragma unroll
+                for (int o = 0; o < OTL; ++o)
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                        for (int rt = 0; rt < R; ++rt)
+                            out[rt][NET * OTL + o] = mfma::mfma16(a2c[o][rho], hv[rt][rho], out[rt][NET * OTL + o]);
+            }
         }
         return;
     }

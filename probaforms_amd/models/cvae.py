@@ -109,6 +109,13 @@ class Decoder(nn.Module):
         return out
 
 
+def _rank0(t):
+    """under torch.distributed: rank 0's tensor on every rank (in place); otherwise t"""
+    if dist_info()[1] > 1:
+        broadcast_(t, 0)
+    return t
+
+
 class CVAE(GenModel):
     """Conditional VAE with the reference's interface (cvae.py:116-291).
 
@@ -150,7 +157,7 @@ class CVAE(GenModel):
         core = self._core
         x, c = _dev(x_batch, core.device), _dev(cond_batch, core.device)
         n = x.shape[0]
-        eps = torch.randn(n, self.lat_size).to(core.device)                       # cvae.py:187 (CPU generator)
+        eps = _rank0(torch.randn(n, self.lat_size).to(core.device))               # cvae.py:187 (CPU generator)
         loss = torch.zeros(1, device=core.device)
         _hip.cvae_loss_grad(core.shape, core.sync(), x, c, None, eps, n, 1.0 / n, self.KL_weight, None, loss,
                             core.workspace(n))
@@ -172,10 +179,12 @@ class CVAE(GenModel):
             from tqdm.auto import tqdm
             bar = tqdm(total=self.n_epochs, unit='epoch')
         for epoch in range(self.n_epochs):
-            perm = loader_permutation(n).to(dev)                                   # DataLoader(shuffle=True), cvae.py:235
+            # data parallel: every rank consumes its own generator like a single process would, but walks rank 0's
+            # shuffle and noise (broadcast), so the shards tile ONE permutation and the run equals rank 0's run
+            perm = _rank0(loader_permutation(n).to(dev))                           # DataLoader(shuffle=True), cvae.py:235
             for (s, e) in bounds:
                 B = e - s
-                eps = torch.randn(B, self.lat_size).to(dev)                        # sample_z, cvae.py:187
+                eps = _rank0(torch.randn(B, self.lat_size).to(dev))                # sample_z, cvae.py:187
                 g = core.grads()
                 lo, hi = (s, e) if world == 1 else shard_bounds(s, e, rank, world)
                 _hip.cvae_loss_grad(core.shape, core.sync(), Xd, Cd, perm[lo:hi], eps[lo - s:hi - s], hi - lo,

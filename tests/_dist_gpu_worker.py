@@ -43,8 +43,18 @@ def main():
         dev[mode] = m.sample(C[:61], distributed=mode) if mode != "full" else m.sample(C[:61])
     np.savez(out + ".rank%d.npz" % rank, shard=smp["shard"], gather=smp["gather"], full=full61,
              dev_shard=dev["shard"], dev_gather=dev["gather"], dev_full=dev["full"])
+    # CVAE, data parallel: ranks seeded differently must still walk rank 0's shuffle and noise
+    from probaforms_amd.models import CVAE
+    torch.manual_seed(0 if rank == 0 else 999 + rank)
+    cv = CVAE(latent_dim=2, hidden=(16,), batch_size=96, n_epochs=2, lr=1e-2)
+    cv.fit(X, C)
+    cflat = cv._core.flat.detach().clone()
+    cg = [torch.empty_like(cflat) for _ in range(world)]
+    dist.all_gather(cg, cflat)
+    csame = all(torch.equal(cg[0], g) for g in cg)
     if rank == 0:
-        np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs)
+        np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs,
+                 cvae_flat=cflat.cpu().numpy(), cvae_hist=np.array([float(v) for v in cv.loss_history]), cvae_same=csame)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -50,6 +50,15 @@ def test_two_ranks_on_hip_kernels_match_single_process(tmp_path):
     torch.manual_seed(5)
     xs = m.sample(C[:64])
     assert np.abs(xs - dp["xs"]).max() < 5e-3
+    # CVAE data parallel (ranks seeded differently): replicas identical, equal to the single process seeded like rank 0
+    from probaforms_amd.models import CVAE
+    assert bool(dp["cvae_same"])
+    torch.manual_seed(0)
+    cv = CVAE(latent_dim=2, hidden=(16,), batch_size=96, n_epochs=2, lr=1e-2)
+    cv.fit(X, C)
+    np.testing.assert_allclose(dp["cvae_hist"], np.array([float(v) for v in cv.loss_history]), rtol=5e-4, atol=5e-4)
+    cf = cv._core.flat.detach().cpu().numpy()
+    assert np.abs(dp["cvae_flat"] - cf).max() < 2e-3 and np.abs(dp["cvae_flat"] - cf).mean() < 5e-5
     # sharded sampling: rank shares are consecutive blocks of the replicated draw; 'gather' rebuilds all of it
     s0, s1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
     assert s0["shard"].shape == (31, 5) and s1["shard"].shape == (30, 5)
