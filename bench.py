@@ -246,12 +246,17 @@ def main():
     P = eng.P
 
     def step_dp(i):
+        """N ranks: per batch the shard's loss + gradient, the all-reduce of [gradient | loss] on RCCL's stream, and --
+        under that all-reduce, which it does not depend on -- the sampling of this batch's 65 536 rows (the 1M sampled
+        rows of the step are drawn batch by batch; the counter-based prior makes the chunks tile the one-shot draw);
+        then loss read-out + Adam in one launch."""
         perm = perms[i]
         for k, (s, e) in enumerate(bounds):
             g = eng.loss_grad(X, C, perm[s:e], e - s, 1.0 / ((e - s) * world))
-            dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM)
-            eng.finish_dp_step(opt, losses[i, k:k + 1])            # loss read-out + Adam, one launch
-        eng.sample(N_ROWS, C, 1000 + i, row_offset=rank * N_ROWS, out=xs)
+            work = dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM, async_op=True)
+            eng.sample(e - s, C[s:e], 1000 + i, row_offset=rank * N_ROWS + s, out=xs[s:e])
+            work.wait()
+            eng.finish_dp_step(opt, losses[i, k:k + 1])
 
     def step_1(i):
         """single GPU: rnvp_fit_epoch (a fused loss + gradient + Adam step per batch, looped in the library),
@@ -282,7 +287,7 @@ def main():
 
     n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
     n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
-    assert n_train == args.steps * nb and n_inv == args.steps, (n_train, n_inv, args.steps)
+    assert n_train == args.steps * nb and n_inv == args.steps * (nb if dp else 1), (n_train, n_inv, args.steps)
     final_loss = float(losses[n_steps - 1, nb - 1].item())
     assert np.isfinite(final_loss), "training diverged"
 
@@ -313,7 +318,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: RealNVP n=1M/GPU d=16 cond=4 L=8 hidden=(128,); one step = one fit epoch over the "
                                    "rank's 1M rows (16 batches of 65536 incl. the ragged one: loss+grad+Adam each) + "
-                                   "sampling 1M rows (counter-based prior draw inside the inverse kernel)",
+                                   "sampling 1M rows (counter-based prior draw inside the inverse kernel)" +
+                                   ("; N > 1: the 1M rows are sampled batch by batch under each gradient all-reduce" if dp else ""),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -324,16 +330,16 @@ def main():
             "roofline_kernels": {
                 "sample (k_mfma_flow inverse, prior drawn in-kernel)": {
                     "bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": inv_ms / n_inv, "rows_per_launch": N_ROWS,
-                    "launches": n_inv, "where": "timed region"},
+                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": inv_ms / n_inv,
+                    "rows_per_launch": N_ROWS * args.steps // n_inv, "launches": n_inv, "where": "timed region"},
                 "log_prob (k_mfma_flow forward)": {
                     "bound": "mfma", "achieved": fwd_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fwd_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": fwd_ms / n_fwd, "rows_per_launch": N_ROWS,
                     "launches": n_fwd, "where": "after the timed region"}},
-            "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / n_inv * 1e-3),
-                                "note": "sample: kernel time only; fit: see ms_per_step minus the sampling launch"},
+            "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / args.steps * 1e-3),
+                                "note": "sample: kernel time only; fit: ms_per_step minus the sampling kernels' time"},
         }
-        out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / n_inv * 1e-3, 1e-9)
+        out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / args.steps * 1e-3, 1e-9)
         params = eng.params.detach().cpu().numpy()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Xh, Ch, params)

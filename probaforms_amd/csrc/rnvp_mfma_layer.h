@@ -62,6 +62,19 @@ using f2 = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ f4 tanh4(f4 u) {
     if (RNVP_ABLATE & 8) return u * 0.5f;
+#ifdef RNVP_TANH_SCALAR
+    f4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float e = __builtin_amdgcn_exp2f(u[i]);
+        float ep1, hv;
+        asm("v_add_f32 %0, 1.0, %1" : "=v"(ep1) : "v"(e));
+        const float rr = __builtin_amdgcn_rcpf(ep1);
+        asm("v_fma_f32 %0, %1, -2.0, 1.0" : "=v"(hv) : "v"(rr));
+        h[i] = hv;
+    }
+    return h;
+#endif
     f2 e0, e1;
     e0[0] = __builtin_amdgcn_exp2f(u[0]); e0[1] = __builtin_amdgcn_exp2f(u[1]);
     e1[0] = __builtin_amdgcn_exp2f(u[2]); e1[1] = __builtin_amdgcn_exp2f(u[3]);
