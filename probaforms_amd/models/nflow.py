@@ -158,13 +158,17 @@ class NormalizingFlow(nn.Module):
         return eng.inverse(z, C, out=z)
 
     # -- host staging -------------------------------------------------
-    PIPELINE_CHUNK_BYTES = 32 << 20        # of one chunk of output rows
+    # one chunk of output rows: at least PIPELINE_CHUNK_BYTES and at least PIPELINE_MIN_ROWS rows (a launch of fewer
+    # rows leaves CUs idle: 256 rows per workgroup).  Measured at API level, C2 sample(1M): 8 MB chunks 3.1 ms (device
+    # prior) / 33 ms (host prior) against 9.4 / 60 ms one-shot with a pageable download.
+    PIPELINE_CHUNK_BYTES = 8 << 20
+    PIPELINE_MIN_ROWS = 131072
 
     def pipelined_rows(self, n):
         """rows per chunk (a multiple of 16, see row_chunks) if sample_to_host() would pipeline n rows, else 0"""
         if not self._fused_prior():
             return 0
-        rows = max(16, (self.PIPELINE_CHUNK_BYTES // (4 * self.prior.var_size)) // 16 * 16)
+        rows = max(16, self.PIPELINE_MIN_ROWS, self.PIPELINE_CHUNK_BYTES // (4 * self.prior.var_size)) // 16 * 16
         return rows if n > 2 * rows else 0
 
     def sample_to_host(self, C):

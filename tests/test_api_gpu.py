@@ -141,6 +141,7 @@ def test_pipelined_sample_equals_one_shot(cond, prior_rng):
     assert m.nf.pipelined_rows(n) == 0
     torch.manual_seed(7)
     one = m.sample(C)
+    m.nf.PIPELINE_MIN_ROWS = 16
     m.nf.PIPELINE_CHUNK_BYTES = 16 * 4 * d * 6                 # 96-row chunks: 11 chunks, ragged tail
     assert m.nf.pipelined_rows(n) == 96
     torch.manual_seed(7)
@@ -175,6 +176,7 @@ def test_pipelined_sample_to_host_vs_oracle(name, oracle32):
     n = 5000 + 13
     rng = np.random.default_rng(8)
     C = rng.standard_normal((n, c)).astype(np.float32)
+    nf.PIPELINE_MIN_ROWS = 16
     nf.PIPELINE_CHUNK_BYTES = 4 * d * 16 * 40                     # 640-row chunks: 8 chunks, ragged tail
     assert nf.pipelined_rows(n) == 640
     torch.manual_seed(21)

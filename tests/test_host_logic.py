@@ -166,7 +166,10 @@ def test_pipelined_rows_policy():
     from probaforms_amd.models.nflow import NormalizingFlow, StandardNormalPrior
     nf = NormalizingFlow([], StandardNormalPrior(64, "cpu"))
     rows = nf.pipelined_rows(16_000_000)
-    assert rows % 16 == 0 and rows * 64 * 4 <= nf.PIPELINE_CHUNK_BYTES and rows > 0
+    # d = 64: the row floor decides (a chunk must still fill the chip); d = 2: the byte size does
+    assert rows % 16 == 0 and rows == nf.PIPELINE_MIN_ROWS
+    nf_small = NormalizingFlow([], StandardNormalPrior(2, "cpu"))
+    assert nf_small.pipelined_rows(10 ** 8) * 2 * 4 == nf_small.PIPELINE_CHUNK_BYTES
     assert nf.pipelined_rows(2 * rows) == 0 and nf.pipelined_rows(2 * rows + 1) == rows
     nf2 = NormalizingFlow([], object())                       # custom prior: one-shot path only
     assert nf2.pipelined_rows(10 ** 9) == 0
