@@ -121,6 +121,29 @@ class NormalizingFlow(nn.Module):
     def _fused_prior(self):
         return isinstance(self.prior, StandardNormalPrior)
 
+    def _layerwise(self):
+        """True when the layers cannot run as ONE fused stack: the reference's container accepts any list of
+        InvertibleLayer (nflow.py:85-88) -- coupling layers of differing hidden widths / activations, or user-defined
+        layers.  Such flows are evaluated layer by layer through each layer's own f / g (RealNVPLayer.f / .g are the
+        HIP kernels with L = 1), exactly the loops of nflow.py:109-114,142-143."""
+        ls = list(self.layers)
+        if not ls:
+            return True
+        l0 = ls[0]
+        key = lambda l: (getattr(l, "var_size", None), getattr(l, "cond_size", None), tuple(getattr(l, "hidden", ())),
+                         getattr(l, "activation", None), hasattr(l, "nn_t") and hasattr(l, "nn_s") and hasattr(l, "mask"))
+        return any(key(l) != key(l0) for l in ls) or not key(l0)[4]
+
+    def _layerwise_forward(self, X, C):
+        dev = X.device if torch.is_tensor(X) and X.is_cuda else DEVICE
+        x = torch.as_tensor(X, dtype=torch.float32).to(dev)
+        c = None if C is None else torch.as_tensor(C, dtype=torch.float32).to(dev)
+        log_det = torch.zeros(x.shape[0], device=x.device)
+        for layer in self.layers:
+            x, ld = layer.f(x, c)
+            log_det = log_det + ld
+        return log_det + self.prior.log_prob(x)
+
     def _on_device(self, t, eng):
         if t is None:
             return None
@@ -128,6 +151,8 @@ class NormalizingFlow(nn.Module):
 
     # -- reference API -------------------------------------------------------------------------
     def log_prob(self, X, C):
+        if self._layerwise():
+            return self._layerwise_forward(X, C).mean()
         eng = self.engine()
         X, C = self._on_device(X, eng), self._on_device(C, eng)
         if self._fused_prior():
@@ -137,6 +162,8 @@ class NormalizingFlow(nn.Module):
         return (ld + self.prior.log_prob(z)).mean()
 
     def log_prob_samples(self, X, C=None):
+        if self._layerwise():
+            return self._layerwise_forward(X, C)
         eng = self.engine()
         X, C = self._on_device(X, eng), self._on_device(C, eng)
         if self._fused_prior():
@@ -145,6 +172,13 @@ class NormalizingFlow(nn.Module):
         return ld + self.prior.log_prob(z)
 
     def sample(self, C):
+        if self._layerwise():
+            n = C if type(C) == type(1) else len(C)
+            c = None if type(C) == type(1) else torch.as_tensor(C, dtype=torch.float32).to(DEVICE)
+            x = torch.as_tensor(self.prior.sample((n,)), dtype=torch.float32).to(DEVICE)
+            for layer in self.layers[::-1]:
+                x = layer.g(x, c)
+            return x
         eng = self.engine()
         if type(C) == type(1):            # python int only, as nflow.py:135 (np.int64 is not an int)
             n, C = C, None
@@ -166,7 +200,7 @@ class NormalizingFlow(nn.Module):
 
     def pipelined_rows(self, n):
         """rows per chunk (a multiple of 16, see row_chunks) if sample_to_host() would pipeline n rows, else 0"""
-        if not self._fused_prior():
+        if not self._fused_prior() or self._layerwise():
             return 0
         rows = max(16, self.PIPELINE_MIN_ROWS, self.PIPELINE_CHUNK_BYTES // (4 * self.prior.var_size)) // 16 * 16
         return rows if n > 2 * rows else 0
