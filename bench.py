@@ -177,7 +177,9 @@ def api_level(Xh, Ch, dev):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter(); m.fit(Xh, Ch); torch.cuda.synchronize(dev); t_fit = time.perf_counter() - t0
         m.sample(Ch)
-        t0 = time.perf_counter(); xs = m.sample(Ch); t_s = time.perf_counter() - t0
+        t_s = float("inf")
+        for _ in range(3):                                # host-side noise (pinned allocations, other processes): best of 3
+            t0 = time.perf_counter(); xs = m.sample(Ch); t_s = min(t_s, time.perf_counter() - t0)
         assert xs.shape == (N_ROWS, D) and np.isfinite(xs).all()
         if prior == "host":
             out["fit_rows_per_s"] = N_ROWS * epochs / t_fit

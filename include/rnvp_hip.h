@@ -71,7 +71,7 @@ typedef struct rnvp_shape {
                                          float32 throughout, realnvp.py:226-228; both settings meet its 1e-5 bar) */
 } rnvp_shape;
 
-#define RNVP_PREC_AUTO 0         /* the faster of the two for the shape: BX3 for d > 16 (measured 1.3-1.4x), F32 else */
+#define RNVP_PREC_AUTO 0         /* the faster of the two for the shape: BX3 for d > 16 or cdim > 4 (measured 1.3-1.4x), F32 else */
 #define RNVP_PREC_F32  1         /* f32-input MFMA (v_mfma_f32_16x16x4_f32): bitwise an fmaf chain          */
 #define RNVP_PREC_BX3  2         /* operands split into three bf16 terms, six bf16 MFMA products per pair:
                                     float32-level accuracy (every dropped product < 2^-24), weights staged in LDS */

@@ -36,7 +36,9 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     if (s->alt_masks < 0 || s->alt_masks > 2) return RNVP_EINVAL;
     k->alt = s->alt_masks;
     if (s->precision < RNVP_PREC_AUTO || s->precision > RNVP_PREC_BX3) return RNVP_EINVAL;
-    k->prec = s->precision == RNVP_PREC_AUTO ? (s->d > 16 ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
+    // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) --
+    // measured 1.3-1.4x there; the d <= 16 geometry gains nothing from it and keeps the f32 kernels
+    k->prec = s->precision == RNVP_PREC_AUTO ? ((s->d > 16 || s->c > 4) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;
     for (int i = 0; i <= s->n_hidden; ++i) {
