@@ -143,3 +143,22 @@ def test_philox_known_answers_and_normal_moments(oracle32, oracle64):
     np.testing.assert_array_equal(a[20:], b)
     assert not np.array_equal(oracle32.prior_normal(78, 0, 50, 5), a)
     assert np.abs(oracle32.prior_normal(77, 0, 50, 5) - oracle64.prior_normal(77, 0, 50, 5)).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["tm", "c2", "relu_sh", "tm_nocond"])
+def test_eager_torch_cpu_baseline_matches_the_reference_outputs(name):
+    """oracle/torch_cpu.py (the loop bench.py times as cpu_baseline) against the golden fixtures produced by the
+    reference: per-row log-prob (G2) and the inverse of the fixture's z (G3)"""
+    import torch
+    from conftest import load_case
+    from oracle.torch_cpu import EagerFlow
+    cs = load_case(name); g = cs["gold"]
+    flow = EagerFlow(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"])
+    flow.load_flat(cs["params"])
+    X = torch.from_numpy(cs["X"]); C = None if cs["C"] is None else torch.from_numpy(cs["C"])
+    with torch.no_grad():
+        lp, z = flow.log_prob_rows(X, C)
+        assert np.abs(lp.numpy() - g["G2_logp"]).max() < 1e-4 and np.abs(z.numpy() - g["G2_z"]).max() < 2e-5
+        flow.prior.sample = lambda shape: torch.from_numpy(cs["Z"])           # the fixture's prior draw
+        x = flow.sample(C, len(cs["Z"]))
+        np.testing.assert_allclose(x.numpy(), g["G3_x"], rtol=2e-5, atol=2e-5)
