@@ -86,6 +86,12 @@ class PermutationPrefetcher:
             self.futs[e] = self.pool.submit(permutation_from_seed, self.n, self.seeds[e])
             self.next_submit += 1
 
+    def start(self):
+        """begin computing the first permutations now (they overlap whatever the caller does next, e.g. the upload)"""
+        if self.pool is not None:
+            self._submit_upto(0)
+        return self
+
     def get(self, epoch):
         if self.pool is None:
             return permutation_from_seed(self.n, self.seeds[epoch])
@@ -389,7 +395,7 @@ def broadcast_(t, src=0):
     return t
 
 
-def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None, prior=None):
+def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None, prior=None, perms=None):
     """The batch loop of RealNVP.fit (realnvp.py:235-262) on device-resident X [n,d], C [n,c].
 
     Single GPU: one rnvp_fit_epoch call per epoch (a fused rnvp_train_step per batch, looped inside the
@@ -408,7 +414,8 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     old = engine.flat
     if engine.sync_params() is not old and world > 1:
         broadcast_(engine.flat, src=0)
-    perms = PermutationPrefetcher(n, n_epochs)
+    if perms is None:
+        perms = PermutationPrefetcher(n, n_epochs)
     try:
         if world > 1:
             # every rank must walk rank 0's shuffle, whatever state its own generator is in (each rank still

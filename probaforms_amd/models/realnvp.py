@@ -11,8 +11,8 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from .._engine import (FlatAdam, broadcast_, default_device, dist_info, fit_epochs, flatten_parameters, shard_bounds,
-                       is_flat, require_hip)
+from .._engine import (FlatAdam, PermutationPrefetcher, broadcast_, default_device, dist_info, fit_epochs,
+                       flatten_parameters, shard_bounds, is_flat, require_hip)
 from .interfaces import GenModel
 from .nflow import InvertibleLayer, NormalizingFlow, StandardNormalPrior
 
@@ -183,6 +183,13 @@ class RealNVP(GenModel):
     def fit(self, X, C=None):
         self._model_init(X, C)
         eng = self.nf.engine()
+        # The epoch shuffles: the loader seeds are drawn here -- the point of the generator stream where the reference's
+        # first DataLoader draws them (nothing between here and the batch loop consumes the generator) -- and, on a single
+        # GPU, the first permutations start computing on worker threads while the data uploads.  (Data parallel: the
+        # seeds are rank 0's, broadcast inside fit_epochs, so nothing is started before that.)
+        perms = PermutationPrefetcher(len(X), self.n_epochs)
+        if dist_info()[1] == 1:
+            perms.start()
         # numpy (any float dtype) -> float32 on the device, once (realnvp.py:226-228); the cast runs on
         # the device (same round-to-nearest as the host cast, without a host-side pass over the data)
         Xd = _to_device_f32(X, eng.device)
@@ -201,7 +208,7 @@ class RealNVP(GenModel):
                 bar.update(1)
                 bar.set_description("loss: %.4f" % last_loss)
 
-        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook, prior=prior)
+        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook, prior=prior, perms=perms)
         if bar is not None:
             bar.close()
 

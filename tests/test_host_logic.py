@@ -163,13 +163,16 @@ def test_chunked_host_randn_is_the_same_stream():
 
 
 def test_pipelined_rows_policy():
+    import torch
+    from probaforms_amd.models import RealNVPLayer
     from probaforms_amd.models.nflow import NormalizingFlow, StandardNormalPrior
-    nf = NormalizingFlow([], StandardNormalPrior(64, "cpu"))
+    layer = lambda d: [RealNVPLayer(d, 0, torch.arange(d) % 2, (4,), "tanh")]
+    nf = NormalizingFlow(layer(64), StandardNormalPrior(64, "cpu"))
     rows = nf.pipelined_rows(16_000_000)
     # d = 64: the row floor decides (a chunk must still fill the chip); d = 2: the byte size does
     assert rows % 16 == 0 and rows == nf.PIPELINE_MIN_ROWS
-    nf_small = NormalizingFlow([], StandardNormalPrior(2, "cpu"))
+    nf_small = NormalizingFlow(layer(2), StandardNormalPrior(2, "cpu"))
     assert nf_small.pipelined_rows(10 ** 8) * 2 * 4 == nf_small.PIPELINE_CHUNK_BYTES
     assert nf.pipelined_rows(2 * rows) == 0 and nf.pipelined_rows(2 * rows + 1) == rows
-    nf2 = NormalizingFlow([], object())                       # custom prior: one-shot path only
+    nf2 = NormalizingFlow(layer(64), object())                # custom prior: one-shot path only
     assert nf2.pipelined_rows(10 ** 9) == 0
