@@ -520,3 +520,56 @@ def test_unaligned_rows_take_the_guarded_path():
     _hip.loss_grad(shape, params, masks, x, c, None, n, 1.0 / n, g1, l1, wt)
     _hip.loss_grad(shape, params, masks, xu, c, None, n, 1.0 / n, g2, l2, wt)
     assert torch.equal(g1, g2) and torch.equal(l1, l2)
+
+
+def _sweep_shapes():
+    """seeded sweep over the padding boundaries of the MFMA geometries: d around 16 / 32 / 64, cdim around 0 / 4 / 8 / 16,
+    hidden widths around the 16-wide tiles and the bx3 stage chunks, ragged row counts"""
+    rng = np.random.default_rng(2024)
+    ds = [1, 2, 3, 7, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64]
+    cs = [0, 1, 3, 4, 5, 8, 9, 15, 16]
+    hs = [1, 5, 15, 16, 17, 33, 64, 100, 129, 200]
+    ns = [1, 15, 16, 17, 63, 255, 256, 257, 1000, 2049]
+    out = []
+    for i in range(120):
+        out.append((int(rng.integers(1, 5)), int(rng.choice(ds)), int(rng.choice(cs)), int(rng.choice(hs)), int(rng.choice(ns)),
+                    ["tanh", "relu"][i % 2], ["f32", "bx3"][(i // 2) % 2]))
+    return out
+
+
+@pytest.mark.parametrize("L,d,c,h,n,act,prec", _sweep_shapes())
+def test_shape_sweep_vs_oracle(L, d, c, h, n, act, prec, oracle32, oracle64):
+    """forward (z, log-prob, sum), inverse, fused sampling and loss + gradient on randomly combined boundary shapes"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(L * 7919 + d * 131 + c * 17 + h + n)
+    shape = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1, precision=prec)
+    assert _hip.kernel_path(shape, None, _hip.OP_FORWARD) == _hip.PATH_MFMA
+    P = _hip.param_count(shape)
+    params = (rng.uniform(-1, 1, size=P) * min(0.5, 1.5 / np.sqrt(h + d + c))).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32) if c else None
+    s = Shape.make(L, d, c, (h,), act)
+    pd, xd, cd = _dev(params), _dev(X), _dev(C)
+    z = torch.empty(n, d, device="cuda"); lp = torch.empty(n, device="cuda"); tot = torch.empty(1, device="cuda")
+    _hip.forward_logprob(shape, pd, None, xd, cd, None, n, z, None, lp, tot, _ws(_hip, shape, _hip.OP_FORWARD, n))
+    z64, lp64, _ = oracle64.log_prob(s, params, X, C)
+    z32, lp32, _ = oracle32.log_prob(s, params, X, C)
+    scale = max(1.0, float(np.abs(z64).max()))
+    assert np.abs(z.cpu().numpy() - z64).max() < max(4 * np.abs(z32 - z64).max(), 4e-6 * scale)
+    assert np.abs(lp.cpu().numpy() - lp64).mean() < max(3 * np.abs(lp32 - lp64).mean(), 3e-6 * max(1.0, np.abs(lp64).max()))
+    assert abs(float(tot) - lp64.sum()) < 1e-5 * max(1.0, np.abs(lp64).sum())
+    back = torch.empty_like(z)
+    _hip.inverse(shape, pd, None, z, cd, n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
+    assert np.abs(back.cpu().numpy() - X).max() < 5e-4 * max(1.0, np.abs(X).max()) * scale
+    xs = torch.empty_like(z); zp = torch.empty_like(z)
+    _hip.sample(shape, pd, None, cd, n, 5, 11, xs, _ws(_hip, shape, _hip.OP_INVERSE, n))
+    _hip.prior_normal(5, 11, n, d, zp)
+    ref = torch.empty_like(z)
+    _hip.inverse(shape, pd, None, zp, cd, n, ref, _ws(_hip, shape, _hip.OP_INVERSE, n))
+    assert torch.equal(xs, ref)
+    grad = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.loss_grad(shape, pd, None, xd, cd, None, n, 1.0 / n, grad, loss, _ws(_hip, shape, _hip.OP_TRAIN, n))
+    lo, go = oracle64.loss_grad(s, params.astype(np.float64), X.astype(np.float64), None if C is None else C.astype(np.float64))
+    go = np.asarray(go, np.float64)
+    assert abs(float(loss) - float(lo)) < 1e-5 * max(1.0, abs(float(lo)))
+    assert np.abs(grad.cpu().numpy() - go).max() < 5e-6 * np.abs(go).max() + 1e-9
