@@ -176,3 +176,39 @@ def test_pipelined_rows_policy():
     assert nf.pipelined_rows(2 * rows) == 0 and nf.pipelined_rows(2 * rows + 1) == rows
     nf2 = NormalizingFlow(layer(64), object())                # custom prior: one-shot path only
     assert nf2.pipelined_rows(10 ** 9) == 0
+
+
+def test_bench_traffic_is_gated_on_the_kernel_source_hash(tmp_path, monkeypatch):
+    """bench.py reports roofline.traffic from a committed PMC profile only while that profile was taken with exactly
+    the kernel sources in the tree and names the kernel; otherwise null (the number must not go stale)"""
+    import json
+    import bench
+    h = bench.csrc_hash()
+    assert len(h) == 16 and h == bench.csrc_hash()
+    f = tmp_path / "traffic.json"
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+    assert bench.pmc_traffic("k_mfma_train") is None                                    # no file
+    f.write_text(json.dumps({"csrc_hash": h, "kernels": {"k_pack_weights": {"hbm_bytes_per_launch": 1.0},
+                                                         "k_mfma_train<2, 1, 4, 1, 0>": {"hbm_bytes_per_launch": 185e6}}}))
+    assert bench.pmc_traffic("k_mfma_train") == 185e6
+    assert bench.pmc_traffic("k_generic_train") is None                                 # kernel not in the profile
+    f.write_text(json.dumps({"csrc_hash": "0" * 16, "kernels": {"k_mfma_train<2, 1, 4, 1, 0>": {"hbm_bytes_per_launch": 185e6}}}))
+    assert bench.pmc_traffic("k_mfma_train") is None                                    # sources changed since the profile
+
+
+def test_shape_struct_matches_the_c_header():
+    """the ctypes mirror of rnvp_shape has the header's size and field order (compiled with gcc as C)"""
+    import ctypes, os, subprocess, tempfile
+    from conftest import ROOT
+    from probaforms_amd import _hip
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "include/rnvp_hip.h"\n'
+           'int main(void){printf("%zu %zu %zu %zu", sizeof(rnvp_shape), offsetof(rnvp_shape, hidden), '
+           'offsetof(rnvp_shape, alt_masks), offsetof(rnvp_shape, precision));return 0;}\n')
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-I", ROOT, c, "-o", exe])
+        size, o_hidden, o_alt, o_prec = map(int, subprocess.check_output([exe]).split())
+    S = _hip.RnvpShape
+    assert (size, o_hidden, o_alt, o_prec) == (ctypes.sizeof(S), S.hidden.offset, S.alt_masks.offset, S.precision.offset)
+    assert _hip.PRECISIONS == {"auto": 0, "f32": 1, "bx3": 2}
