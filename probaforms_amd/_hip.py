@@ -14,7 +14,7 @@ import torch
 MAX_HIDDEN = 8
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
-PATH_GENERIC, PATH_MFMA = 0, 1
+PATH_GENERIC, PATH_MFMA, PATH_LMM = 0, 1, 2
 # arithmetic of the first Linear of the s/t nets in the forward / inverse / sampling kernels (rnvp_shape.precision):
 # 'f32' = f32-input MFMA; 'bx3' = three-term bf16 split, six products (float32-level accuracy, see rnvp_bx3.h)
 # 'auto' lets the library take the faster one for the shape (bx3 for d > 16)
@@ -97,6 +97,7 @@ _SP = C.POINTER(RnvpShape)
 _SIGNATURES = {
     "rnvp_version": (C.c_int, []),
     "rnvp_status_string": (C.c_char_p, [C.c_int]),
+    "rnvp_generic_mode": (None, [C.c_int]),
     "rnvp_param_count": (_SZ, [_SP]),
     "rnvp_workspace_bytes": (_SZ, [_SP, C.c_int, _I64]),
     "rnvp_kernel_path": (C.c_int, [_SP, _VP, C.c_int]),
@@ -186,6 +187,12 @@ def profile_read(kind=PROFILE_TRAIN):
     n, ms = C.c_int(0), C.c_float(0.0)
     check(lib().rnvp_profile_read(int(kind), C.byref(n), C.byref(ms)), "rnvp_profile_read")
     return n.value, ms.value
+
+
+def generic_mode(mode):
+    """test / measurement aid (process-wide): 0 automatic, 1 the VALU kernels, 2 the lmm kernels for every shape outside
+    the register-chained MFMA path"""
+    lib().rnvp_generic_mode(int(mode))
 
 
 def param_count(shape):

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "rnvp_common.h"
+#include "rnvp_lmm.h"
 #include "rnvp_mfma.h"
 
 using namespace rnvp;
@@ -76,6 +77,8 @@ int rnvp_profile_read(int kind, int *n_launches, float *total_ms) {
 
 int rnvp_version(void) { return 200; }
 
+void rnvp_generic_mode(int mode) { rnvp::lmm::set_mode(mode); }
+
 const char *rnvp_status_string(int status) {
     switch (status) {
         case RNVP_OK: return "ok";
@@ -100,15 +103,17 @@ int rnvp_kernel_path(const rnvp_shape *shape, const uint8_t *host_masks, int op)
             for (int j = 0; j < k.d; ++j)
                 if (host_masks[(size_t)l * k.d + j] != (uint8_t)((j + l + k.alt - 1) & 1)) return RNVP_EINVAL;
     }
-    if (op == RNVP_OP_TRAIN) return mfma::train_supported(k) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
-    return mfma::supported(k) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
+    if (op == RNVP_OP_TRAIN ? mfma::train_supported(k) : mfma::supported(k)) return RNVP_PATH_MFMA;
+    return lmm::use_lmm(k, op) ? RNVP_PATH_LMM : RNVP_PATH_GENERIC;
 }
 
 size_t rnvp_workspace_bytes(const rnvp_shape *shape, int op, int64_t max_rows) {
     KShape k;
     if (make_kshape(shape, &k) != RNVP_OK) return 0;
     const bool use_mfma = (op == RNVP_OP_TRAIN) ? mfma::train_supported(k) : mfma::supported(k);
-    const size_t b = use_mfma ? mfma::workspace_bytes(k, op, max_rows) : generic_workspace_bytes(k, op, max_rows);
+    const size_t b = use_mfma ? mfma::workspace_bytes(k, op, max_rows)
+                              : (lmm::use_lmm(k, op) ? lmm::workspace_bytes(k, op, max_rows < 1 ? 1 : max_rows)
+                                                     : generic_workspace_bytes(k, op, max_rows));
     return b + 256;
 }
 
@@ -130,6 +135,9 @@ int rnvp_forward_logprob(void *stream, const rnvp_shape *shape, const float *par
         return mfma::forward(st, k, params, x, c, row_index, n_rows, z_out, logdet_out, logp_out, logp_sum,
                              workspace, workspace_bytes);
     if (!masks) return RNVP_EINVAL;
+    if (lmm::use_lmm(k, RNVP_OP_FORWARD))
+        return lmm::forward(st, k, params, masks, x, c, row_index, n_rows, z_out, logdet_out, logp_out, logp_sum, workspace,
+                            workspace_bytes);
     return generic_forward(st, k, params, masks, x, c, row_index, n_rows, z_out, logdet_out, logp_out,
                            logp_sum, workspace, workspace_bytes);
 }
@@ -147,6 +155,8 @@ int rnvp_inverse(void *stream, const rnvp_shape *shape, const float *params, con
         return mfma::inverse(static_cast<hipStream_t>(stream), k, params, z, c, n_rows, x_out, workspace,
                              workspace_bytes);
     if (!masks) return RNVP_EINVAL;
+    if (lmm::use_lmm(k, RNVP_OP_INVERSE))
+        return lmm::inverse(static_cast<hipStream_t>(stream), k, params, masks, z, c, n_rows, x_out, workspace, workspace_bytes);
     return generic_inverse(static_cast<hipStream_t>(stream), k, params, masks, z, c, n_rows, x_out);
 }
 
@@ -172,6 +182,7 @@ int rnvp_sample(void *stream, const rnvp_shape *shape, const float *params, cons
     // generic kernels: the same draws written to x_out, then the inverse in place
     rc = prior_normal(st, seed, row_offset, n_rows, k.d, x_out);
     if (rc) return rc;
+    if (lmm::use_lmm(k, RNVP_OP_INVERSE)) return lmm::inverse(st, k, params, masks, x_out, c, n_rows, x_out, workspace, workspace_bytes);
     return generic_inverse(st, k, params, masks, x_out, c, n_rows, x_out);
 }
 
@@ -213,6 +224,9 @@ static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *par
         return mfma::loss_grad(st, k, params, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
                                workspace_bytes, gz);
     if (!masks) return RNVP_EINVAL;
+    if (lmm::use_lmm(k, RNVP_OP_TRAIN))
+        return lmm::loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
+                              workspace_bytes, gz);
     return generic_loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out,
                              workspace, workspace_bytes, gz);
 }

@@ -1,0 +1,37 @@
+// rnvp_lmm.h -- geometry and entry points of the "lmm" kernels (rnvp_lmm.hip): any-shape coupling stack on f32 MFMA
+// with wave-private LDS-resident activations.
+#pragma once
+#include "rnvp_common.h"
+
+namespace rnvp {
+namespace lmm {
+
+struct LGeo {
+    int nlin;                              // Linears per net: n_hidden + 1
+    int nin[kMaxLin], nout[kMaxLin];
+    int MT[kMaxLin], KS[kMaxLin];          // forward: out tiles (16), k-steps (4) over the inputs
+    int MTt[kMaxLin], KSt[kMaxLin];        // transposed (input gradient): in tiles, k-steps over the outputs
+    int PT[kMaxLin];                       // weight gradient: in tiles incl. the ones (bias) column
+    int offF[kMaxLin], offT[kMaxLin];      // float offsets of the fragment blocks inside one net's packed image
+    int offG[kMaxLin];                     // ... of Linear k's [m][p][64 lanes][4] block inside one net's partial gradient
+    int offA[kMaxLin], offP[kMaxLin];      // ... of the dumped input / pre-activation-gradient tiles of one (row tile, net)
+    int net_floats, gnet_floats, dump_floats, pairs_per_net;
+    int hs, hmax, wmax;
+    size_t lds_flow, lds_train;            // bytes of one wave's LDS image
+};
+
+LGeo make_lgeo(const KShape &k);
+bool use_lmm(const KShape &k, int op);     // policy (rnvp_generic_mode: 0 auto, 1 never, 2 whenever the LDS image fits)
+void set_mode(int mode);
+size_t workspace_bytes(const KShape &k, int op, int64_t max_rows);
+int forward(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
+            const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out, float *logp_sum,
+            void *ws, size_t ws_bytes);
+int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *z, const float *c,
+            int64_t n, float *x_out, void *ws, size_t ws_bytes);
+int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
+              const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
+              const float *gz);
+
+}  // namespace lmm
+}  // namespace rnvp

@@ -1,0 +1,516 @@
+// rnvp_lmm.hip -- "lmm": any-shape RealNVP coupling stack on f32 MFMA with LDS-resident activations (gfx950).
+//
+// Serves what the register-chained MFMA path (rnvp_mfma*.hip, rnvp_bx3.hip) does not specialise -- several hidden
+// layers (the reference's docstring example is hidden=(10, 20, 15): /root/reference/probaforms/models/realnvp.py:22-38),
+// user-supplied masks (realnvp.py:65-68), d > 64, cdim > 16 -- for nets wide enough that the one-thread-per-row VALU
+// kernels of rnvp_generic.hip fall off a cliff (hidden=(128, 128): 0.3 M rows/s in fit).  Design:
+//   * one WAVE owns one tile of 16 rows for the whole stack; its activations live in a wave-private LDS image
+//     [feature][17] (no barriers anywhere: DS operations of a wave execute in order);
+//   * every Linear is computed transposed, out^T[out x rows] = W[out x in] . act^T[in x rows], as
+//     v_mfma_f32_16x16x4_f32: A = weight fragments pre-packed per call into lane order (the layer's mask folded into
+//     the first Linear's x columns, so [x*mask || c] is never formed), B = the LDS image (ds_read_b32, conflict free),
+//     the accumulator (bias added, activation applied) written back to the LDS image of the next Linear;
+//   * forward / inverse: x, c read once, z / log-prob written once per row;
+//   * training: the same kernel runs forward, then per layer recomputes both nets and chains the INPUT gradients through
+//     W^T fragments (the hand-derived backward of SURVEY.md 3.3); the WEIGHT gradients contract over rows, so each wave
+//     dumps, per Linear, its input activations (+ a ones column for the bias) and the pre-activation gradients as
+//     [feature][16 rows] tiles, and k_lmm_wgrad forms dW = gP^T . act tile pair by tile pair over fixed row splits;
+//     k_lmm_reduce adds the splits in order and scatters into the reference's flat parameter order.
+//     No float atomics: bitwise reproducible.
+#include "rnvp_common.h"
+#include "rnvp_generic_net.h"
+#include "rnvp_lmm.h"
+
+namespace rnvp {
+namespace lmm {
+namespace {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+constexpr int RS = 17;                 // row stride of the LDS image [feature][RS]: 16 rows + 1 (bank spread for the row-contraction reads)
+constexpr int kMaxGrid = 4096;
+constexpr int kSplits = 64;            // row splits of the weight-gradient pass
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- weight packing -----------------------------------------------------------------------------------------------
+// forward fragments F[k][m][ks][lane]: lane (q, i) = W_k[16m + i][4ks + q];  transposed T[k][m][ks][lane]:
+// lane (q, i) = W_k[4ks + q][16m + i] (for k == 0 only the x columns: C gets no gradient).  First Linear: x column j
+// is multiplied by mask[l][j].
+__global__ void __launch_bounds__(256)
+k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__restrict__ masks, float *__restrict__ packed) {
+    const int64_t total = (int64_t)s.L * 2 * g.net_floats;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int ln = (int)(t / g.net_floats), o = (int)(t - (int64_t)ln * g.net_floats);
+        const int l = ln >> 1;
+        const float *pn = params + (size_t)ln * s.npn;
+        float v = 0.f;
+        for (int k = 0; k < g.nlin; ++k) {
+            const int nin = g.nin[k], nout = g.nout[k];
+            const float *W = pn + s.woff[k];
+            if (o >= g.offF[k] && o < g.offF[k] + g.MT[k] * g.KS[k] * 64) {
+                const int j = o - g.offF[k], lane = j & 63, rest = j >> 6;
+                const int ks = rest % g.KS[k], m = rest / g.KS[k];
+                const int row = 16 * m + (lane & 15), col = 4 * ks + (lane >> 4);
+                if (row < nout && col < nin) v = W[row * nin + col] * ((k == 0 && col < s.d) ? (float)masks[l * s.d + col] : 1.f);
+                break;
+            }
+            if (o >= g.offT[k] && o < g.offT[k] + g.MTt[k] * g.KSt[k] * 64) {
+                const int j = o - g.offT[k], lane = j & 63, rest = j >> 6;
+                const int ks = rest % g.KSt[k], m = rest / g.KSt[k];
+                const int out = 4 * ks + (lane >> 4), in = 16 * m + (lane & 15);
+                const int nin_eff = k == 0 ? s.d : nin;
+                if (out < nout && in < nin_eff) v = W[out * nin + in] * (k == 0 ? (float)masks[l * s.d + in] : 1.f);
+                break;
+            }
+        }
+        packed[t] = v;
+    }
+}
+
+// out^T[nout x 16 rows] = act(W . in^T + b): MT out tiles x KS k-steps; `in` / `out` are LDS images [feature][RS]
+// ACT: -1 none, RNVP_ACT_TANH, RNVP_ACT_RELU.  ACCUM: add into `out` instead of overwriting (input gradients of the two nets).
+template <bool ACCUM>
+__device__ __forceinline__ void linear(const float *__restrict__ frag, int MT, int KS, int nin, int nout, const float *in,
+                                       float *out, const float *__restrict__ bias, int act, int lane) {
+    const int q = lane >> 4, r = lane & 15;
+    for (int m = 0; m < MT; ++m) {
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int o = 16 * m + 4 * q + e; acc[e] = o < nout ? bias[o] : 0.f; }
+        }
+        const float *fp = frag + (size_t)m * KS * 64 + lane;
+        int ks = 0;
+        for (; ks + 4 <= KS; ks += 4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = fp[(ks + u) * 64];
+                const int kk = 4 * (ks + u) + q;
+                b[u] = kk < nin ? in[kk * RS + r] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = mfma16(a[u], b[u], acc);
+        }
+        for (; ks < KS; ++ks) {
+            const int kk = 4 * ks + q;
+            acc = mfma16(fp[ks * 64], kk < nin ? in[kk * RS + r] : 0.f, acc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = 16 * m + 4 * q + e;
+            if (o < nout) {
+                float v = acc[e];
+                if (act >= 0) v = act_fwd(v, act);
+                if (ACCUM) out[o * RS + r] += v; else out[o * RS + r] = v;
+            }
+        }
+    }
+}
+
+// one s or t net, forward: Linear k reads buffer k-1's output; hidden activations go to hbuf + (KEEP ? running
+// offset : ping-pong between hbuf and hbuf2); the last Linear writes `out` [d]
+template <bool KEEP>
+__device__ __forceinline__ void net_fwd(const float *__restrict__ pk, const float *__restrict__ pn, const KShape &s,
+                                        const LGeo &g, const float *xc, float *hbuf, float *hbuf2, float *out, int lane) {
+    const float *cur = xc;
+    float *dst = hbuf;
+    for (int k = 0; k < g.nlin; ++k) {
+        const bool last = k == g.nlin - 1;
+        float *ob = last ? out : dst;
+        linear<false>(pk + g.offF[k], g.MT[k], g.KS[k], g.nin[k], g.nout[k], cur, ob, pn + s.boff[k], last ? -1 : s.act, lane);
+        wave_fence();
+        cur = ob;
+        if (!last) {
+            if (KEEP) dst += g.nout[k] * RS;
+            else dst = (dst == hbuf) ? hbuf2 : hbuf;
+        }
+    }
+}
+
+// rows of one tile <-> LDS image; element e = lane + 64 t of the 16 x w block (coalesced when the rows are contiguous)
+__device__ __forceinline__ void load_tile(const float *__restrict__ src, const int64_t *__restrict__ row_index, int64_t base,
+                                          int64_t n, int w, float *img, int lane) {
+    for (int e = lane; e < 16 * w; e += 64) {
+        const int rr = e / w, j = e - rr * w;
+        const int64_t row = base + rr;
+        float v = 0.f;
+        if (row < n) v = src[(row_index ? row_index[row] : row) * w + j];
+        img[j * RS + rr] = v;
+    }
+}
+
+// ---- forward (+ log-det + prior) / inverse ----------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ void __launch_bounds__(64)
+k_lmm_flow(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
+           const uint8_t *__restrict__ masks, const float *x, const float *__restrict__ c,
+           const int64_t *__restrict__ row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out, float *part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
+    float *XC = lds, *H0 = XC + (d + cd) * RS, *H1 = H0 + g.hmax * RS, *T = H1 + g.hmax * RS, *S = T + d * RS;
+    const int64_t ntiles = (n + 15) / 16;
+    const float prior_c = 0.5f * (float)d * kLog2Pi;
+    float wave_sum = 0.f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * 16;
+        load_tile(x, row_index, base, n, d, XC, lane);
+        if (cd) load_tile(c, row_index, base, n, cd, XC + d * RS, lane);
+        wave_fence();
+        float ld = 0.f;
+        for (int lp = 0; lp < s.L; ++lp) {
+            const int l = INVERSE ? s.L - 1 - lp : lp;
+            const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
+            net_fwd<false>(pk, pn, s, g, XC, H0, H1, T, lane);
+            net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, H0, H1, S, lane);
+            const uint8_t *m = masks + l * d;
+            for (int j = q; j < d; j += 4) {
+                if (!m[j]) {
+                    const float sv = S[j * RS + r], tv = T[j * RS + r], xv = XC[j * RS + r];
+                    if (INVERSE) XC[j * RS + r] = (xv - tv) * expf(-sv);
+                    else { XC[j * RS + r] = fmaf(xv, expf(sv), tv); ld += sv; }
+                }
+            }
+            wave_fence();
+        }
+        const int64_t row = base + r;
+        const bool valid = row < n;
+        if (out_x) {
+            for (int e = lane; e < 16 * d; e += 64) {
+                const int rr = e / d, j = e - rr * d;
+                if (base + rr < n) out_x[(base + rr) * d + j] = XC[j * RS + rr];
+            }
+        }
+        if (!INVERSE) {
+            float ss = 0.f;
+            for (int j = q; j < d; j += 4) { const float zv = XC[j * RS + r]; ss = fmaf(zv, zv, ss); }
+            ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+            const float lpv = ld + (-0.5f * ss - prior_c);
+            if (valid && q == 0) {
+                if (logdet_out) logdet_out[row] = ld;
+                if (logp_out) logp_out[row] = lpv;
+            }
+            float v = (valid && q == 0) ? lpv : 0.f;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            wave_sum += v;
+        }
+        wave_fence();
+    }
+    if (!INVERSE && part && lane == 0) part[blockIdx.x] = wave_sum;
+}
+
+// [feature][RS] image -> [feature][16] tile in global memory, nfeat real features padded with `pad` zero features up
+// to ntot; feature `ones_at` (if >= 0) is written as 1 (the bias column of the weight-gradient product)
+__device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot, int ones_at, float *__restrict__ dst, int lane) {
+    const int q = lane >> 4, r = lane & 15;
+    for (int f = q; f < ntot; f += 4) {
+        float v = 0.f;
+        if (f < nfeat) v = img[f * RS + r];
+        else if (f == ones_at) v = 1.f;
+        dst[f * 16 + r] = v;
+    }
+}
+
+// ---- loss + input-gradient chain; dumps the operands of the weight gradients -------------------------------------------
+__global__ void __launch_bounds__(64)
+k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
+            const uint8_t *__restrict__ masks, const float *__restrict__ x, const float *__restrict__ c,
+            const int64_t *__restrict__ row_index, int64_t n, float inv_B, const float *__restrict__ gz,
+            float *__restrict__ dump, float *__restrict__ xsave, float *losspart) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
+    float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
+    float *GA = GIN + d * RS, *GB = GA + g.wmax * RS;
+    const int64_t ntiles = (n + 15) / 16;
+    const float prior_c = 0.5f * (float)d * kLog2Pi;
+    float wave_sum = 0.f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * 16, row = base + r;
+        const bool valid = row < n;
+        load_tile(x, row_index, base, n, d, XC, lane);
+        if (cd) load_tile(c, row_index, base, n, cd, XC + d * RS, lane);
+        wave_fence();
+        float *xs = xsave + (size_t)tile * s.L * d * 16;
+        float ld = 0.f;
+        for (int l = 0; l < s.L; ++l) {
+            const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
+            for (int j = q; j < d; j += 4) xs[(l * d + j) * 16 + r] = XC[j * RS + r];        // layer input, for the backward
+            net_fwd<false>(pk, pn, s, g, XC, GA, GB, T, lane);
+            net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, GA, GB, S, lane);
+            const uint8_t *m = masks + l * d;
+            for (int j = q; j < d; j += 4)
+                if (!m[j]) { const float sv = S[j * RS + r]; XC[j * RS + r] = fmaf(XC[j * RS + r], expf(sv), T[j * RS + r]); ld += sv; }
+            wave_fence();
+        }
+        {   // loss terms and the seed of the backward
+            float ss = 0.f;
+            for (int j = q; j < d; j += 4) { const float zv = XC[j * RS + r]; ss = fmaf(zv, zv, ss); }
+            ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+            const float lpv = gz ? ld : ld + (-0.5f * ss - prior_c);
+            float v = (valid && q == 0) ? lpv : 0.f;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            wave_sum += v;
+            for (int j = q; j < d; j += 4)
+                GY[j * RS + r] = valid ? (gz ? gz[row * d + j] : XC[j * RS + r] * inv_B) : 0.f;
+        }
+        const float gld = valid ? -inv_B : 0.f;
+        wave_fence();
+        for (int l = s.L - 1; l >= 0; --l) {
+            const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
+            const uint8_t *m = masks + l * d;
+            float *dl = dump + ((size_t)tile * s.L + l) * 2 * g.dump_floats;
+            for (int j = q; j < d; j += 4) { XC[j * RS + r] = xs[(l * d + j) * 16 + r]; GIN[j * RS + r] = 0.f; }
+            wave_fence();
+            for (int net = 1; net >= 0; --net) {                     // s first (its output is needed for exp(s)), then t
+                const float *pkn = pk + net * g.net_floats, *pnn = pn + (size_t)net * s.npn;
+                float *dn = dl + (size_t)net * g.dump_floats;
+                net_fwd<true>(pkn, pnn, s, g, XC, ACT, nullptr, net ? S : T, lane);
+                // d loss / d (net output): s: (1-m)(gy x e^s + gld), t: (1-m) gy
+                for (int j = q; j < d; j += 4) {
+                    float v = 0.f;
+                    if (!m[j]) {
+                        const float gy = GY[j * RS + r];
+                        v = net ? fmaf(gy * XC[j * RS + r], expf(S[j * RS + r]), gld) : gy;
+                    }
+                    GA[j * RS + r] = v;
+                }
+                wave_fence();
+                float *gcur = GA, *gprev = GB;
+                int aoff = g.hs;                                       // running feature offset of Linear k's own activation block
+                for (int k = nh; k >= 0; --k) {
+                    const int nin = g.nin[k], nout = g.nout[k];
+                    if (k < nh) {
+                        aoff -= nout;
+                        const float *ak = ACT + aoff * RS;
+                        for (int f = q; f < nout; f += 4) {
+                            const float a = ak[f * RS + r], gv = gcur[f * RS + r];
+                            gcur[f * RS + r] = (s.act == RNVP_ACT_TANH) ? gv * (1.f - a * a) : (a > 0.f ? gv : 0.f);
+                        }
+                        wave_fence();
+                    }
+                    const float *inp = (k == 0) ? XC : ACT + (aoff - nin) * RS;
+                    dump_tile(gcur, nout, 16 * g.MT[k], -1, dn + g.offP[k], lane);
+                    dump_tile(inp, nin, 16 * g.PT[k], nin, dn + g.offA[k], lane);
+                    // input gradient: for Linear 0 only the x part, added into GIN (the mask is folded into the fragments)
+                    if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, d, gcur, GIN, nullptr, -1, lane);
+                    else linear<false>(pkn + g.offT[k], g.MTt[k], g.KSt[k], nout, nin, gcur, gprev, nullptr, -1, lane);
+                    wave_fence();
+                    float *tmp = gcur; gcur = gprev; gprev = tmp;
+                }
+            }
+            for (int j = q; j < d; j += 4) {
+                const float gy = GY[j * RS + r];
+                GY[j * RS + r] = (m[j] ? gy : gy * expf(S[j * RS + r])) + GIN[j * RS + r];
+            }
+            wave_fence();
+        }
+    }
+    if (lane == 0) losspart[blockIdx.x] = wave_sum;
+}
+
+// ---- weight gradients: dW[k] tile (m, p) = sum over rows gP[row][16m + i] * act[row][16p + j] ---------------------------
+// one wave per (layer, net, Linear, m, p) and row split; operands are the [feature][16 rows] tiles dumped above, read as
+// one float4 per lane (rows 4q .. 4q+3 of feature i): k-step ks of lane group q stands for row 4q + ks on both sides
+__global__ void __launch_bounds__(64)
+k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, float *__restrict__ gpart) {
+    const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+    int pair = blockIdx.x;
+    const int ln = pair / g.pairs_per_net;
+    pair -= ln * g.pairs_per_net;
+    int k = 0;
+    while (k + 1 < g.nlin && pair >= g.MT[k] * g.PT[k]) { pair -= g.MT[k] * g.PT[k]; ++k; }
+    const int m = pair / g.PT[k], p = pair - m * g.PT[k];
+    const size_t tstride = (size_t)s.L * 2 * g.dump_floats;
+    const float *pa = dump + (size_t)ln * g.dump_floats + g.offP[k] + m * 256 + i * 16 + 4 * q;
+    const float *pb = dump + (size_t)ln * g.dump_floats + g.offA[k] + p * 256 + i * 16 + 4 * q;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = blockIdx.y; t < ntiles; t += gridDim.y) {
+        const f4 a = *reinterpret_cast<const f4 *>(pa + (size_t)t * tstride);
+        const f4 b = *reinterpret_cast<const f4 *>(pb + (size_t)t * tstride);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = mfma16(a[ks], b[ks], acc);
+    }
+    float *dst = gpart + ((size_t)blockIdx.y * s.L * 2 + ln) * g.gnet_floats + g.offG[k] + (m * g.PT[k] + p) * 256 + lane * 4;
+    *reinterpret_cast<f4 *>(dst) = acc;
+}
+
+// flat reference-order gradient: sum of the row splits in index order; loss = -(sum of wave partials) * inv_B
+__global__ void __launch_bounds__(256)
+k_lmm_reduce(KShape s, LGeo g, const float *__restrict__ gpart, int S, const uint8_t *__restrict__ masks,
+             const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss) {
+    const size_t P = (size_t)2 * s.npn * s.L;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) {
+        if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
+            const int lane = threadIdx.x - 192;
+            float a = 0.f;
+            for (int t = lane; t < G; t += 64) a += losspart[t];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            if (lane == 0) loss[0] = -a * inv_B;
+        }
+        return;
+    }
+    const int ln = (int)(p / s.npn), l = ln >> 1;
+    const int idx = (int)(p - (size_t)ln * s.npn);
+    int k = 0;
+    while (k + 1 < g.nlin && idx >= s.woff[k + 1]) ++k;
+    const int nin = g.nin[k];
+    int o, in;
+    float scale = 1.f;
+    if (idx < s.boff[k]) {
+        o = (idx - s.woff[k]) / nin; in = (idx - s.woff[k]) - o * nin;
+        if (k == 0 && in < s.d) scale = (float)masks[l * s.d + in];          // W'[:, j] = W[:, j] * mask_j
+    } else { o = idx - s.boff[k]; in = nin; }                                // bias: the ones column
+    const int m = o >> 4, pt = in >> 4;
+    const int loc = g.offG[k] + (m * g.PT[k] + pt) * 256 + ((((o & 15) >> 2) * 16) + (in & 15)) * 4 + (o & 3);
+    const float *src = gpart + (size_t)ln * g.gnet_floats + loc;
+    const size_t stride = (size_t)s.L * 2 * g.gnet_floats;
+    float a = 0.f;
+    for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];
+    grad[p] = a * scale;
+}
+
+std::atomic<uint64_t> g_attr_fwd{0}, g_attr_inv{0}, g_attr_train{0};
+std::atomic<int> g_mode{0};
+
+int grid_for(int64_t ntiles) { return (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid); }
+
+}  // namespace
+
+LGeo make_lgeo(const KShape &k) {
+    LGeo g;
+    std::memset(&g, 0, sizeof(g));
+    g.nlin = k.nh + 1;
+    int oW = 0, oG = 0, oD = 0, pairs = 0;
+    for (int i = 0; i < g.nlin; ++i) {
+        g.nin[i] = k.nin[i]; g.nout[i] = k.nout[i];
+        g.MT[i] = (k.nout[i] + 15) / 16; g.KS[i] = (k.nin[i] + 3) / 4;
+        g.MTt[i] = ((i == 0 ? k.d : k.nin[i]) + 15) / 16; g.KSt[i] = (k.nout[i] + 3) / 4;
+        g.PT[i] = (k.nin[i] + 1 + 15) / 16;
+        g.offF[i] = oW; oW += g.MT[i] * g.KS[i] * 64;
+        g.offT[i] = oW; oW += g.MTt[i] * g.KSt[i] * 64;
+        g.offG[i] = oG; oG += g.MT[i] * g.PT[i] * 256;
+        g.offA[i] = oD; oD += g.PT[i] * 256;
+        g.offP[i] = oD; oD += g.MT[i] * 256;
+        pairs += g.MT[i] * g.PT[i];
+    }
+    g.net_floats = oW; g.gnet_floats = oG; g.dump_floats = oD; g.pairs_per_net = pairs;
+    g.hs = k.hs; g.hmax = k.hmax;
+    g.wmax = k.hmax > k.d ? k.hmax : k.d;
+    g.lds_flow = (size_t)(3 * k.d + k.c + 2 * k.hmax) * RS * sizeof(float);
+    g.lds_train = (size_t)(k.d + k.c + k.hs + 4 * k.d + 2 * g.wmax) * RS * sizeof(float);
+    return g;
+}
+
+void set_mode(int mode) { g_mode.store(mode, std::memory_order_relaxed); }
+
+// auto: the nets must be wide enough for 16-wide tiles to pay (else the VALU kernels' thread-per-row form is as good and
+// needs fewer launches), and a wave's LDS image must leave room for at least two waves per CU
+bool use_lmm(const KShape &k, int op) {
+    const int mode = g_mode.load(std::memory_order_relaxed);
+    if (mode == 1) return false;
+    const LGeo g = make_lgeo(k);
+    const size_t need = op == RNVP_OP_TRAIN ? g.lds_train : g.lds_flow;
+    if (need > 76 * 1024) return false;
+    if (mode == 2) return true;
+    return k.hmax >= 32 || k.d + k.c >= 32;
+}
+
+size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
+    const LGeo g = make_lgeo(k);
+    const int64_t ntiles = (max_rows + 15) / 16;
+    size_t b = align_up((size_t)k.L * 2 * g.net_floats * sizeof(float), 256);                       // packed weights
+    b += align_up((size_t)kMaxGrid * sizeof(float), 256);                                           // per-wave loss / log-prob partials
+    if (op == RNVP_OP_TRAIN) {
+        b += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);               // wgrad operands
+        b += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);                        // layer inputs
+        b += align_up((size_t)kSplits * k.L * 2 * g.gnet_floats * sizeof(float), 256);              // split partials
+    }
+    return b;
+}
+
+static int pack(hipStream_t st, const KShape &k, const LGeo &g, const float *params, const uint8_t *masks, float *packed) {
+    const int64_t total = (int64_t)k.L * 2 * g.net_floats;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_lmm_pack, dim3(blocks), dim3(256), 0, st, k, g, params, masks, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+int forward(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
+            const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out, float *logp_sum,
+            void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_FORWARD, n)) return RNVP_EWORKSPACE;
+    const LGeo g = make_lgeo(k);
+    float *packed = static_cast<float *>(ws);
+    float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)k.L * 2 * g.net_floats * sizeof(float), 256));
+    int rc = pack(st, k, g, params, masks, packed);
+    if (rc) return rc;
+    rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_flow<false>), 160 * 1024, g_attr_fwd);
+    if (rc) return rc;
+    const int G = grid_for((n + 15) / 16);
+    hipLaunchKernelGGL(k_lmm_flow<false>, dim3(G), dim3(64), g.lds_flow, st, k, g, packed, params, masks, x, c, row_index, n,
+                       z_out, logdet_out, logp_out, part);
+    RNVP_HIP_TRY(hipGetLastError());
+    if (logp_sum) return generic_reduce_partials(st, nullptr, part, G, 0, 1.0f, nullptr, logp_sum);
+    return RNVP_OK;
+}
+
+int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *z, const float *c,
+            int64_t n, float *x_out, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
+    const LGeo g = make_lgeo(k);
+    float *packed = static_cast<float *>(ws);
+    int rc = pack(st, k, g, params, masks, packed);
+    if (rc) return rc;
+    rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_flow<true>), 160 * 1024, g_attr_inv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lmm_flow<true>, dim3(grid_for((n + 15) / 16)), dim3(64), g.lds_flow, st, k, g, packed, params, masks, z,
+                       c, nullptr, n, x_out, nullptr, nullptr, nullptr);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
+              const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
+              const float *gz) {
+    if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
+    const LGeo g = make_lgeo(k);
+    const int64_t ntiles = (n + 15) / 16;
+    char *w = static_cast<char *>(ws);
+    float *packed = reinterpret_cast<float *>(w); w += align_up((size_t)k.L * 2 * g.net_floats * sizeof(float), 256);
+    float *losspart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * sizeof(float), 256);
+    float *dump = reinterpret_cast<float *>(w); w += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);
+    float *xsave = reinterpret_cast<float *>(w); w += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);
+    float *gpart = reinterpret_cast<float *>(w);
+    int rc = pack(st, k, g, params, masks, packed);
+    if (rc) return rc;
+    rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_train), 160 * 1024, g_attr_train);
+    if (rc) return rc;
+    const int G = grid_for(ntiles);
+    const int S = (int)(ntiles < kSplits ? ntiles : kSplits);
+    {
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
+        hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64), g.lds_train, st, k, g, packed, params, masks, x, c, row_index, n, inv_B,
+                           gz, dump, xsave, losspart);
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)(k.L * 2 * g.pairs_per_net), (unsigned)S), dim3(64), 0, st, k, g, dump, ntiles, gpart);
+    RNVP_HIP_TRY(hipGetLastError());
+    const size_t P = (size_t)2 * k.npn * k.L;
+    hipLaunchKernelGGL(k_lmm_reduce, dim3((unsigned)(P / 256 + 2)), dim3(256), 0, st, k, g, gpart, S, masks, losspart, G, inv_B,
+                       grad_out, loss_out);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+}  // namespace lmm
+}  // namespace rnvp

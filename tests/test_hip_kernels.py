@@ -15,12 +15,21 @@ def _dev(a, dtype=torch.float32):
     return None if a is None else torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda().contiguous()
 
 
-PATHS = ["declared", "table"]     # masks declared alternating (MFMA path where it applies) / read from the table (generic path)
+# masks declared alternating (register-chained MFMA path where it applies) / read from the table: the VALU kernels
+# ("table") and the any-shape MFMA kernels with LDS-resident activations ("table/lmm", forced for every fixture)
+PATHS = ["declared", "table", "table/lmm"]
+
+
+@pytest.fixture(autouse=True)
+def _reset_generic_mode():
+    yield
+    from probaforms_amd import _hip
+    _hip.generic_mode(0)
 
 
 # "declared/bx3": same masks declaration, GEMM1 of the forward / inverse kernels on the split-bf16 path with
 # LDS-staged weights (rnvp_shape.precision = RNVP_PREC_BX3); "declared" pins RNVP_PREC_F32
-FLOW_PATHS = ["declared", "declared/bx3", "table"]
+FLOW_PATHS = ["declared", "declared/bx3", "table", "table/lmm"]
 
 
 def _setup(name, path="declared"):
@@ -29,12 +38,14 @@ def _setup(name, path="declared"):
     alt = _hip.RnvpShape.classify_masks(cs["masks"])
     assert alt == 1
     prec = "bx3" if path.endswith("/bx3") else "f32"
+    lmm = path.endswith("/lmm")
     path = path.split("/")[0]
+    _hip.generic_mode(2 if lmm else (1 if path == "table" else 0))
     shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=alt if path == "declared" else 0,
                                 precision=prec)
     assert _hip.param_count(shape) == cs["params"].size
     if path == "table":
-        assert _hip.kernel_path(shape, cs["masks"], _hip.OP_TRAIN) == _hip.PATH_GENERIC
+        assert _hip.kernel_path(shape, cs["masks"], _hip.OP_TRAIN) == (_hip.PATH_LMM if lmm else _hip.PATH_GENERIC)
     return _hip, cs, shape, _dev(cs["params"]), _dev(cs["masks"], torch.uint8)
 
 
@@ -389,7 +400,7 @@ def test_fused_sample_equals_prior_then_inverse(name, path, oracle32):
     split of the rows; and matches the oracle's sample() on the oracle's own draw"""
     from oracle import Shape
     _hip, cs, shape, params, masks = _setup(name, path)
-    if path != "table" and len(cs["hidden"]) > 1:
+    if path.startswith("declared") and len(cs["hidden"]) > 1:
         pytest.skip("several hidden layers: same (generic) kernels as the table path")
     n, d, cdim, seed = 777, cs["d"], cs["c"], 99
     rng = np.random.default_rng(5)
@@ -423,8 +434,9 @@ def _rand_flow(L, d, c, hidden, act, seed, scale=0.3):
     return sh, (rng.uniform(-1, 1, P) * scale).astype(np.float32), rng
 
 
+@pytest.mark.parametrize("family", ["valu", "lmm"])
 @pytest.mark.parametrize("kind", ["blocks", "all_ones_layer", "random", "wide_d80_c20"])
-def test_user_masks_and_wide_shapes_vs_oracle(kind, oracle32, oracle64):
+def test_user_masks_and_wide_shapes_vs_oracle(kind, family, oracle32, oracle64):
     """RealNVPLayer(mask=...) accepts any {0,1} mask (realnvp.py:65-68): non-alternating tables, a layer whose mask is
     all ones (identity, log-det 0), and d > 64 / cdim > 16 run on the generic kernels -- forward, inverse, gradient"""
     from oracle import Shape
@@ -443,7 +455,8 @@ def test_user_masks_and_wide_shapes_vs_oracle(kind, oracle32, oracle64):
     else:
         masks = ((np.arange(d)[None] // 3 + np.arange(L)[:, None]) % 2).astype(np.uint8)
     assert _hip.RnvpShape.classify_masks(masks) == 0
-    assert _hip.kernel_path(sh, masks, _hip.OP_TRAIN) == _hip.PATH_GENERIC
+    _hip.generic_mode(2 if family == "lmm" else 1)
+    assert _hip.kernel_path(sh, masks, _hip.OP_TRAIN) == (_hip.PATH_LMM if family == "lmm" else _hip.PATH_GENERIC)
     X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
     so = Shape.make(L, d, c, hidden, act)
     params, mk, x, cc = _dev(p), _dev(masks, torch.uint8), _dev(X), _dev(C)
