@@ -38,9 +38,26 @@ __device__ __forceinline__ void wave_fence() {
 }
 
 // ---- weight packing -----------------------------------------------------------------------------------------------
-// forward fragments F[k][m][ks][lane]: lane (q, i) = W_k[16m + i][4ks + q];  transposed T[k][m][ks][lane]:
-// lane (q, i) = W_k[4ks + q][16m + i] (for k == 0 only the x columns: C gets no gradient).  First Linear: x column j
-// is multiplied by mask[l][j].
+// Fragment value for out tile m, k-step ks, lane (q, i): forward W_k[16m + i][4ks + q]; transposed W_k[4ks + q][16m + i]
+// (for k == 0 only the x columns: C gets no gradient).  First Linear: x column j is multiplied by mask[l][j].
+// Layout of one Linear's fragments: out tiles in blocks of MB = 4 (then one of 2, one of 1), a block stored
+// [k-step][tile in block][lane] with the k-steps padded to a multiple of 4 (zeros), so that the kernel's group of
+// 4 k-steps x MB tiles is MB * 4 loads at constant offsets from one base.
+__device__ __forceinline__ void block_decode(int o, int MT, int KSp, int *m, int *ks, int *lane) {
+    const int n4 = MT >> 2, rem = MT & 3, per = KSp * 64;
+    int MB, m0, oo;
+    if (o < n4 * 4 * per) { MB = 4; m0 = 4 * (o / (4 * per)); oo = o % (4 * per); }
+    else {
+        oo = o - n4 * 4 * per; m0 = 4 * n4;
+        if (rem >= 2 && oo < 2 * per) MB = 2;
+        else { if (rem >= 2) { oo -= 2 * per; m0 += 2; } MB = 1; }
+    }
+    *lane = oo & 63;
+    const int rest = oo >> 6;
+    *m = m0 + rest % MB;
+    *ks = rest / MB;
+}
+
 __global__ void __launch_bounds__(256)
 k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__restrict__ masks, float *__restrict__ packed) {
     const int64_t total = (int64_t)s.L * 2 * g.net_floats;
@@ -52,16 +69,15 @@ k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__
         for (int k = 0; k < g.nlin; ++k) {
             const int nin = g.nin[k], nout = g.nout[k];
             const float *W = pn + s.woff[k];
+            int m, ks, lane;
             if (o >= g.offF[k] && o < g.offF[k] + g.MT[k] * g.KS[k] * 64) {
-                const int j = o - g.offF[k], lane = j & 63, rest = j >> 6;
-                const int ks = rest % g.KS[k], m = rest / g.KS[k];
+                block_decode(o - g.offF[k], g.MT[k], g.KS[k], &m, &ks, &lane);
                 const int row = 16 * m + (lane & 15), col = 4 * ks + (lane >> 4);
                 if (row < nout && col < nin) v = W[row * nin + col] * ((k == 0 && col < s.d) ? (float)masks[l * s.d + col] : 1.f);
                 break;
             }
             if (o >= g.offT[k] && o < g.offT[k] + g.MTt[k] * g.KSt[k] * 64) {
-                const int j = o - g.offT[k], lane = j & 63, rest = j >> 6;
-                const int ks = rest % g.KSt[k], m = rest / g.KSt[k];
+                block_decode(o - g.offT[k], g.MTt[k], g.KSt[k], &m, &ks, &lane);
                 const int out = 4 * ks + (lane >> 4), in = 16 * m + (lane & 15);
                 const int nin_eff = k == 0 ? s.d : nin;
                 if (out < nout && in < nin_eff) v = W[out * nin + in] * (k == 0 ? (float)masks[l * s.d + in] : 1.f);
@@ -72,45 +88,88 @@ k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__
     }
 }
 
-// out^T[nout x 16 rows] = act(W . in^T + b): MT out tiles x KS k-steps; `in` / `out` are LDS images [feature][RS]
-// ACT: -1 none, RNVP_ACT_TANH, RNVP_ACT_RELU.  ACCUM: add into `out` instead of overwriting (input gradients of the two nets).
-template <bool ACCUM>
-__device__ __forceinline__ void linear(const float *__restrict__ frag, int MT, int KS, int nin, int nout, const float *in,
-                                       float *out, const float *__restrict__ bias, int act, int lane) {
+// out^T[nout x 16 rows] = act(W . in^T + b) for the MB out tiles of one fragment block; `in` / `out` are LDS images
+// [feature][RS].  ACT: -1 none, RNVP_ACT_TANH, RNVP_ACT_RELU.  ACCUM: add into `out` (input gradients of the two nets).
+// The instruction budget matters more than anything here -- an f32 MFMA and VALU work do not overlap on a SIMD, and
+// a wave's LDS image leaves room for one or two waves per SIMD only -- so the group loop is 4 k-steps x MB tiles of
+// loads at constant offsets from two bases (no clamps, no guards: the fragments are zero-padded, and an LDS row past
+// the real inputs holds finite stale data that those zeros cancel), MB independent accumulator chains, and the next
+// group's operands in flight while the current one multiplies.
+template <bool ACCUM, int MB, int ACT>
+__device__ __forceinline__ void linear_mb(const float *__restrict__ fblk, int m0, int KSp, int nout, const float *in,
+                                          float *out, const float *__restrict__ bias, int lane) {
     const int q = lane >> 4, r = lane & 15;
-    for (int m = 0; m < MT; ++m) {
-        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    f4 acc[MB];
+#pragma unroll
+    for (int t = 0; t < MB; ++t) {
+        acc[t] = f4{0.f, 0.f, 0.f, 0.f};
         if (bias) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const int o = 16 * m + 4 * q + e; acc[e] = o < nout ? bias[o] : 0.f; }
+            for (int e = 0; e < 4; ++e) { const int o = 16 * (m0 + t) + 4 * q + e; acc[t][e] = o < nout ? bias[o] : 0.f; }
         }
-        const float *fp = frag + (size_t)m * KS * 64 + lane;
-        int ks = 0;
-        for (; ks + 4 <= KS; ks += 4) {
-            float a[4], b[4];
+    }
+    const float *fa = fblk + lane;                 // + ((ks + u) * MB + t) * 64
+    const float *fb = in + q * RS + r;             // + (ks + u) * 4 * RS
+    float a0[MB][4], b0[4], a1[MB][4], b1[4], a2[MB][4], b2[4];
+    auto fetch = [&](float (&a)[MB][4], float (&b)[4], int ks) {
+        const float *pa = fa + ks * MB * 64, *pb = fb + ks * 4 * RS;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = fp[(ks + u) * 64];
-                const int kk = 4 * (ks + u) + q;
-                b[u] = kk < nin ? in[kk * RS + r] : 0.f;
-            }
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = mfma16(a[u], b[u], acc);
+            for (int t = 0; t < MB; ++t) a[t][u] = pa[(u * MB + t) * 64];
+            b[u] = pb[u * 4 * RS];
         }
-        for (; ks < KS; ++ks) {
-            const int kk = 4 * ks + q;
-            acc = mfma16(fp[ks * 64], kk < nin ? in[kk * RS + r] : 0.f, acc);
-        }
+    };
+    auto mul = [&](const float (&a)[MB][4], const float (&b)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < MB; ++t) acc[t] = mfma16(a[t][u], b[u], acc[t]);
+    };
+    // three named operand sets rotate: the fragments of two groups (2 x 16 MFMAs ~ 1000 cycles) are in flight while
+    // one multiplies -- an L2 hit under load takes about that long, and the wave's LDS image, not its registers,
+    // limits the occupancy, so nothing else would hide it
+    fetch(a0, b0, 0);
+    if (4 < KSp) fetch(a1, b1, 4);
+    for (int ks = 0; ks < KSp; ks += 12) {
+        if (ks + 8 < KSp) fetch(a2, b2, ks + 8);
+        mul(a0, b0);
+        if (ks + 4 >= KSp) break;
+        if (ks + 12 < KSp) fetch(a0, b0, ks + 12);
+        mul(a1, b1);
+        if (ks + 8 >= KSp) break;
+        if (ks + 16 < KSp) fetch(a1, b1, ks + 16);
+        mul(a2, b2);
+    }
+#pragma unroll
+    for (int t = 0; t < MB; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int o = 16 * m + 4 * q + e;
+            const int o = 16 * (m0 + t) + 4 * q + e;
             if (o < nout) {
-                float v = acc[e];
-                if (act >= 0) v = act_fwd(v, act);
+                float v = acc[t][e];
+                if (ACT >= 0) v = act_fwd(v, ACT);
                 if (ACCUM) out[o * RS + r] += v; else out[o * RS + r] = v;
             }
         }
-    }
+}
+
+template <bool ACCUM, int ACT>
+__device__ __forceinline__ void linear_act(const float *__restrict__ frag, int MT, int KSp, int nout, const float *in, float *out,
+                                           const float *__restrict__ bias, int lane) {
+    int m = 0;
+    for (; m + 4 <= MT; m += 4) linear_mb<ACCUM, 4, ACT>(frag + (size_t)m * KSp * 64, m, KSp, nout, in, out, bias, lane);
+    if (m + 2 <= MT) { linear_mb<ACCUM, 2, ACT>(frag + (size_t)m * KSp * 64, m, KSp, nout, in, out, bias, lane); m += 2; }
+    if (m < MT) linear_mb<ACCUM, 1, ACT>(frag + (size_t)m * KSp * 64, m, KSp, nout, in, out, bias, lane);
+}
+
+template <bool ACCUM>
+__device__ __forceinline__ void linear(const float *__restrict__ frag, int MT, int KSp, int nin, int nout, const float *in,
+                                       float *out, const float *__restrict__ bias, int act, int lane) {
+    (void)nin;
+    if (act < 0) linear_act<ACCUM, -1>(frag, MT, KSp, nout, in, out, bias, lane);
+    else if (act == RNVP_ACT_TANH) linear_act<ACCUM, RNVP_ACT_TANH>(frag, MT, KSp, nout, in, out, bias, lane);
+    else linear_act<ACCUM, RNVP_ACT_RELU>(frag, MT, KSp, nout, in, out, bias, lane);
 }
 
 // one s or t net, forward: Linear k reads buffer k-1's output; hidden activations go to hbuf + (KEEP ? running
@@ -154,6 +213,8 @@ k_lmm_flow(KShape s, LGeo g, const float *__restrict__ packed, const float *__re
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
     float *XC = lds, *H0 = XC + (d + cd) * RS, *H1 = H0 + g.hmax * RS, *T = H1 + g.hmax * RS, *S = T + d * RS;
+    for (int e = lane; e < (int)(g.lds_flow / sizeof(float)); e += 64) lds[e] = 0.f;      // see linear_mb: stale rows must be finite
+    wave_fence();
     const int64_t ntiles = (n + 15) / 16;
     const float prior_c = 0.5f * (float)d * kLog2Pi;
     float wave_sum = 0.f;
@@ -209,11 +270,18 @@ k_lmm_flow(KShape s, LGeo g, const float *__restrict__ packed, const float *__re
 // to ntot; feature `ones_at` (if >= 0) is written as 1 (the bias column of the weight-gradient product)
 __device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot, int ones_at, float *__restrict__ dst, int lane) {
     const int q = lane >> 4, r = lane & 15;
-    for (int f = q; f < ntot; f += 4) {
-        float v = 0.f;
-        if (f < nfeat) v = img[f * RS + r];
-        else if (f == ones_at) v = 1.f;
-        dst[f * 16 + r] = v;
+    for (int f0 = q; f0 < ntot; f0 += 16) {        // four features per lane and pass: the LDS reads overlap
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + 4 * u;
+            v[u] = f < nfeat ? img[f * RS + r] : (f == ones_at ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + 4 * u;
+            if (f < ntot) dst[f * 16 + r] = v[u];
+        }
     }
 }
 
@@ -227,6 +295,8 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
     const int lane = threadIdx.x, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
     float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
     float *GA = GIN + d * RS, *GB = GA + g.wmax * RS;
+    for (int e = lane; e < (int)(g.lds_train / sizeof(float)); e += 64) lds[e] = 0.f;     // see linear_mb: stale rows must be finite
+    wave_fence();
     const int64_t ntiles = (n + 15) / 16;
     const float prior_c = 0.5f * (float)d * kLog2Pi;
     float wave_sum = 0.f;
@@ -289,9 +359,17 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
                     if (k < nh) {
                         aoff -= nout;
                         const float *ak = ACT + aoff * RS;
-                        for (int f = q; f < nout; f += 4) {
-                            const float a = ak[f * RS + r], gv = gcur[f * RS + r];
-                            gcur[f * RS + r] = (s.act == RNVP_ACT_TANH) ? gv * (1.f - a * a) : (a > 0.f ? gv : 0.f);
+                        for (int f0 = q; f0 < nout; f0 += 16) {          // four features per pass: overlapped LDS reads
+                            float a[4], gv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int f = f0 + 4 * u < nout ? f0 + 4 * u : f0;
+                                a[u] = ak[f * RS + r]; gv[u] = gcur[f * RS + r];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (f0 + 4 * u < nout)
+                                    gcur[(f0 + 4 * u) * RS + r] = (s.act == RNVP_ACT_TANH) ? gv[u] * (1.f - a[u] * a[u]) : (a[u] > 0.f ? gv[u] : 0.f);
                         }
                         wave_fence();
                     }
@@ -391,8 +469,8 @@ LGeo make_lgeo(const KShape &k) {
     int oW = 0, oG = 0, oD = 0, pairs = 0;
     for (int i = 0; i < g.nlin; ++i) {
         g.nin[i] = k.nin[i]; g.nout[i] = k.nout[i];
-        g.MT[i] = (k.nout[i] + 15) / 16; g.KS[i] = (k.nin[i] + 3) / 4;
-        g.MTt[i] = ((i == 0 ? k.d : k.nin[i]) + 15) / 16; g.KSt[i] = (k.nout[i] + 3) / 4;
+        g.MT[i] = (k.nout[i] + 15) / 16; g.KS[i] = ((k.nin[i] + 3) / 4 + 3) / 4 * 4;          // k-steps padded to groups of 4
+        g.MTt[i] = ((i == 0 ? k.d : k.nin[i]) + 15) / 16; g.KSt[i] = ((k.nout[i] + 3) / 4 + 3) / 4 * 4;
         g.PT[i] = (k.nin[i] + 1 + 15) / 16;
         g.offF[i] = oW; oW += g.MT[i] * g.KS[i] * 64;
         g.offT[i] = oW; oW += g.MTt[i] * g.KSt[i] * 64;
@@ -404,8 +482,9 @@ LGeo make_lgeo(const KShape &k) {
     g.net_floats = oW; g.gnet_floats = oG; g.dump_floats = oD; g.pairs_per_net = pairs;
     g.hs = k.hs; g.hmax = k.hmax;
     g.wmax = k.hmax > k.d ? k.hmax : k.d;
-    g.lds_flow = (size_t)(3 * k.d + k.c + 2 * k.hmax) * RS * sizeof(float);
-    g.lds_train = (size_t)(k.d + k.c + k.hs + 4 * k.d + 2 * g.wmax) * RS * sizeof(float);
+    // + 16 slack rows: a padded k-group of the last buffer may read (and multiply by zero weights) up to 15 rows past it
+    g.lds_flow = (size_t)(3 * k.d + k.c + 2 * k.hmax + 16) * RS * sizeof(float);
+    g.lds_train = (size_t)(k.d + k.c + k.hs + 4 * k.d + 2 * g.wmax + 16) * RS * sizeof(float);
     return g;
 }
 
