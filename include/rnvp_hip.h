@@ -51,7 +51,7 @@ extern "C" {
 #define RNVP_PATH_GENERIC 0      /* any shape, VALU + LDS, one thread per row           */
 #define RNVP_PATH_MFMA    1      /* register-chained MFMA path (one hidden layer, alternating masks, d <= 64, cdim <= 16) */
 #define RNVP_PATH_LMM     2      /* any shape (several hidden layers, user masks, wide rows) on f32 MFMA with
-                                    LDS-resident activations; taken when the nets are wide enough to fill 16-wide tiles */
+                                    LDS-resident activations; taken whenever a 16-row tile's LDS image fits (<= 76 KB) */
 
 typedef struct rnvp_shape {
     int32_t L;                        /* n_layers                  realnvp.py:160,196   */
@@ -85,7 +85,7 @@ typedef struct rnvp_shape {
 
 int         rnvp_version(void);
 /* test / measurement aid, process-wide: which kernels serve the shapes outside RNVP_PATH_MFMA --
- * 0 automatic (RNVP_PATH_LMM for wide nets), 1 always RNVP_PATH_GENERIC, 2 RNVP_PATH_LMM whenever its LDS image fits */
+ * 0 automatic (= 2), 1 always RNVP_PATH_GENERIC, 2 RNVP_PATH_LMM whenever its LDS image fits */
 void        rnvp_generic_mode(int mode);
 const char *rnvp_status_string(int status);
 

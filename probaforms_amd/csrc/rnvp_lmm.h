@@ -15,7 +15,7 @@ struct LGeo {
     int offF[kMaxLin], offT[kMaxLin];      // float offsets of the fragment blocks inside one net's packed image
     int offG[kMaxLin];                     // ... of Linear k's [m][p][64 lanes][4] block inside one net's partial gradient
     int offA[kMaxLin], offP[kMaxLin];      // ... of the dumped input / pre-activation-gradient tiles of one (row tile, net)
-    int net_floats, gnet_floats, dump_floats, pairs_per_net;
+    int net_floats, gnet_floats, dump_floats, pairs_per_net, quads_per_net;
     int hs, hmax, wmax;
     size_t lds_flow, lds_train;            // bytes of one wave's LDS image
 };

@@ -4,8 +4,10 @@
 // layers (the reference's docstring example is hidden=(10, 20, 15): /root/reference/probaforms/models/realnvp.py:22-38),
 // user-supplied masks (realnvp.py:65-68), d > 64, cdim > 16 -- for nets wide enough that the one-thread-per-row VALU
 // kernels of rnvp_generic.hip fall off a cliff (hidden=(128, 128): 0.3 M rows/s in fit).  Design:
-//   * one WAVE owns one tile of 16 rows for the whole stack; its activations live in a wave-private LDS image
-//     [feature][17] (no barriers anywhere: DS operations of a wave execute in order);
+//   * one WORKGROUP of 4 waves owns one tile of 16 rows for the whole stack; its activations live in one LDS image
+//     [feature][17]; the waves split every Linear's out tiles (and the elementwise passes' features) among themselves,
+//     one workgroup barrier per Linear -- the image, not the registers, limits how many tiles a CU holds, so four
+//     waves per image is what gives the SIMDs something to overlap the fragment loads with;
 //   * every Linear is computed transposed, out^T[out x rows] = W[out x in] . act^T[in x rows], as
 //     v_mfma_f32_16x16x4_f32: A = weight fragments pre-packed per call into lane order (the layer's mask folded into
 //     the first Linear's x columns, so [x*mask || c] is never formed), B = the LDS image (ds_read_b32, conflict free),
@@ -29,6 +31,7 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 constexpr int RS = 17;                 // row stride of the LDS image [feature][RS]: 16 rows + 1 (bank spread for the row-contraction reads)
 constexpr int kMaxGrid = 4096;
 constexpr int kSplits = 64;            // row splits of the weight-gradient pass
+constexpr int kW = 4;                  // waves per workgroup (all on the same 16-row tile)
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void wave_fence() {
@@ -40,18 +43,18 @@ __device__ __forceinline__ void wave_fence() {
 // ---- weight packing -----------------------------------------------------------------------------------------------
 // Fragment value for out tile m, k-step ks, lane (q, i): forward W_k[16m + i][4ks + q]; transposed W_k[4ks + q][16m + i]
 // (for k == 0 only the x columns: C gets no gradient).  First Linear: x column j is multiplied by mask[l][j].
-// Layout of one Linear's fragments: out tiles in blocks of MB = 4 (then one of 2, one of 1), a block stored
+// Layout of one Linear's fragments: out tiles in blocks of MB = 2 (then one of 1; MB = 1 throughout for fewer than 8 tiles), a block stored
 // [k-step][tile in block][lane] with the k-steps padded to a multiple of 4 (zeros), so that the kernel's group of
-// 4 k-steps x MB tiles is MB * 4 loads at constant offsets from one base.
+// 4 k-steps x MB tiles is MB * 4 loads at constant offsets from one base.  Blocks go round-robin to the waves.
+// tiles per block of a Linear with MT out tiles: 2 where that still gives every wave a block, else 1
+__host__ __device__ __forceinline__ int block_tiles(int MT) { return MT >= 2 * kW ? 2 : 1; }
+
 __device__ __forceinline__ void block_decode(int o, int MT, int KSp, int *m, int *ks, int *lane) {
-    const int n4 = MT >> 2, rem = MT & 3, per = KSp * 64;
-    int MB, m0, oo;
-    if (o < n4 * 4 * per) { MB = 4; m0 = 4 * (o / (4 * per)); oo = o % (4 * per); }
-    else {
-        oo = o - n4 * 4 * per; m0 = 4 * n4;
-        if (rem >= 2 && oo < 2 * per) MB = 2;
-        else { if (rem >= 2) { oo -= 2 * per; m0 += 2; } MB = 1; }
-    }
+    const int per = KSp * 64;
+    int MB = block_tiles(MT), m0, oo;
+    const int nb = MT / MB;                       // full blocks; a last single tile follows when MB == 2 and MT is odd
+    if (o < nb * MB * per) { m0 = MB * (o / (MB * per)); oo = o % (MB * per); }
+    else { m0 = nb * MB; oo = o - nb * MB * per; MB = 1; }
     *lane = oo & 63;
     const int rest = oo >> 6;
     *m = m0 + rest % MB;
@@ -156,34 +159,37 @@ __device__ __forceinline__ void linear_mb(const float *__restrict__ fblk, int m0
 
 template <bool ACCUM, int ACT>
 __device__ __forceinline__ void linear_act(const float *__restrict__ frag, int MT, int KSp, int nout, const float *in, float *out,
-                                           const float *__restrict__ bias, int lane) {
-    int m = 0;
-    for (; m + 4 <= MT; m += 4) linear_mb<ACCUM, 4, ACT>(frag + (size_t)m * KSp * 64, m, KSp, nout, in, out, bias, lane);
-    if (m + 2 <= MT) { linear_mb<ACCUM, 2, ACT>(frag + (size_t)m * KSp * 64, m, KSp, nout, in, out, bias, lane); m += 2; }
-    if (m < MT) linear_mb<ACCUM, 1, ACT>(frag + (size_t)m * KSp * 64, m, KSp, nout, in, out, bias, lane);
+                                           const float *__restrict__ bias, int lane, int wave) {
+    if (block_tiles(MT) == 2) {
+        const int n2 = MT >> 1;
+        for (int b = wave; b < n2; b += kW) linear_mb<ACCUM, 2, ACT>(frag + (size_t)b * 2 * KSp * 64, 2 * b, KSp, nout, in, out, bias, lane);
+        if ((MT & 1) && wave == n2 % kW) linear_mb<ACCUM, 1, ACT>(frag + (size_t)n2 * 2 * KSp * 64, 2 * n2, KSp, nout, in, out, bias, lane);
+    } else {
+        for (int b = wave; b < MT; b += kW) linear_mb<ACCUM, 1, ACT>(frag + (size_t)b * KSp * 64, b, KSp, nout, in, out, bias, lane);
+    }
 }
 
 template <bool ACCUM>
 __device__ __forceinline__ void linear(const float *__restrict__ frag, int MT, int KSp, int nin, int nout, const float *in,
-                                       float *out, const float *__restrict__ bias, int act, int lane) {
+                                       float *out, const float *__restrict__ bias, int act, int lane, int wave) {
     (void)nin;
-    if (act < 0) linear_act<ACCUM, -1>(frag, MT, KSp, nout, in, out, bias, lane);
-    else if (act == RNVP_ACT_TANH) linear_act<ACCUM, RNVP_ACT_TANH>(frag, MT, KSp, nout, in, out, bias, lane);
-    else linear_act<ACCUM, RNVP_ACT_RELU>(frag, MT, KSp, nout, in, out, bias, lane);
+    if (act < 0) linear_act<ACCUM, -1>(frag, MT, KSp, nout, in, out, bias, lane, wave);
+    else if (act == RNVP_ACT_TANH) linear_act<ACCUM, RNVP_ACT_TANH>(frag, MT, KSp, nout, in, out, bias, lane, wave);
+    else linear_act<ACCUM, RNVP_ACT_RELU>(frag, MT, KSp, nout, in, out, bias, lane, wave);
 }
 
 // one s or t net, forward: Linear k reads buffer k-1's output; hidden activations go to hbuf + (KEEP ? running
 // offset : ping-pong between hbuf and hbuf2); the last Linear writes `out` [d]
 template <bool KEEP>
 __device__ __forceinline__ void net_fwd(const float *__restrict__ pk, const float *__restrict__ pn, const KShape &s,
-                                        const LGeo &g, const float *xc, float *hbuf, float *hbuf2, float *out, int lane) {
+                                        const LGeo &g, const float *xc, float *hbuf, float *hbuf2, float *out, int lane, int wave) {
     const float *cur = xc;
     float *dst = hbuf;
     for (int k = 0; k < g.nlin; ++k) {
         const bool last = k == g.nlin - 1;
         float *ob = last ? out : dst;
-        linear<false>(pk + g.offF[k], g.MT[k], g.KS[k], g.nin[k], g.nout[k], cur, ob, pn + s.boff[k], last ? -1 : s.act, lane);
-        wave_fence();
+        linear<false>(pk + g.offF[k], g.MT[k], g.KS[k], g.nin[k], g.nout[k], cur, ob, pn + s.boff[k], last ? -1 : s.act, lane, wave);
+        __syncthreads();
         cur = ob;
         if (!last) {
             if (KEEP) dst += g.nout[k] * RS;
@@ -194,8 +200,8 @@ __device__ __forceinline__ void net_fwd(const float *__restrict__ pk, const floa
 
 // rows of one tile <-> LDS image; element e = lane + 64 t of the 16 x w block (coalesced when the rows are contiguous)
 __device__ __forceinline__ void load_tile(const float *__restrict__ src, const int64_t *__restrict__ row_index, int64_t base,
-                                          int64_t n, int w, float *img, int lane) {
-    for (int e = lane; e < 16 * w; e += 64) {
+                                          int64_t n, int w, float *img, int tid) {
+    for (int e = tid; e < 16 * w; e += 64 * kW) {
         const int rr = e / w, j = e - rr * w;
         const int64_t row = base + rr;
         float v = 0.f;
@@ -204,73 +210,91 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ src, const i
     }
 }
 
+// cross-wave sum of a per-row value: every lane holds a partial for row r (already reduced over the lane groups q);
+// `red` is a kW x 16 scratch in LDS; the result is returned to the lanes of wave 0 (other waves get garbage)
+__device__ __forceinline__ float wg_row_sum(float v, float *red, int lane, int wave) {
+    const int q = lane >> 4, r = lane & 15;
+    if (q == 0) red[wave * 16 + r] = v;
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) a += red[w * 16 + r];
+    __syncthreads();
+    return a;
+}
+
 // ---- forward (+ log-det + prior) / inverse ----------------------------------------------------------------------------
 template <bool INVERSE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kW)
 k_lmm_flow(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
            const uint8_t *__restrict__ masks, const float *x, const float *__restrict__ c,
            const int64_t *__restrict__ row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out, float *part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
     float *XC = lds, *H0 = XC + (d + cd) * RS, *H1 = H0 + g.hmax * RS, *T = H1 + g.hmax * RS, *S = T + d * RS;
-    for (int e = lane; e < (int)(g.lds_flow / sizeof(float)); e += 64) lds[e] = 0.f;      // see linear_mb: stale rows must be finite
-    wave_fence();
+    float *RED = lds + g.lds_flow / sizeof(float) - 2 * kW * 16;
+    for (int e = tid; e < (int)(g.lds_flow / sizeof(float)); e += 64 * kW) lds[e] = 0.f;      // see linear_mb: stale rows must be finite
+    __syncthreads();
     const int64_t ntiles = (n + 15) / 16;
     const float prior_c = 0.5f * (float)d * kLog2Pi;
     float wave_sum = 0.f;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * 16;
-        load_tile(x, row_index, base, n, d, XC, lane);
-        if (cd) load_tile(c, row_index, base, n, cd, XC + d * RS, lane);
-        wave_fence();
+        load_tile(x, row_index, base, n, d, XC, tid);
+        if (cd) load_tile(c, row_index, base, n, cd, XC + d * RS, tid);
+        __syncthreads();
         float ld = 0.f;
         for (int lp = 0; lp < s.L; ++lp) {
             const int l = INVERSE ? s.L - 1 - lp : lp;
             const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
-            net_fwd<false>(pk, pn, s, g, XC, H0, H1, T, lane);
-            net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, H0, H1, S, lane);
+            net_fwd<false>(pk, pn, s, g, XC, H0, H1, T, lane, wave);
+            net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, H0, H1, S, lane, wave);
             const uint8_t *m = masks + l * d;
-            for (int j = q; j < d; j += 4) {
+            for (int j = q + 4 * wave; j < d; j += 4 * kW) {
                 if (!m[j]) {
                     const float sv = S[j * RS + r], tv = T[j * RS + r], xv = XC[j * RS + r];
                     if (INVERSE) XC[j * RS + r] = (xv - tv) * expf(-sv);
                     else { XC[j * RS + r] = fmaf(xv, expf(sv), tv); ld += sv; }
                 }
             }
-            wave_fence();
+            __syncthreads();
         }
         const int64_t row = base + r;
         const bool valid = row < n;
         if (out_x) {
-            for (int e = lane; e < 16 * d; e += 64) {
+            for (int e = tid; e < 16 * d; e += 64 * kW) {
                 const int rr = e / d, j = e - rr * d;
                 if (base + rr < n) out_x[(base + rr) * d + j] = XC[j * RS + rr];
             }
         }
         if (!INVERSE) {
             float ss = 0.f;
-            for (int j = q; j < d; j += 4) { const float zv = XC[j * RS + r]; ss = fmaf(zv, zv, ss); }
+            for (int j = q + 4 * wave; j < d; j += 4 * kW) { const float zv = XC[j * RS + r]; ss = fmaf(zv, zv, ss); }
             ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
             ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-            const float lpv = ld + (-0.5f * ss - prior_c);
-            if (valid && q == 0) {
-                if (logdet_out) logdet_out[row] = ld;
-                if (logp_out) logp_out[row] = lpv;
+            ld = wg_row_sum(ld, RED, lane, wave);
+            ss = wg_row_sum(ss, RED + kW * 16, lane, wave);
+            if (wave == 0) {
+                const float lpv = ld + (-0.5f * ss - prior_c);
+                if (valid && q == 0) {
+                    if (logdet_out) logdet_out[row] = ld;
+                    if (logp_out) logp_out[row] = lpv;
+                }
+                float v = (valid && q == 0) ? lpv : 0.f;
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                wave_sum += v;
             }
-            float v = (valid && q == 0) ? lpv : 0.f;
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            wave_sum += v;
         }
-        wave_fence();
+        __syncthreads();
     }
-    if (!INVERSE && part && lane == 0) part[blockIdx.x] = wave_sum;
+    if (!INVERSE && part && tid == 0) part[blockIdx.x] = wave_sum;
 }
 
 // [feature][RS] image -> [feature][16] tile in global memory, nfeat real features padded with `pad` zero features up
 // to ntot; feature `ones_at` (if >= 0) is written as 1 (the bias column of the weight-gradient product)
-__device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot, int ones_at, float *__restrict__ dst, int lane) {
+__device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot, int ones_at, float *__restrict__ dst, int lane, int wave) {
     const int q = lane >> 4, r = lane & 15;
-    for (int f0 = q; f0 < ntot; f0 += 16) {        // four features per lane and pass: the LDS reads overlap
+    for (int f0 = q + 16 * wave; f0 < ntot; f0 += 16 * kW) {        // four features per lane and pass: the LDS reads overlap
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -286,64 +310,70 @@ __device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot,
 }
 
 // ---- loss + input-gradient chain; dumps the operands of the weight gradients -------------------------------------------
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kW)
 k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
             const uint8_t *__restrict__ masks, const float *__restrict__ x, const float *__restrict__ c,
             const int64_t *__restrict__ row_index, int64_t n, float inv_B, const float *__restrict__ gz,
             float *__restrict__ dump, float *__restrict__ xsave, float *losspart) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
+    const int jq = q + 4 * wave, jstep = 4 * kW;           // this lane's features in the elementwise passes
     float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
     float *GA = GIN + d * RS, *GB = GA + g.wmax * RS;
-    for (int e = lane; e < (int)(g.lds_train / sizeof(float)); e += 64) lds[e] = 0.f;     // see linear_mb: stale rows must be finite
-    wave_fence();
+    float *RED = lds + g.lds_train / sizeof(float) - 2 * kW * 16;
+    for (int e = tid; e < (int)(g.lds_train / sizeof(float)); e += 64 * kW) lds[e] = 0.f;     // see linear_mb: stale rows must be finite
+    __syncthreads();
     const int64_t ntiles = (n + 15) / 16;
     const float prior_c = 0.5f * (float)d * kLog2Pi;
     float wave_sum = 0.f;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * 16, row = base + r;
         const bool valid = row < n;
-        load_tile(x, row_index, base, n, d, XC, lane);
-        if (cd) load_tile(c, row_index, base, n, cd, XC + d * RS, lane);
-        wave_fence();
+        load_tile(x, row_index, base, n, d, XC, tid);
+        if (cd) load_tile(c, row_index, base, n, cd, XC + d * RS, tid);
+        __syncthreads();
         float *xs = xsave + (size_t)tile * s.L * d * 16;
         float ld = 0.f;
         for (int l = 0; l < s.L; ++l) {
             const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
-            for (int j = q; j < d; j += 4) xs[(l * d + j) * 16 + r] = XC[j * RS + r];        // layer input, for the backward
-            net_fwd<false>(pk, pn, s, g, XC, GA, GB, T, lane);
-            net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, GA, GB, S, lane);
+            for (int j = jq; j < d; j += jstep) xs[(l * d + j) * 16 + r] = XC[j * RS + r];        // layer input, for the backward
+            net_fwd<false>(pk, pn, s, g, XC, GA, GB, T, lane, wave);
+            net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, GA, GB, S, lane, wave);
             const uint8_t *m = masks + l * d;
-            for (int j = q; j < d; j += 4)
+            for (int j = jq; j < d; j += jstep)
                 if (!m[j]) { const float sv = S[j * RS + r]; XC[j * RS + r] = fmaf(XC[j * RS + r], expf(sv), T[j * RS + r]); ld += sv; }
-            wave_fence();
+            __syncthreads();
         }
         {   // loss terms and the seed of the backward
             float ss = 0.f;
-            for (int j = q; j < d; j += 4) { const float zv = XC[j * RS + r]; ss = fmaf(zv, zv, ss); }
+            for (int j = jq; j < d; j += jstep) { const float zv = XC[j * RS + r]; ss = fmaf(zv, zv, ss); }
             ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
             ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-            const float lpv = gz ? ld : ld + (-0.5f * ss - prior_c);
-            float v = (valid && q == 0) ? lpv : 0.f;
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            wave_sum += v;
-            for (int j = q; j < d; j += 4)
+            ld = wg_row_sum(ld, RED, lane, wave);
+            ss = wg_row_sum(ss, RED + kW * 16, lane, wave);
+            if (wave == 0) {
+                const float lpv = gz ? ld : ld + (-0.5f * ss - prior_c);
+                float v = (valid && q == 0) ? lpv : 0.f;
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                wave_sum += v;
+            }
+            for (int j = jq; j < d; j += jstep)
                 GY[j * RS + r] = valid ? (gz ? gz[row * d + j] : XC[j * RS + r] * inv_B) : 0.f;
         }
         const float gld = valid ? -inv_B : 0.f;
-        wave_fence();
+        __syncthreads();
         for (int l = s.L - 1; l >= 0; --l) {
             const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
             const uint8_t *m = masks + l * d;
             float *dl = dump + ((size_t)tile * s.L + l) * 2 * g.dump_floats;
-            for (int j = q; j < d; j += 4) { XC[j * RS + r] = xs[(l * d + j) * 16 + r]; GIN[j * RS + r] = 0.f; }
-            wave_fence();
+            for (int j = jq; j < d; j += jstep) { XC[j * RS + r] = xs[(l * d + j) * 16 + r]; GIN[j * RS + r] = 0.f; }
+            __syncthreads();
             for (int net = 1; net >= 0; --net) {                     // s first (its output is needed for exp(s)), then t
                 const float *pkn = pk + net * g.net_floats, *pnn = pn + (size_t)net * s.npn;
                 float *dn = dl + (size_t)net * g.dump_floats;
-                net_fwd<true>(pkn, pnn, s, g, XC, ACT, nullptr, net ? S : T, lane);
+                net_fwd<true>(pkn, pnn, s, g, XC, ACT, nullptr, net ? S : T, lane, wave);
                 // d loss / d (net output): s: (1-m)(gy x e^s + gld), t: (1-m) gy
-                for (int j = q; j < d; j += 4) {
+                for (int j = jq; j < d; j += jstep) {
                     float v = 0.f;
                     if (!m[j]) {
                         const float gy = GY[j * RS + r];
@@ -351,7 +381,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
                     }
                     GA[j * RS + r] = v;
                 }
-                wave_fence();
+                __syncthreads();
                 float *gcur = GA, *gprev = GB;
                 int aoff = g.hs;                                       // running feature offset of Linear k's own activation block
                 for (int k = nh; k >= 0; --k) {
@@ -359,7 +389,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
                     if (k < nh) {
                         aoff -= nout;
                         const float *ak = ACT + aoff * RS;
-                        for (int f0 = q; f0 < nout; f0 += 16) {          // four features per pass: overlapped LDS reads
+                        for (int f0 = q + 16 * wave; f0 < nout; f0 += 16 * kW) {          // four features per pass: overlapped LDS reads
                             float a[4], gv[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
@@ -371,52 +401,71 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
                                 if (f0 + 4 * u < nout)
                                     gcur[(f0 + 4 * u) * RS + r] = (s.act == RNVP_ACT_TANH) ? gv[u] * (1.f - a[u] * a[u]) : (a[u] > 0.f ? gv[u] : 0.f);
                         }
-                        wave_fence();
+                        __syncthreads();
                     }
                     const float *inp = (k == 0) ? XC : ACT + (aoff - nin) * RS;
-                    dump_tile(gcur, nout, 16 * g.MT[k], -1, dn + g.offP[k], lane);
-                    dump_tile(inp, nin, 16 * g.PT[k], nin, dn + g.offA[k], lane);
+                    dump_tile(gcur, nout, 16 * g.MT[k], -1, dn + g.offP[k], lane, wave);
+                    dump_tile(inp, nin, 16 * g.PT[k], nin, dn + g.offA[k], lane, wave);
                     // input gradient: for Linear 0 only the x part, added into GIN (the mask is folded into the fragments)
-                    if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, d, gcur, GIN, nullptr, -1, lane);
-                    else linear<false>(pkn + g.offT[k], g.MTt[k], g.KSt[k], nout, nin, gcur, gprev, nullptr, -1, lane);
-                    wave_fence();
+                    if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, d, gcur, GIN, nullptr, -1, lane, wave);
+                    else linear<false>(pkn + g.offT[k], g.MTt[k], g.KSt[k], nout, nin, gcur, gprev, nullptr, -1, lane, wave);
+                    __syncthreads();
                     float *tmp = gcur; gcur = gprev; gprev = tmp;
                 }
             }
-            for (int j = q; j < d; j += 4) {
+            for (int j = jq; j < d; j += jstep) {
                 const float gy = GY[j * RS + r];
                 GY[j * RS + r] = (m[j] ? gy : gy * expf(S[j * RS + r])) + GIN[j * RS + r];
             }
-            wave_fence();
+            __syncthreads();
         }
     }
-    if (lane == 0) losspart[blockIdx.x] = wave_sum;
+    if (tid == 0) losspart[blockIdx.x] = wave_sum;
 }
 
 // ---- weight gradients: dW[k] tile (m, p) = sum over rows gP[row][16m + i] * act[row][16p + j] ---------------------------
-// one wave per (layer, net, Linear, m, p) and row split; operands are the [feature][16 rows] tiles dumped above, read as
-// one float4 per lane (rows 4q .. 4q+3 of feature i): k-step ks of lane group q stands for row 4q + ks on both sides
+// one wave per (layer, net, Linear, 2 x 2 block of tile pairs) and row split; operands are the [feature][16 rows] tiles
+// dumped above, read as one float4 per lane (rows 4q .. 4q+3 of feature i): k-step ks of lane group q stands for row
+// 4q + ks on both sides.  The 2 x 2 block takes 4 loads of 1 KiB per 16 MFMAs instead of 8.
 __global__ void __launch_bounds__(64)
 k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, float *__restrict__ gpart) {
     const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
-    int pair = blockIdx.x;
-    const int ln = pair / g.pairs_per_net;
-    pair -= ln * g.pairs_per_net;
+    int quad = blockIdx.x;
+    const int ln = quad / g.quads_per_net;
+    quad -= ln * g.quads_per_net;
     int k = 0;
-    while (k + 1 < g.nlin && pair >= g.MT[k] * g.PT[k]) { pair -= g.MT[k] * g.PT[k]; ++k; }
-    const int m = pair / g.PT[k], p = pair - m * g.PT[k];
+    while (k + 1 < g.nlin && quad >= ((g.MT[k] + 1) >> 1) * ((g.PT[k] + 1) >> 1)) { quad -= ((g.MT[k] + 1) >> 1) * ((g.PT[k] + 1) >> 1); ++k; }
+    const int pb2 = (g.PT[k] + 1) >> 1;
+    const int m0 = 2 * (quad / pb2), p0 = 2 * (quad % pb2);
+    const bool m1 = m0 + 1 < g.MT[k], p1 = p0 + 1 < g.PT[k];
     const size_t tstride = (size_t)s.L * 2 * g.dump_floats;
-    const float *pa = dump + (size_t)ln * g.dump_floats + g.offP[k] + m * 256 + i * 16 + 4 * q;
-    const float *pb = dump + (size_t)ln * g.dump_floats + g.offA[k] + p * 256 + i * 16 + 4 * q;
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t t = blockIdx.y; t < ntiles; t += gridDim.y) {
-        const f4 a = *reinterpret_cast<const f4 *>(pa + (size_t)t * tstride);
-        const f4 b = *reinterpret_cast<const f4 *>(pb + (size_t)t * tstride);
+    const float *pa = dump + (size_t)ln * g.dump_floats + g.offP[k] + m0 * 256 + i * 16 + 4 * q;
+    const float *pb = dump + (size_t)ln * g.dump_floats + g.offA[k] + p0 * 256 + i * 16 + 4 * q;
+    f4 acc[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = mfma16(a[ks], b[ks], acc);
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = blockIdx.y; t < ntiles; t += gridDim.y) {
+        const f4 a0 = *reinterpret_cast<const f4 *>(pa + (size_t)t * tstride);
+        const f4 a1 = m1 ? *reinterpret_cast<const f4 *>(pa + (size_t)t * tstride + 256) : zero;
+        const f4 b0 = *reinterpret_cast<const f4 *>(pb + (size_t)t * tstride);
+        const f4 b1 = p1 ? *reinterpret_cast<const f4 *>(pb + (size_t)t * tstride + 256) : zero;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][0] = mfma16(a0[ks], b0[ks], acc[0][0]);
+            acc[0][1] = mfma16(a0[ks], b1[ks], acc[0][1]);
+            acc[1][0] = mfma16(a1[ks], b0[ks], acc[1][0]);
+            acc[1][1] = mfma16(a1[ks], b1[ks], acc[1][1]);
+        }
     }
-    float *dst = gpart + ((size_t)blockIdx.y * s.L * 2 + ln) * g.gnet_floats + g.offG[k] + (m * g.PT[k] + p) * 256 + lane * 4;
-    *reinterpret_cast<f4 *>(dst) = acc;
+    float *dst = gpart + ((size_t)blockIdx.y * s.L * 2 + ln) * g.gnet_floats + g.offG[k] + lane * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if ((a == 0 || m1) && (b == 0 || p1)) *reinterpret_cast<f4 *>(dst + ((m0 + a) * g.PT[k] + p0 + b) * 256) = acc[a][b];
 }
 
 // flat reference-order gradient: sum of the row splits in index order; loss = -(sum of wave partials) * inv_B
@@ -466,7 +515,7 @@ LGeo make_lgeo(const KShape &k) {
     LGeo g;
     std::memset(&g, 0, sizeof(g));
     g.nlin = k.nh + 1;
-    int oW = 0, oG = 0, oD = 0, pairs = 0;
+    int oW = 0, oG = 0, oD = 0, pairs = 0, quads = 0;
     for (int i = 0; i < g.nlin; ++i) {
         g.nin[i] = k.nin[i]; g.nout[i] = k.nout[i];
         g.MT[i] = (k.nout[i] + 15) / 16; g.KS[i] = ((k.nin[i] + 3) / 4 + 3) / 4 * 4;          // k-steps padded to groups of 4
@@ -478,28 +527,31 @@ LGeo make_lgeo(const KShape &k) {
         g.offA[i] = oD; oD += g.PT[i] * 256;
         g.offP[i] = oD; oD += g.MT[i] * 256;
         pairs += g.MT[i] * g.PT[i];
+        quads += ((g.MT[i] + 1) / 2) * ((g.PT[i] + 1) / 2);
     }
+    g.quads_per_net = quads;
     g.net_floats = oW; g.gnet_floats = oG; g.dump_floats = oD; g.pairs_per_net = pairs;
     g.hs = k.hs; g.hmax = k.hmax;
     g.wmax = k.hmax > k.d ? k.hmax : k.d;
     // + 16 slack rows: a padded k-group of the last buffer may read (and multiply by zero weights) up to 15 rows past it
-    g.lds_flow = (size_t)(3 * k.d + k.c + 2 * k.hmax + 16) * RS * sizeof(float);
-    g.lds_train = (size_t)(k.d + k.c + k.hs + 4 * k.d + 2 * g.wmax + 16) * RS * sizeof(float);
+    // ... then 2 x kW x 16 floats of cross-wave reduction scratch at the very end
+    g.lds_flow = ((size_t)(3 * k.d + k.c + 2 * k.hmax + 16) * RS + 2 * kW * 16) * sizeof(float);
+    g.lds_train = ((size_t)(k.d + k.c + k.hs + 4 * k.d + 2 * g.wmax + 16) * RS + 2 * kW * 16) * sizeof(float);
     return g;
 }
 
 void set_mode(int mode) { g_mode.store(mode, std::memory_order_relaxed); }
 
-// auto: the nets must be wide enough for 16-wide tiles to pay (else the VALU kernels' thread-per-row form is as good and
-// needs fewer launches), and a wave's LDS image must leave room for at least two waves per CU
+// auto: whenever a tile's LDS image leaves room for at least two workgroups per CU.  Measured against the VALU kernels
+// (rnvp_generic.hip) the MFMA form wins at every width and batch size tried -- hidden=(10,20,15), d=2, batch 32:
+// 245 vs 1368 us per training step; hidden=(128,128), 65536 rows: 3.9 vs 217 ms -- so those remain only for shapes whose
+// image does not fit (and as the second implementation the tests pin this one against).
 bool use_lmm(const KShape &k, int op) {
     const int mode = g_mode.load(std::memory_order_relaxed);
     if (mode == 1) return false;
     const LGeo g = make_lgeo(k);
     const size_t need = op == RNVP_OP_TRAIN ? g.lds_train : g.lds_flow;
-    if (need > 76 * 1024) return false;
-    if (mode == 2) return true;
-    return k.hmax >= 32 || k.d + k.c >= 32;
+    return need <= 76 * 1024;
 }
 
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
@@ -536,7 +588,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const uint8_t 
     rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_flow<false>), 160 * 1024, g_attr_fwd);
     if (rc) return rc;
     const int G = grid_for((n + 15) / 16);
-    hipLaunchKernelGGL(k_lmm_flow<false>, dim3(G), dim3(64), g.lds_flow, st, k, g, packed, params, masks, x, c, row_index, n,
+    hipLaunchKernelGGL(k_lmm_flow<false>, dim3(G), dim3(64 * kW), g.lds_flow, st, k, g, packed, params, masks, x, c, row_index, n,
                        z_out, logdet_out, logp_out, part);
     RNVP_HIP_TRY(hipGetLastError());
     if (logp_sum) return generic_reduce_partials(st, nullptr, part, G, 0, 1.0f, nullptr, logp_sum);
@@ -552,7 +604,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
     if (rc) return rc;
     rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_flow<true>), 160 * 1024, g_attr_inv);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lmm_flow<true>, dim3(grid_for((n + 15) / 16)), dim3(64), g.lds_flow, st, k, g, packed, params, masks, z,
+    hipLaunchKernelGGL(k_lmm_flow<true>, dim3(grid_for((n + 15) / 16)), dim3(64 * kW), g.lds_flow, st, k, g, packed, params, masks, z,
                        c, nullptr, n, x_out, nullptr, nullptr, nullptr);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -578,11 +630,11 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_
     const int S = (int)(ntiles < kSplits ? ntiles : kSplits);
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);
-        hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64), g.lds_train, st, k, g, packed, params, masks, x, c, row_index, n, inv_B,
+        hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64 * kW), g.lds_train, st, k, g, packed, params, masks, x, c, row_index, n, inv_B,
                            gz, dump, xsave, losspart);
     }
     RNVP_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)(k.L * 2 * g.pairs_per_net), (unsigned)S), dim3(64), 0, st, k, g, dump, ntiles, gpart);
+    hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)(k.L * 2 * g.quads_per_net), (unsigned)S), dim3(64), 0, st, k, g, dump, ntiles, gpart);
     RNVP_HIP_TRY(hipGetLastError());
     const size_t P = (size_t)2 * k.npn * k.L;
     hipLaunchKernelGGL(k_lmm_reduce, dim3((unsigned)(P / 256 + 2)), dim3(256), 0, st, k, g, gpart, S, masks, losspart, G, inv_B,

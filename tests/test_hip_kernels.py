@@ -586,3 +586,32 @@ def test_shape_sweep_vs_oracle(L, d, c, h, n, act, prec, oracle32, oracle64):
     go = np.asarray(go, np.float64)
     assert abs(float(loss) - float(lo)) < 1e-5 * max(1.0, abs(float(lo)))
     assert np.abs(grad.cpu().numpy() - go).max() < 5e-6 * np.abs(go).max() + 1e-9
+
+
+def test_auto_mode_takes_lmm_for_generic_shapes_and_is_bitwise_reproducible():
+    """several hidden layers / user masks / wide rows go to the any-shape MFMA kernels by default; their training step
+    (input-gradient chain in-kernel, weight gradients over fixed row splits) gives identical bits run to run"""
+    from probaforms_amd import _hip
+    _hip.generic_mode(0)
+    for L, d, c, hidden, n in [(4, 6, 2, (12, 20), 5000), (3, 80, 20, (24,), 3000), (8, 16, 4, (128, 128), 20000)]:
+        sh, p, rng = _rand_flow(L, d, c, hidden, "tanh", 5)
+        masks = rng.integers(0, 2, (L, d)).astype(np.uint8)
+        for op in (_hip.OP_FORWARD, _hip.OP_INVERSE, _hip.OP_TRAIN):
+            assert _hip.kernel_path(sh, masks, op) == _hip.PATH_LMM
+        P = p.size
+        x = _dev(rng.standard_normal((n, d)).astype(np.float32)); cc = _dev(rng.standard_normal((n, c)).astype(np.float32))
+        mk = _dev(masks, torch.uint8)
+        ws = _ws(_hip, sh, _hip.OP_TRAIN, n)
+        outs = []
+        for _ in range(2):
+            pp = _dev(p); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+            g = torch.empty(P, device="cuda"); loss = torch.empty(2, device="cuda")
+            for step in (1, 2):
+                _hip.train_step(sh, pp, mk, x, cc, None, n, 1.0 / n, g, loss[step - 1:step], m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, ws)
+            outs.append((pp, m, v, g, loss))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert torch.isfinite(outs[0][4]).all()
+    # a shape whose 16-row LDS image does not fit falls back to the one-thread-per-row kernels
+    big = _hip.RnvpShape.make(2, 16, 4, (512, 512, 512), "tanh", alt_masks=0)
+    assert _hip.kernel_path(big, None, _hip.OP_TRAIN) == _hip.PATH_GENERIC
