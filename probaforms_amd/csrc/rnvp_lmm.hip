@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64 * kW)
 k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
             const uint8_t *__restrict__ masks, const float *__restrict__ x, const float *__restrict__ c,
             const int64_t *__restrict__ row_index, int64_t n, float inv_B, const float *__restrict__ gz,
-            float *__restrict__ dump, float *__restrict__ xsave, float *losspart) {
+            float *__restrict__ dump, float *__restrict__ xsave, float *losspart, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
     const int jq = q + 4 * wave, jstep = 4 * kW;           // this lane's features in the elementwise passes
@@ -420,7 +420,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             __syncthreads();
         }
     }
-    if (tid == 0) losspart[blockIdx.x] = wave_sum;
+    if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;      // chunks run in order on one stream
 }
 
 // ---- weight gradients: dW[k] tile (m, p) = sum over rows gP[row][16m + i] * act[row][16p + j] ---------------------------
@@ -428,7 +428,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
 // dumped above, read as one float4 per lane (rows 4q .. 4q+3 of feature i): k-step ks of lane group q stands for row
 // 4q + ks on both sides.  The 2 x 2 block takes 4 loads of 1 KiB per 16 MFMAs instead of 8.
 __global__ void __launch_bounds__(64)
-k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, float *__restrict__ gpart) {
+k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, float *__restrict__ gpart, int accumulate) {
     const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
     int quad = blockIdx.x;
     const int ln = quad / g.quads_per_net;
@@ -465,7 +465,10 @@ k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, fl
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-            if ((a == 0 || m1) && (b == 0 || p1)) *reinterpret_cast<f4 *>(dst + ((m0 + a) * g.PT[k] + p0 + b) * 256) = acc[a][b];
+            if ((a == 0 || m1) && (b == 0 || p1)) {
+                f4 *o = reinterpret_cast<f4 *>(dst + ((m0 + a) * g.PT[k] + p0 + b) * 256);
+                *o = accumulate ? *o + acc[a][b] : acc[a][b];          // row chunks of one call, in order: deterministic
+            }
 }
 
 // flat reference-order gradient: sum of the row splits in index order; loss = -(sum of wave partials) * inv_B
@@ -554,14 +557,25 @@ bool use_lmm(const KShape &k, int op) {
     return need <= 76 * 1024;
 }
 
+// rows per pass of the training kernels: the dumped weight-gradient operands take dump_floats * L * 2 / 16 floats per
+// row (38 KB for hidden = (128,128), L = 8), so a big batch is processed in row chunks that keep them under ~1 GiB
+static int64_t chunk_rows(const KShape &k, const LGeo &g) {
+    const double per_row = (double)k.L * 2 * g.dump_floats * sizeof(float) / 16.0;
+    int64_t r = (int64_t)((1u << 30) / per_row) / 16 * 16;
+    if (r < 4096) r = 4096;
+    if (r > 65536) r = 65536;
+    return r;
+}
+
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
     const LGeo g = make_lgeo(k);
-    const int64_t ntiles = (max_rows + 15) / 16;
     size_t b = align_up((size_t)k.L * 2 * g.net_floats * sizeof(float), 256);                       // packed weights
     b += align_up((size_t)kMaxGrid * sizeof(float), 256);                                           // per-wave loss / log-prob partials
     if (op == RNVP_OP_TRAIN) {
-        b += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);               // wgrad operands
-        b += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);                        // layer inputs
+        const int64_t cr = chunk_rows(k, g);
+        const int64_t ntiles = ((max_rows < cr ? max_rows : cr) + 15) / 16;
+        b += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);               // wgrad operands of one chunk
+        b += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);                        // layer inputs of one chunk
         b += align_up((size_t)kSplits * k.L * 2 * g.gnet_floats * sizeof(float), 256);              // split partials
     }
     return b;
@@ -615,27 +629,38 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_
               const float *gz) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
     const LGeo g = make_lgeo(k);
-    const int64_t ntiles = (n + 15) / 16;
+    const int64_t cr = chunk_rows(k, g);
+    const int64_t ctiles = ((n < cr ? n : cr) + 15) / 16;
     char *w = static_cast<char *>(ws);
     float *packed = reinterpret_cast<float *>(w); w += align_up((size_t)k.L * 2 * g.net_floats * sizeof(float), 256);
     float *losspart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * sizeof(float), 256);
-    float *dump = reinterpret_cast<float *>(w); w += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);
-    float *xsave = reinterpret_cast<float *>(w); w += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);
+    float *dump = reinterpret_cast<float *>(w); w += align_up((size_t)ctiles * k.L * 2 * g.dump_floats * sizeof(float), 256);
+    float *xsave = reinterpret_cast<float *>(w); w += align_up((size_t)ctiles * k.L * k.d * 16 * sizeof(float), 256);
     float *gpart = reinterpret_cast<float *>(w);
     int rc = pack(st, k, g, params, masks, packed);
     if (rc) return rc;
     rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_train), 160 * 1024, g_attr_train);
     if (rc) return rc;
-    const int G = grid_for(ntiles);
-    const int S = (int)(ntiles < kSplits ? ntiles : kSplits);
-    {
-        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
-        hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64 * kW), g.lds_train, st, k, g, packed, params, masks, x, c, row_index, n, inv_B,
-                           gz, dump, xsave, losspart);
+    // every chunk uses the same grid and the same number of row splits, so partial b always holds the same rows' sums
+    const int G = grid_for(ctiles);
+    const int S = (int)(ctiles < kSplits ? ctiles : kSplits);
+    for (int64_t r0 = 0; r0 < n; r0 += cr) {
+        const int64_t rows = n - r0 < cr ? n - r0 : cr;
+        const int64_t ntiles = (rows + 15) / 16;
+        const bool first = r0 == 0;
+        const float *xc = row_index ? x : x + r0 * k.d;
+        const float *cc = (row_index || !c) ? c : c + r0 * k.c;
+        {
+            KernelTimer timer(st, RNVP_PROFILE_TRAIN);
+            hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64 * kW), g.lds_train, st, k, g, packed, params, masks, xc, cc,
+                               row_index ? row_index + r0 : nullptr, rows, inv_B, gz ? gz + r0 * k.d : nullptr, dump, xsave,
+                               losspart, first ? 1 : 0);
+        }
+        RNVP_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)(k.L * 2 * g.quads_per_net), (unsigned)S), dim3(64), 0, st, k, g, dump,
+                           ntiles, gpart, first ? 0 : 1);
+        RNVP_HIP_TRY(hipGetLastError());
     }
-    RNVP_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)(k.L * 2 * g.quads_per_net), (unsigned)S), dim3(64), 0, st, k, g, dump, ntiles, gpart);
-    RNVP_HIP_TRY(hipGetLastError());
     const size_t P = (size_t)2 * k.npn * k.L;
     hipLaunchKernelGGL(k_lmm_reduce, dim3((unsigned)(P / 256 + 2)), dim3(256), 0, st, k, g, gpart, S, masks, losspart, G, inv_B,
                        grad_out, loss_out);

@@ -615,3 +615,38 @@ def test_auto_mode_takes_lmm_for_generic_shapes_and_is_bitwise_reproducible():
     # a shape whose 16-row LDS image does not fit falls back to the one-thread-per-row kernels
     big = _hip.RnvpShape.make(2, 16, 4, (512, 512, 512), "tanh", alt_masks=0)
     assert _hip.kernel_path(big, None, _hip.OP_TRAIN) == _hip.PATH_GENERIC
+
+
+def test_lmm_row_chunks_add_up():
+    """the lmm training pass works through a big batch in row chunks (bounded workspace: the dumped weight-gradient
+    operands take 38 KB per row for hidden=(128,128)); the chunked gradient equals the sum of separately computed parts"""
+    from probaforms_amd import _hip
+    L, d, c, hidden, n = 8, 16, 4, (128, 128), 60000            # chunk = 28160 rows -> 3 chunks
+    sh, p, rng = _rand_flow(L, d, c, hidden, "tanh", 9, scale=0.15)
+    masks = ((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8)
+    assert _hip.kernel_path(sh, masks, _hip.OP_TRAIN) == _hip.PATH_LMM
+    assert _hip.workspace_bytes(sh, _hip.OP_TRAIN, 10 ** 7) == _hip.workspace_bytes(sh, _hip.OP_TRAIN, 10 ** 6) < 2 ** 31
+    P = p.size
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(n, d, device="cuda", generator=gen); cc = torch.randn(n, c, device="cuda", generator=gen)
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    pd, mk = _dev(p), _dev(masks, torch.uint8)
+    ws = _ws(_hip, sh, _hip.OP_TRAIN, n)
+    full = torch.empty(P + 1, device="cuda")
+    _hip.loss_grad(sh, pd, mk, x, cc, perm, n, 1.0 / n, full[:P], full[P:], ws)
+    again = torch.empty(P + 1, device="cuda")
+    _hip.loss_grad(sh, pd, mk, x, cc, perm, n, 1.0 / n, again[:P], again[P:], ws)
+    assert torch.equal(full, again)
+    acc = torch.zeros(P + 1, device="cuda", dtype=torch.float64)
+    part = torch.empty(P + 1, device="cuda")
+    for lo in range(0, n, 20000):
+        _hip.loss_grad(sh, pd, mk, x, cc, perm[lo:lo + 20000].contiguous(), 20000, 1.0 / n, part[:P], part[P:], ws)
+        acc += part.double()
+    scale = acc[:P].abs().max().item()
+    assert (full[:P].double() - acc[:P]).abs().max().item() < 3e-6 * scale
+    assert abs(full[P].item() - acc[P].item()) < 1e-5 * abs(acc[P].item())
+    # without a row index the chunks walk the arrays directly
+    direct = torch.empty(P + 1, device="cuda")
+    xg, cg = x[perm].contiguous(), cc[perm].contiguous()
+    _hip.loss_grad(sh, pd, mk, xg, cg, None, n, 1.0 / n, direct[:P], direct[P:], ws)
+    assert torch.equal(direct, full)
