@@ -2,8 +2,8 @@
 //
 // Serves what the register-chained MFMA path (rnvp_mfma*.hip, rnvp_bx3.hip) does not specialise -- several hidden
 // layers (the reference's docstring example is hidden=(10, 20, 15): /root/reference/probaforms/models/realnvp.py:22-38),
-// user-supplied masks (realnvp.py:65-68), d > 64, cdim > 16 -- for nets wide enough that the one-thread-per-row VALU
-// kernels of rnvp_generic.hip fall off a cliff (hidden=(128, 128): 0.3 M rows/s in fit).  Design:
+// user-supplied masks (realnvp.py:65-68), d > 64, cdim > 16 -- which the one-thread-per-row VALU kernels of
+// rnvp_generic.hip served at 0.3 M rows/s (fit, hidden=(128, 128)).  Design:
 //   * one WORKGROUP of 4 waves owns one tile of 16 rows for the whole stack; its activations live in one LDS image
 //     [feature][17]; the waves split every Linear's out tiles (and the elementwise passes' features) among themselves,
 //     one workgroup barrier per Linear -- the image, not the registers, limits how many tiles a CU holds, so four
@@ -14,11 +14,11 @@
 //     the accumulator (bias added, activation applied) written back to the LDS image of the next Linear;
 //   * forward / inverse: x, c read once, z / log-prob written once per row;
 //   * training: the same kernel runs forward, then per layer recomputes both nets and chains the INPUT gradients through
-//     W^T fragments (the hand-derived backward of SURVEY.md 3.3); the WEIGHT gradients contract over rows, so each wave
-//     dumps, per Linear, its input activations (+ a ones column for the bias) and the pre-activation gradients as
-//     [feature][16 rows] tiles, and k_lmm_wgrad forms dW = gP^T . act tile pair by tile pair over fixed row splits;
-//     k_lmm_reduce adds the splits in order and scatters into the reference's flat parameter order.
-//     No float atomics: bitwise reproducible.
+//     W^T fragments (the hand-derived backward of SURVEY.md 3.3); the WEIGHT gradients contract over rows, so each
+//     tile dumps, per Linear, its input activations (+ a ones column for the bias) and the pre-activation gradients as
+//     [feature][16 rows] tiles, and k_lmm_wgrad forms dW = gP^T . act per 2 x 2 block of tile pairs over fixed row
+//     splits; k_lmm_reduce adds the splits in order and scatters into the reference's flat parameter order.  A big
+//     batch goes through in row chunks (the dumps stay under ~1 GiB).  No float atomics: bitwise reproducible.
 #include "rnvp_common.h"
 #include "rnvp_generic_net.h"
 #include "rnvp_lmm.h"
@@ -34,12 +34,6 @@ constexpr int kSplits = 64;            // row splits of the weight-gradient pass
 constexpr int kW = 4;                  // waves per workgroup (all on the same 16-row tile)
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ void wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ---- weight packing -----------------------------------------------------------------------------------------------
 // Fragment value for out tile m, k-step ks, lane (q, i): forward W_k[16m + i][4ks + q]; transposed W_k[4ks + q][16m + i]
 // (for k == 0 only the x columns: C gets no gradient).  First Linear: x column j is multiplied by mask[l][j].
