@@ -216,6 +216,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # stdout carries exactly ONE line, the JSON: libraries that chat on fd 1 (RCCL prints a five-line banner there when a
+    # communicator is created) are sent to stderr for the whole run; rank 0 writes the result to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -386,7 +392,7 @@ def main():
                                   "vs_oracle_f64": float(np.abs(lp - lp64).mean()),
                                   "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
                                   "target": 1e-5}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
         dist.barrier()                      # rank 0 may still be timing the CPU baseline
         dist.destroy_process_group()
