@@ -460,33 +460,44 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
             ev.record(side)
         return d, ev
 
-    nxt = upload(0) if n_epochs > 0 else None
-    for epoch in range(n_epochs):
-        perm, ev = nxt
-        if ev is not None:
-            torch.cuda.current_stream(dev).wait_event(ev)
-            perm.record_stream(torch.cuda.current_stream(dev))
-        losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
-        if world == 1 and prior is None:
-            engine.fit_epoch(opt, X, C, perm, batch_size, losses)       # every batch, one library call
-            if epoch + 1 < n_epochs:
-                nxt = upload(epoch + 1)
-        else:
-            for k, (s, e) in enumerate(bounds):
-                lo, hi = shard_bounds(s, e, rank, world)
-                if prior is None:
-                    g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
-                else:
-                    g = engine.loss_grad_prior(prior, X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
-                if world == 1:
-                    losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
-                    engine.adam(opt)
-                    continue
-                all_reduce_sum(g[:engine.P + 1])
-                engine.finish_dp_step(opt, losses[k:k + 1])
-            if epoch + 1 < n_epochs:
-                nxt = upload(epoch + 1)
+    def read_back(epoch, losses):
         host = losses.cpu()
         loss_history.extend(host[i].clone() for i in range(host.numel()))
         if epoch_hook is not None:
             epoch_hook(epoch, float(host[-1]))
+
+    # Epoch e's losses are read back only after epoch e+1 has been enqueued (and its successor's permutation uploaded),
+    # so the GPU never waits for the host between epochs; loss_history / the progress hook trail by one epoch.
+    pending = None
+    nxt = upload(0) if n_epochs > 0 else None
+    try:
+        for epoch in range(n_epochs):
+            perm, ev = nxt
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)
+                perm.record_stream(torch.cuda.current_stream(dev))
+            losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
+            if world == 1 and prior is None:
+                engine.fit_epoch(opt, X, C, perm, batch_size, losses)       # every batch, one library call
+            else:
+                for k, (s, e) in enumerate(bounds):
+                    lo, hi = shard_bounds(s, e, rank, world)
+                    if prior is None:
+                        g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+                    else:
+                        g = engine.loss_grad_prior(prior, X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+                    if world == 1:
+                        losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
+                        engine.adam(opt)
+                        continue
+                    all_reduce_sum(g[:engine.P + 1])
+                    engine.finish_dp_step(opt, losses[k:k + 1])
+            if epoch + 1 < n_epochs:
+                nxt = upload(epoch + 1)
+            if pending is not None:
+                done, pending = pending, None
+                read_back(*done)
+            pending = (epoch, losses)
+    finally:
+        if pending is not None:
+            read_back(*pending)
