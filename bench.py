@@ -264,6 +264,10 @@ def main():
     eng = nf.engine()
     if dp:
         _engine.broadcast_(eng.flat, 0)
+        # the communicator and the all-reduce of exactly this message size set themselves up here, outside any timing
+        # (with --warmup 0 the first timed step would otherwise carry RCCL's lazy initialisation)
+        dist.all_reduce(torch.zeros(eng.P + 1, device=dev), op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
     opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
 
     # data: resident in HBM before timing; each rank owns its own n rows (weak scaling)
