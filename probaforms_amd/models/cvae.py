@@ -13,8 +13,8 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from .._engine import (FlatAdam, all_reduce_sum, batch_bounds, broadcast_, default_device, dist_info,
-                       flatten_parameters, is_flat, loader_permutation, require_hip, shard_bounds)
+from .._engine import (FlatAdam, _perm_pool, all_reduce_sum, batch_bounds, broadcast_, default_device, dist_info,
+                       flatten_parameters, is_flat, permutation_from_seed, require_hip, shard_bounds)
 from .interfaces import GenModel
 
 DEVICE = default_device()
@@ -109,6 +109,87 @@ class Decoder(nn.Module):
         return out
 
 
+def _perm_into(buf, seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(buf.numel(), generator=g, out=buf)
+
+
+class _FitDraws:
+    """Every draw CVAE.fit makes on the global CPU generator, made AHEAD of the GPU on a worker thread.
+
+    The reference interleaves, per epoch: the two int64 seed draws of a fresh DataLoader iterator (cvae.py:235), one
+    `randn(B, latent)` per batch (sample_z, cvae.py:187) and one `randn(n, latent)` for the full-data loss
+    (cvae.py:254-259).  The sequence depends on nothing the GPU computes, so a private generator that starts from the
+    global generator's state replays it exactly, epochs ahead; `finish()` leaves the global generator where the
+    reference's fit would have left it.  The shuffles themselves (randperm from the drawn seed, private generator) run on
+    the shared permutation pool.  Everything is written into a small ring of reusable (pinned) host buffers: fresh
+    8 MB tensors per epoch cost more in page faults on the MI355X hosts than the draws themselves, and pinned memory
+    uploads asynchronously.  At C5 (n = 1M, latent 2) an epoch needs ~4M normals: the stream, not the GPU (~2.5 ms per
+    epoch), bounds the fit -- `noise_rng='device'` lifts that."""
+
+    def __init__(self, n, bounds, lat, n_epochs, device=None, slots=3):
+        import queue, threading
+        self.n, self.bounds, self.lat, self.n_epochs = n, bounds, lat, n_epochs
+        self.gen = torch.Generator()
+        self.gen.set_state(torch.get_rng_state())
+        pin = device is not None and torch.device(device).type == "cuda" and n * lat >= (1 << 16)
+        self.free, self.ready = queue.Queue(), queue.Queue()
+        for _ in range(max(1, min(slots, n_epochs))):
+            self.free.put((torch.empty(n, dtype=torch.int64, pin_memory=pin),
+                           torch.empty(n, lat, dtype=torch.float32, pin_memory=pin),
+                           torch.empty(n, lat, dtype=torch.float32, pin_memory=pin)))
+        self.stop = False
+        self.thread = threading.Thread(target=self._run, name="cvae-draws", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        import queue
+        try:
+            g = self.gen
+            pool = _perm_pool(2) if self.n >= 65536 else None
+            for _ in range(self.n_epochs):
+                slot = None
+                while slot is None and not self.stop:
+                    try:
+                        slot = self.free.get(timeout=0.1)
+                    except queue.Empty:
+                        pass
+                if self.stop:
+                    return
+                perm, eps, eps_full = slot
+                torch.empty((), dtype=torch.int64).random_(generator=g)                    # loader base seed
+                seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item())  # RandomSampler seed
+                fut = pool.submit(_perm_into, perm, seed) if pool else _perm_into(perm, seed)
+                for (s, e) in self.bounds:
+                    torch.randn(e - s, self.lat, generator=g, out=eps[s:e])
+                torch.randn(self.n, self.lat, generator=g, out=eps_full)
+                self.ready.put((slot, fut))
+        except BaseException as ex:               # surfaces in the consumer
+            self.ready.put(ex)
+
+    def next_epoch(self):
+        """-> (slot, perm [n] int64, eps of the batches [n, latent], eps of the loss pass [n, latent]); the tensors are
+        the slot's buffers: give the slot back with release() once nothing reads them any more"""
+        item = self.ready.get()
+        if isinstance(item, BaseException):
+            raise item
+        slot, fut = item
+        if hasattr(fut, "result"):
+            fut.result()
+        return slot, slot[0], slot[1], slot[2]
+
+    def release(self, slot):
+        self.free.put(slot)
+
+    def finish(self):
+        self.thread.join()
+        torch.set_rng_state(self.gen.get_state())
+
+    def abort(self):
+        self.stop = True
+
+
 def _rank0(t):
     """under torch.distributed: rank 0's tensor on every rank (in place); otherwise t"""
     if dist_info()[1] > 1:
@@ -123,8 +204,14 @@ class CVAE(GenModel):
          weight_decay=0, KL_weight=0.001, verbose=0); fit(X, C=None) -> self; sample(C=10)."""
 
     def __init__(self, latent_dim=2, hidden=(10,), activation='tanh', batch_size=32, n_epochs=10, lr=0.0001,
-                 weight_decay=0, KL_weight=0.001, verbose=0):
+                 weight_decay=0, KL_weight=0.001, verbose=0, *, noise_rng='host'):
+        """noise_rng (build-only, keyword-only): 'host' -- eps of sample_z from the global CPU generator, the reference's
+        stream (cvae.py:187), produced ahead of the GPU by _FitDraws; 'device' -- a counter-based draw on the GPU
+        (rnvp_prior_normal keyed by one host-drawn seed per batch): not the reference's numbers, no host work per row."""
         super().__init__()
+        if noise_rng not in ('host', 'device'):
+            raise ValueError("noise_rng must be 'host' or 'device'")
+        self.noise_rng = noise_rng
         self.lat_size = latent_dim
         self.hidden = hidden
         self.activation = activation
@@ -152,12 +239,22 @@ class CVAE(GenModel):
             broadcast_(core.flat, 0)
         self.opt = FlatAdam(core.flat.numel(), core.device, lr=self.lr, weight_decay=self.weight_decay)
 
-    def compute_loss(self, x_batch, cond_batch):
-        """KL_weight * KL + MSE on one batch with freshly drawn eps (cvae.py:195-203); no autograd graph"""
+    def _device_eps(self, rows):
+        """counter-based N(0, 1) draw on the GPU, keyed by one int64 from the global CPU generator"""
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        eps = torch.empty(rows, self.lat_size, dtype=torch.float32, device=self._core.device)
+        _hip.prior_normal(seed, 0, rows, self.lat_size, eps)
+        return eps
+
+    def compute_loss(self, x_batch, cond_batch, eps=None):
+        """KL_weight * KL + MSE on one batch with freshly drawn eps (cvae.py:195-203); no autograd graph.
+        eps: the [n, latent] normal draw if the caller already made it (fit's look-ahead stream)"""
         core = self._core
         x, c = _dev(x_batch, core.device), _dev(cond_batch, core.device)
         n = x.shape[0]
-        eps = _rank0(torch.randn(n, self.lat_size).to(core.device))               # cvae.py:187 (CPU generator)
+        if eps is None:
+            eps = self._device_eps(n) if self.noise_rng == 'device' else torch.randn(n, self.lat_size)   # cvae.py:187
+        eps = _rank0(eps.to(core.device))
         loss = torch.zeros(1, device=core.device)
         _hip.cvae_loss_grad(core.shape, core.sync(), x, c, None, eps, n, 1.0 / n, self.KL_weight, None, loss,
                             core.workspace(n))
@@ -178,26 +275,67 @@ class CVAE(GenModel):
         if self.verbose >= 1:
             from tqdm.auto import tqdm
             bar = tqdm(total=self.n_epochs, unit='epoch')
-        for epoch in range(self.n_epochs):
-            # data parallel: every rank consumes its own generator like a single process would, but walks rank 0's
-            # shuffle and noise (broadcast), so the shards tile ONE permutation and the run equals rank 0's run
-            perm = _rank0(loader_permutation(n).to(dev))                           # DataLoader(shuffle=True), cvae.py:235
-            for (s, e) in bounds:
-                B = e - s
-                eps = _rank0(torch.randn(B, self.lat_size).to(dev))                # sample_z, cvae.py:187
-                g = core.grads()
-                lo, hi = (s, e) if world == 1 else shard_bounds(s, e, rank, world)
-                _hip.cvae_loss_grad(core.shape, core.sync(), Xd, Cd, perm[lo:hi], eps[lo - s:hi - s], hi - lo,
-                                    1.0 / B, self.KL_weight, g[:core.P], g[core.P:core.P + 1], core.workspace(B))
-                if world > 1:
-                    all_reduce_sum(g[:core.P + 1])
-                self.opt.step_count += 1
-                _hip.adam_step(core.sync(), g[:core.P], self.opt.exp_avg[:core.P], self.opt.exp_avg_sq[:core.P],
-                               core.P, lr, b1, b2, eps_adam, wd, self.opt.step_count)
-            loss_epoch = self.compute_loss(Xd, Cd)                                 # cvae.py:254-259
-            self.loss_history.append(loss_epoch.detach().cpu())
-            if bar is not None:
-                bar.update(1); bar.set_description("loss: %.4f" % float(loss_epoch))
+        host_noise = self.noise_rng != 'device'
+        draws = _FitDraws(n, bounds, self.lat_size, self.n_epochs, dev) if host_noise else None
+        perms = None
+        if not host_noise:
+            from .._engine import PermutationPrefetcher
+            perms = PermutationPrefetcher(n, self.n_epochs).start()
+        pending = []                     # device scalars of the per-epoch losses, read back once (or one epoch behind)
+        inflight = None                  # (slot, event): host buffers the GPU may still be copying from
+
+        def flush(keep):
+            while len(pending) > keep:
+                v = pending.pop(0).detach().cpu()
+                self.loss_history.append(v)
+                if bar is not None:
+                    bar.update(1); bar.set_description("loss: %.4f" % float(v))
+
+        def upload(t):
+            return t.to(dev, non_blocking=True) if dev.type == "cuda" else t.clone()
+
+        try:
+            for epoch in range(self.n_epochs):
+                # data parallel: every rank consumes its own generator like a single process would, but walks rank 0's
+                # shuffle and noise (broadcast), so the shards tile ONE permutation and the run equals rank 0's run
+                if host_noise:
+                    slot, perm_h, eps_h, eps_full_h = draws.next_epoch()           # DataLoader(shuffle=True), cvae.py:235
+                    perm = _rank0(upload(perm_h))
+                    eps_all = _rank0(upload(eps_h))                                # sample_z of every batch, cvae.py:187
+                    eps_full = upload(eps_full_h)
+                    if inflight is not None:
+                        if inflight[1] is not None:
+                            inflight[1].synchronize()
+                        draws.release(inflight[0])
+                    ev = None
+                    if dev.type == "cuda":
+                        ev = torch.cuda.Event(); ev.record()
+                    inflight = (slot, ev)
+                else:
+                    perm = _rank0(perms.get(epoch).to(dev))
+                    eps_full = None
+                for (s, e) in bounds:
+                    B = e - s
+                    eps = eps_all[s:e] if host_noise else _rank0(self._device_eps(B))
+                    g = core.grads()
+                    lo, hi = (s, e) if world == 1 else shard_bounds(s, e, rank, world)
+                    _hip.cvae_loss_grad(core.shape, core.sync(), Xd, Cd, perm[lo:hi], eps[lo - s:hi - s], hi - lo,
+                                        1.0 / B, self.KL_weight, g[:core.P], g[core.P:core.P + 1], core.workspace(B))
+                    if world > 1:
+                        all_reduce_sum(g[:core.P + 1])
+                    self.opt.step_count += 1
+                    _hip.adam_step(core.sync(), g[:core.P], self.opt.exp_avg[:core.P], self.opt.exp_avg_sq[:core.P],
+                                   core.P, lr, b1, b2, eps_adam, wd, self.opt.step_count)
+                pending.append(self.compute_loss(Xd, Cd, eps_full))      # cvae.py:254-259
+                flush(1 if bar is not None else self.n_epochs)     # never make the GPU wait for the host between epochs
+            flush(0)
+            if draws is not None:
+                draws.finish()
+        finally:
+            if draws is not None:
+                draws.abort()
+            if perms is not None:
+                perms.close()
         if bar is not None:
             bar.close()
         return self

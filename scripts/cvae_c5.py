@@ -30,5 +30,10 @@ for _ in range(10): step()
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 10
 print("device-resident train step, 65536 rows: %.3f ms -> %.1f M rows/s" % (ms, B / ms / 1e3))
+for noise in ("host", "device"):
+    mm = CVAE(latent_dim=2, hidden=(128,), batch_size=65536, n_epochs=8, lr=1e-3, noise_rng=noise)
+    mm.fit(X, C); torch.cuda.synchronize()
+    t0 = time.perf_counter(); mm.fit(X, C); torch.cuda.synchronize(); t1 = time.perf_counter()
+    print("API-level fit 8 epochs, noise_rng=%s: %.1f ms = %.2f ms/epoch -> %.1f M rows/s" % (noise, (t1 - t0) * 1e3, (t1 - t0) * 1e3 / 8, 8 * n / (t1 - t0) / 1e6))
 t0 = time.perf_counter(); xs = m.sample(C); t1 = time.perf_counter()
 print("sample(1M): %.1f ms" % ((t1 - t0) * 1e3))

@@ -167,3 +167,65 @@ def test_api_contract_like_reference_tests():
     assert gen.sample(C).shape == X.shape
     gen = CVAE(); gen.fit(X, C=None)
     assert gen.sample(C=n).shape == X.shape
+
+
+def _c5_like(n, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, 16)).astype(np.float32)
+    C = (rng.random(size=(n, 4)) > 0.5).astype(np.float32)
+    X[:, :4] += C
+    return X, C
+
+
+def test_lookahead_draws_replay_the_serial_generator_stream():
+    """the worker-thread replay of fit's CPU-generator draws (seeds, per-batch eps, full-data eps; permutations on the
+    shared pool) consumes the stream exactly like the serial loop: same values, same final generator state"""
+    from probaforms_amd.models.cvae import _FitDraws
+    from probaforms_amd._engine import batch_bounds, loader_permutation
+    n, lat, epochs = 70_000, 3, 3
+    bounds = batch_bounds(n, 16_384)
+    torch.manual_seed(11)
+    serial = []
+    for _ in range(epochs):
+        perm = loader_permutation(n)
+        eps = torch.cat([torch.randn(e - s, lat) for (s, e) in bounds])
+        serial.append((perm, eps, torch.randn(n, lat)))
+    end_state = torch.get_rng_state()
+    torch.manual_seed(11)
+    draws = _FitDraws(n, bounds, lat, epochs, torch.device("cuda"), slots=2)
+    for ref in serial:
+        slot, *got = draws.next_epoch()
+        for a, b in zip(got, ref):
+            assert a.is_pinned() and torch.equal(a, b)
+        draws.release(slot)
+    draws.finish()
+    assert torch.equal(torch.get_rng_state(), end_state)
+
+
+@pytest.mark.parametrize("noise", ["host", "device"])
+def test_large_fit_is_deterministic_and_learns(noise):
+    from probaforms_amd.models import CVAE
+    X, C = _c5_like(70_000)
+    hists = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        m = CVAE(latent_dim=2, hidden=(64,), batch_size=8192, n_epochs=4, lr=3e-3, noise_rng=noise).fit(X, C)
+        hists.append(np.array([float(v) for v in m.loss_history]))
+        assert len(m.loss_history) == 4 and all(v.device.type == "cpu" and v.dim() == 0 for v in m.loss_history)
+    assert np.array_equal(hists[0], hists[1])
+    assert np.isfinite(hists[0]).all() and hists[0][-1] < hists[0][0]
+    assert m.sample(C[:100]).shape == (100, 16)
+
+
+def test_device_noise_matches_host_noise_statistically():
+    """the two noise sources train to the same loss level (different numbers, same distribution)"""
+    from probaforms_amd.models import CVAE
+    X, C = _c5_like(40_000, seed=1)
+    out = {}
+    for noise in ("host", "device"):
+        torch.manual_seed(7)
+        m = CVAE(latent_dim=2, hidden=(32,), batch_size=4096, n_epochs=6, lr=3e-3, noise_rng=noise).fit(X, C)
+        out[noise] = float(m.loss_history[-1])
+    assert abs(out["host"] - out["device"]) < 0.05 * abs(out["host"]), out
+    with pytest.raises(ValueError):
+        CVAE(noise_rng="gpu")
