@@ -40,6 +40,15 @@ KernelTimer::~KernelTimer() {
         if ((size_t)(2 * slot + 1) < g_ev[kind].size()) (void)hipEventRecord(g_ev[kind][2 * slot + 1], st);
     }
 }
+KernelEvents::KernelEvents(int kind) {
+    if (kind < 0 || kind >= kKinds) return;
+    std::lock_guard<std::mutex> lk(g_ev_mu);
+    if (!g_ev[kind].empty() && (size_t)(2 * g_ev_used[kind] + 1) < g_ev[kind].size()) {
+        start = g_ev[kind][2 * g_ev_used[kind]];
+        stop = g_ev[kind][2 * g_ev_used[kind] + 1];
+        ++g_ev_used[kind];
+    }
+}
 }  // namespace rnvp
 
 extern "C" {

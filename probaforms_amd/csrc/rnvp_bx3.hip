@@ -475,9 +475,9 @@ int launch(hipStream_t st, const KShape &k, const Geo3 &g, const uint32_t *packe
     const int grid = (int)(ngroups < kMaxGridBx3 ? ngroups : kMaxGridBx3);
     if (grid_out) *grid_out = grid;
     {
-        KernelTimer timer(st, INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesBx3 * 64), lds_bytes, st, packed, g, k.L, k.alt, x, c, row_index, n,
-                           out_x, logdet_out, logp_out, part, seed, row0);
+        const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWavesBx3 * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt,
+                              x, c, row_index, n, out_x, logdet_out, logp_out, part, seed, row0);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;

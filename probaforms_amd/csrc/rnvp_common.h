@@ -1,6 +1,7 @@
 // rnvp_common.h -- shared host/device declarations of librnvp_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <atomic>
@@ -134,6 +135,13 @@ struct KernelTimer {
     int kind, slot;
     KernelTimer(hipStream_t s, int kind);  // records the start event if profiling is enabled
     ~KernelTimer();                        // records the stop event
+};
+// The same event pairs, for launches made with hipExtLaunchKernelGGL(kernel, ..., start, stop, 0, args): the kernel's own
+// dispatch packet stamps the two events (no barrier packets around the launch: the bracketing form costs ~6 us of idle
+// queue per side on MI355X, 1.8 % of the C2 step).  Both are nullptr while profiling is off = a plain launch.
+struct KernelEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+    explicit KernelEvents(int kind);
 };
 
 #define RNVP_HIP_TRY(expr)                         \

@@ -259,9 +259,9 @@ int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pack
     const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
     *grid_out = grid;
     {
-        KernelTimer timer(st, INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
-        hipLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE, ACT>), dim3(grid), dim3(kWaves * 64), 0, st, packed, g, k.L, k.alt, x,
-                           c, row_index, n, out_x, logdet_out, logp_out, part, seed, row0);
+        const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
+        hipExtLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE, ACT>), dim3(grid), dim3(kWaves * 64), 0, st, ev.start, ev.stop, 0,
+                              packed, g, k.L, k.alt, x, c, row_index, n, out_x, logdet_out, logp_out, part, seed, row0);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;

@@ -695,9 +695,9 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
     if (arc) return arc;
     {
-        KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, packed, g, k.L, k.alt, x, c,
-                           row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
+        const KernelEvents ev(RNVP_PROFILE_TRAIN);      // rnvp_profile_*: this launch's own start / stop stamps when enabled
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, ev.start, ev.stop, 0, packed, g,
+                              k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
