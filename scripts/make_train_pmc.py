@@ -1,0 +1,48 @@
+"""profiles/<tag>_train_pmc.json from the counter CSVs that `NT=65536 N=1048576 bash scripts/gpu_pmc.sh <tag>train c2 train`
+left under gpurun_out/pmc_<tag>train/ (five separate --pmc passes): per-launch averages for the C2 training kernel and
+the derived per-SIMD / per-wave figures DESIGN.md section 5 quotes.   usage: python scripts/make_train_pmc.py <tag>"""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+vals = collections.defaultdict(list)
+durs = []
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%strain" % tag, "s*", "*counter_collection.csv")):
+    seen = set()
+    for row in csv.DictReader(open(f)):
+        if "k_mfma_train<2, 1, 4, 1, 0>" not in row["Kernel_Name"]:
+            continue
+        vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        key = row.get("Dispatch_Id")
+        if key not in seen and row.get("End_Timestamp") and row.get("Start_Timestamp"):
+            seen.add(key)
+            durs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+assert vals, "no counter rows for k_mfma_train<2,1,4,1,0> under gpurun_out/pmc_%strain" % tag
+per = {k: sum(v) / len(v) for k, v in vals.items()}
+waves = per["SQ_WAVES"]
+simds = 1024.0
+wave_cycles = per["SQ_WAVE_CYCLES"] * 4.0                    # the counter ticks once per 4 cycles
+cycles_per_wave = wave_cycles / waves
+dur_us = sum(durs) / len(durs) if durs else None
+out = {
+    "kernel": "k_mfma_train<2,1,4,1,0> (C2, 65536 rows, net-split, 256 workgroups x 8 waves)",
+    "csrc_hash": bench.csrc_hash(),
+    "command": "NT=65536 N=1048576 bash scripts/gpu_pmc.sh %strain c2 train  (rocprofv3 --pmc, 5 separate passes over scripts/bench_kernels.py); scripts/make_train_pmc.py %s" % (tag, tag),
+    "per_launch": per,
+    "avg_duration_us_under_pmc": dur_us,
+    "derived": {
+        "cycles_per_wave": cycles_per_wave,
+        "effective_clock_GHz": (cycles_per_wave / (dur_us * 1e3)) if dur_us else None,
+        "mfma_busy_cycles_per_simd": per["SQ_VALU_MFMA_BUSY_CYCLES"] / simds,
+        "mfma_busy_frac_of_wave_lifetime": per["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cycles_per_wave,
+        "valu_active_cycles_per_simd (quad-cycles x4, includes MFMA issue)": per["SQ_ACTIVE_INST_VALU"] * 4.0 / simds,
+        "useful_mfma_cycles_per_simd (245760 flop/row x 65536 rows / 1024 SIMDs / 64 flop/clk)": 245760.0 * 65536 / simds / 64.0,
+        "mfma_instructions_per_wave": per["SQ_INSTS_MFMA"] / waves,
+        "non_mfma_valu_instructions_per_wave": (per["SQ_INSTS_VALU"] - per["SQ_INSTS_MFMA"]) / waves,
+    },
+}
+dst = os.path.join(ROOT, "gpurun_out", "%s_train_pmc.json" % tag)
+json.dump(out, open(dst, "w"), indent=1)
+print(dst, json.dumps(out["derived"]))
