@@ -168,7 +168,7 @@ def api_level(Xh, Ch, dev):
     import torch
     from probaforms_amd.models import RealNVP
     out = {}
-    epochs = 3
+    epochs = 10                                           # the reference's default n_epochs (realnvp.py:161)
     for prior in ("host", "device"):
         torch.manual_seed(0)
         m = RealNVP(n_layers=LAYERS, hidden=HIDDEN, batch_size=BATCH, n_epochs=1, lr=1e-3, prior_rng=prior)
