@@ -90,6 +90,19 @@ template <int NF, int CQ> struct Dims {
     static constexpr int FT = NF == 2 ? 4 : (NF == 4 ? 2 : 1);
 #endif
     static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
+    // W2C (d <= 16 in net-split mode: every wave owns ONE net): dW2 = h^T g_out runs as 16 independent 4x4x1 blocks per
+    // instruction instead of a 16x16x4 tile whose other net's eight columns are structural zeros -- block (q, hb) of lane
+    // 16q + 4hb + j contracts hidden units 4hb..4hb+3 with out columns 4cb + j over the rows 4ks + q, the four row classes
+    // q are added by a permlane reduce-scatter once per hidden tile, and the tile's dW2 record shrinks from 256 to 128
+    // floats (only this net's 16 x 8 entries).  g_out^T is read from a wave-private LDS image [row tile][row][GS]
+    // (position 2j + cb holds column 4cb + j, so one ds_read_b64 feeds both column blocks) instead of registers.
+    template <int NS> static constexpr bool w2c() { return NF == 2 && NS == 1 && kUseX4; }
+    template <int NS> static constexpr int tblk() { return w2c<NS>() ? NTI * 256 + 128 : (NTI + OTL) * 256; }
+    template <int NS> static constexpr int slot() { return FT * tblk<NS>() + NT2 * 16; }
+    static constexpr int GS = 10;
+    template <int R, int NS> static constexpr int tbn() {
+        return (w2c<NS>() ? R * 16 * GS : NT2 * 16 * kTS) + 16 * SIN + 2 * (R >= 4 ? 2 : R) * 16 * kTS;
+    }
 };
 
 // ---- backward of one layer ---------------------------------------------------------------------------
@@ -112,11 +125,12 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int q = lane >> 4, r = lane & 15, tid = wave * 64 + lane;
     const int role = NS ? (wave >> 2) : 0;
     const int HT = g.HT;
-    constexpr int FT = D::FT, SLOT = D::SLOT, TBLK = (NTI + OTL) * 256;
+    constexpr bool W2C = D::template w2c<NS>();
+    constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
     float *slot = lds + wave * SLOT;
-    float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging)
-    float *bufI = tb + NT2 * 16 * kTS;                    // 16 x SIN
+    float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging); W2C: R x 16 x GS
+    float *bufI = tb + (W2C ? R * 16 * GS : NT2 * 16 * kTS);   // 16 x SIN
     float *bufH = bufI + 16 * SIN;                        // 2R tiles of 16 x kTS: (h, g_pre) per row tile
 
     // 1. restore the layer input, form g_out = [g_t | g_s] and the gradient of the pass-through part
@@ -148,8 +162,15 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     float goT[R][NT2][4], inT[R][NTI][4];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
+        if constexpr (W2C) {        // this wave's net only: columns 2q, 2q+1 of row r, at positions 2j + cb (Dims)
+            const float v0 = role ? go[rt][0][2] : go[rt][0][0], v1 = role ? go[rt][0][3] : go[rt][0][1];
+            float *gp = bufG + (rt * 16 + r) * GS + 4 * (q & 1) + (q >> 1);
+            wave_lds_fence();
+            gp[0] = v0; gp[2] = v1;
+        } else {
 #pragma unroll
-        for (int ot = 0; ot < NT2; ++ot) transpose16(bufG + ot * 16 * kTS, go[rt][ot], lane, goT[rt][ot]);
+            for (int ot = 0; ot < NT2; ++ot) transpose16(bufG + ot * 16 * kTS, go[rt][ot], lane, goT[rt][ot]);
+        }
         wave_lds_fence();
 #pragma unroll
         for (int k4 = 0; k4 < KP4; ++k4) {
@@ -208,9 +229,9 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
             BWD_SCHED_BARRIER();
 
-            f4 gW2[OTL], gW1[NTI];
+            f4 gW2[W2C ? 2 : OTL], gW1[NTI];           // W2C: one accumulator per column block cb
 #pragma unroll
-            for (int o = 0; o < OTL; ++o) gW2[o] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int o = 0; o < (W2C ? 2 : OTL); ++o) gW2[o] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < NTI; ++nt) gW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
             // The four phases run over RH row tiles at a time (two interleaved MFMA chains are enough for
@@ -282,6 +303,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                 gin[r0 + u][m] = mfma16(a1t[m][rho], gpv[u][rho], gin[r0 + u][m]);
                 }
                 float hT[RH][4], pT[RH][4];
+                float2 gB[W2C ? RH : 1][4];
 #pragma unroll
                 for (int u = 0; u < RH; ++u)
 #pragma unroll
@@ -292,6 +314,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         } else {
                             hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
                         }
+                        if constexpr (W2C)
+                            gB[u][ks] = *reinterpret_cast<const float2 *>(bufG + ((r0 + u) * 16 + 4 * ks + q) * GS + 2 * (r & 3));
                     }
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p3, t0);
@@ -302,9 +326,14 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     for (int u = 0; u < RH; ++u)
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) {
+                            if constexpr (W2C) {
+                                gW2[0] = mfma4(hT[u][ks], gB[u][ks].x, gW2[0]);
+                                gW2[1] = mfma4(hT[u][ks], gB[u][ks].y, gW2[1]);
+                            } else {
 #pragma unroll
-                            for (int o = 0; o < OTL; ++o)
-                                gW2[o] = mfma16(hT[u][ks], goT[r0 + u][(NF >= 4 ? net * OTL : 0) + o][ks], gW2[o]);
+                                for (int o = 0; o < OTL; ++o)
+                                    gW2[o] = mfma16(hT[u][ks], goT[r0 + u][(NF >= 4 ? net * OTL : 0) + o][ks], gW2[o]);
+                            }
 #pragma unroll
                             for (int nt = 0; nt < NTI; ++nt) gW1[nt] = mfma16(pT[u][ks], inT[r0 + u][nt][ks], gW1[nt]);
                         }
@@ -322,13 +351,23 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) *reinterpret_cast<f4 *>(sb + nt * 256) = gW1[nt];
+                if constexpr (W2C) {
+                    // add the four row classes q; lane group q keeps column block q >> 1, hidden units 4hb + 2(q & 1) + {0, 1}
+                    float s4[4];
 #pragma unroll
-                for (int o = 0; o < OTL; ++o) *reinterpret_cast<f4 *>(sb + (NTI + o) * 256) = gW2[o];
+                    for (int i = 0; i < 4; ++i) s4[i] = swap_add32(gW2[0][i], gW2[1][i]);
+                    float2 kept;
+                    kept.x = swap_add16(s4[0], s4[2]); kept.y = swap_add16(s4[1], s4[3]);
+                    *reinterpret_cast<float2 *>(slot + (size_t)(ht % FT) * TBLK + NTI * 256 + lane * 2) = kept;
+                } else {
+#pragma unroll
+                    for (int o = 0; o < OTL; ++o) *reinterpret_cast<f4 *>(sb + (NTI + o) * 256) = gW2[o];
+                }
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) asm volatile("" ::"v"(gW1[nt]));
 #pragma unroll
-                for (int o = 0; o < OTL; ++o) asm volatile("" ::"v"(gW2[o]));
+                for (int o = 0; o < (W2C ? 2 : OTL); ++o) asm volatile("" ::"v"(gW2[o]));
             }
             const bool last_tile = (ht + 1 == HT);
             STAMP_ADD(stp.p5, t0);
@@ -465,8 +504,9 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pw = wave & (kWaves - 1), role = NS ? wave >> 2 : 0;     // row owner index; net of this wave (NS)
     const int q = lane >> 4, r = lane & 15;
-    float *tb = lds + NW * DM::SLOT + wave * DM::template tb<R>();
-    float *xbuf = lds + NW * DM::SLOT + NW * DM::template tb<R>();     // NS: 2 x NW x XW, double buffered by layer parity
+    constexpr int SLOTN = DM::template slot<NS>(), TBN = DM::template tbn<R, NS>();
+    float *tb = lds + NW * SLOTN + wave * TBN;
+    float *xbuf = lds + NW * SLOTN + NW * TBN;                         // NS: 2 x NW x XW, double buffered by layer parity
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
@@ -561,9 +601,10 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
 // One thread per flat parameter; finds where the packed gradient keeps it (or that the masks make
 // it dead: exactly zero, as in the reference) and sums the workgroup partials in index order.
 __global__ void __launch_bounds__(256)
-k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restrict__ seg, int S,
+k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, int w2c, const float *__restrict__ seg, int S,
               const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss,
               float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
+    // w2c: the launch wrote the compact dW2 records of Dims::w2c (128 floats per hidden tile after the dW1 tiles)
     const size_t P = (size_t)2 * k.npn * k.L;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) {
@@ -584,7 +625,8 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
     const int pc = (l + k.alt) & 1;
     const int NF = g.NF, CQ = g.CQ, HT = g.HT, OTL = g.OTL, h = k.nout[0], nin = k.d + k.c;
     const int KSP = 4 * NTI;
-    const int netblock = HT * (NTI + OTL) * 256;
+    const int tblk = w2c ? NTI * 256 + 128 : (NTI + OTL) * 256;      // floats of one hidden tile's record
+    const int netblock = HT * tblk;
     int loc = -1;
     if (idx < k.boff[0]) {                                     // W1 [h][d + c]
         const int hid = idx / nin, col = idx - hid * nin;
@@ -598,11 +640,11 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
         }
         if (jn >= 0) {
             const int i = hid & 15;
-            loc = net * netblock + ((hid >> 4) * (NTI + OTL) + (jn >> 4)) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
+            loc = net * netblock + (hid >> 4) * tblk + (jn >> 4) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
         }
     } else if (idx < k.woff[1]) {                              // b1 [h]: the ones column
         const int hid = idx - k.boff[0], i = hid & 15, jn = NF + CQ;
-        loc = net * netblock + ((hid >> 4) * (NTI + OTL) + (jn >> 4)) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
+        loc = net * netblock + (hid >> 4) * tblk + (jn >> 4) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
     } else if (idx < k.boff[1]) {                              // W2 [d][h]
         const int j = (idx - k.woff[1]) / h, hid = (idx - k.woff[1]) - j * h;
         const int qo = j / (2 * NF), e = j % (2 * NF);
@@ -612,7 +654,12 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, const float *__restri
             if (NF >= 4) { otl = f >> 2; io = 4 * qo + (f & 3); }
             else { otl = 0; io = 4 * qo + 2 * net + f; }
             const int i = hid & 15;
-            loc = net * netblock + ((hid >> 4) * (NTI + OTL) + NTI + otl) * 256 + (16 * (i >> 2) + io) * 4 + (i & 3);
+            if (w2c) {      // column 2 qo + f of this net: block cb = col >> 2, kept by lane group 2 cb + (i >> 1) & 1 (layer_bwd)
+                const int col = 2 * qo + f, lane = 16 * (2 * (col >> 2) + ((i >> 1) & 1)) + 4 * (i >> 2) + (col & 3);
+                loc = net * netblock + (hid >> 4) * tblk + NTI * 256 + lane * 2 + (i & 1);
+            } else {
+                loc = net * netblock + (hid >> 4) * tblk + (NTI + otl) * 256 + (16 * (i >> 2) + io) * 4 + (i & 3);
+            }
         }
     } else {                                                   // b2 [d]
         const int j = idx - k.boff[1];
@@ -718,22 +765,33 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 #define RNVP_NET_SPLIT 1
 #endif
 
+// layout of the partials a launch wrote (the net-split launches of d <= 16 use the compact dW2 records)
+struct PartialLayout { int glayer_floats, w2c; };
+
 template <int NF, int CQ, int R>
 int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                    const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                   float *losspart, float *scratch, int *grid_out, const float *gz) {
+                   float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
     using DM = Dims<NF, CQ>;
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
     *grid_out = grid;
     const size_t per_wave = (size_t)DM::SLOT + DM::template tb<R>();
+    const size_t per_wave_ns = (size_t)DM::template slot<1>() + DM::template tbn<R, 1>();
     // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
     // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
-    const size_t lds_ns = (2 * kWaves * per_wave + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float);
-    if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024)
-        return launch_train_ns<NF, CQ, R, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+    const size_t lds_ns = (2 * kWaves * per_wave_ns + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float);
+    if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024) {
+        lay->w2c = DM::template w2c<1>() ? 1 : 0;
+        lay->glayer_floats = 2 * g.HT * DM::template tblk<1>() + DM::NT2 * 16;
+        TrainPlan pn = pl;
+        pn.glayer_floats = lay->glayer_floats;
+        return launch_train_ns<NF, CQ, R, 1>(st, k, g, pn, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
                                              grid, lds_ns, gz);
+    }
+    lay->w2c = 0;
+    lay->glayer_floats = pl.glayer_floats;
     return launch_train_ns<NF, CQ, R, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
                                          kWaves * per_wave * sizeof(float), gz);
 }
@@ -741,14 +799,14 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
 template <int NF, int CQ>
 int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                  const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                 float *losspart, float *scratch, int *grid_out, const float *gz) {
+                 float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
     constexpr int RMAX = TrainRows<NF, CQ>::value;
     const int R = pick_rows(RMAX, n);
 #define RNVP_ROWS(r)                                                                                              \
     if constexpr (RMAX >= r) {                                                                                    \
         if (R == r)                                                                                               \
             return launch_train_r<NF, CQ, r>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, \
-                                             grid_out, gz);                                                       \
+                                             grid_out, gz, lay);                                                  \
     }
     RNVP_ROWS(4) RNVP_ROWS(2) RNVP_ROWS(1)
 #undef RNVP_ROWS
@@ -799,16 +857,17 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
     int grid = 0;
-    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
-    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
-    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
-    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz);
+    PartialLayout lay{pl.glayer_floats, 0};
+    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
+    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
+    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
+    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
     const size_t P = (size_t)2 * k.npn * k.L;
     const unsigned blocks = (unsigned)(P / 256 + 2);     // last block's last wave is always past P: it sums the loss
     int NTI = (g.KS1 + 1 + 3) / 4;
-    const size_t n4 = (size_t)pl.glayer_floats * k.L / 4;
+    const size_t n4 = (size_t)lay.glayer_floats * k.L / 4;
     // second level (<= kSeg segment sums per parameter) is folded into the scatter to flat order; up to kSeg
     // workgroups ARE the segments (small batches: one launch fewer per step)
     const int S = grid < kSeg ? grid : kSeg;
@@ -818,7 +877,7 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     } else {
         seg = gpart;
     }
-    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, pl.glayer_floats, seg, S, losspart,
+    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, lay.glayer_floats, lay.w2c, seg, S, losspart,
                        grid, inv_B, grad_out, loss_out, adam_p, adam_m, adam_v, adam);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
