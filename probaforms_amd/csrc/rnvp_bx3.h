@@ -74,7 +74,7 @@ bool supported(const KShape &k);
 size_t packed_bytes(const KShape &k);          // stages + b2 blocks
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
             const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out, float *part,
-            int *grid_out, void *packed);
+            int *grid_out, int *waves_out, void *packed);
 int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c, int64_t n,
             float *x_out, uint64_t seed, int64_t row0, void *packed);
 constexpr int kWavesBx3 = 8;

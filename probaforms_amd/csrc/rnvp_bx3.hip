@@ -304,8 +304,9 @@ __device__ __forceinline__ void run_stage(const uint32_t *sb, const Geo3 &g, int
 
 // LDS-DMA of one stage: the 8 waves copy its NP 1-KiB pieces (piece = one wave-instruction: wave-uniform LDS base +
 // lane * 16, exactly the fragment layout)
+template <int WAVES>
 __device__ __forceinline__ void issue_stage(const uint32_t *gsrc, uint32_t *ldst, int NP, int wave, int lane) {
-    for (int p = wave; p < NP; p += kWavesBx3) {
+    for (int p = wave; p < NP; p += WAVES) {
         const uint32_t *gp = gsrc + (size_t)p * 256 + lane * 4;
         uint32_t *lp = ldst + p * 256;        // wave-uniform; the hardware adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)gp,
@@ -313,8 +314,11 @@ __device__ __forceinline__ void issue_stage(const uint32_t *gsrc, uint32_t *ldst
     }
 }
 
-template <int NF, int CQ, int R, bool INVERSE, int ACT>
-__global__ void __launch_bounds__(kWavesBx3 * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+// STAGED: the workgroup's WAVES waves share each stage through LDS (above).  !STAGED (d <= 16, where a stage is small and
+// the barrier-paced schedule loses more than the shared copy saves): every wave reads the same stage images straight from
+// global memory, one hidden tile ahead, like the f32 kernels of rnvp_mfma_layer.h -- no LDS, no barriers.
+template <int NF, int CQ, int R, bool INVERSE, int ACT, int WAVES, bool STAGED>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float *x, const float *__restrict__ c,
            const int64_t *__restrict__ row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out,
            float *part, uint64_t seed, int64_t row0) {
@@ -325,7 +329,7 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];       // two stage buffers of g.SD dwords
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, r = lane & 15;
-    const int64_t rows_per_wg = (int64_t)kWavesBx3 * R * 16;
+    const int64_t rows_per_wg = (int64_t)WAVES * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
     const bool full = (g.d == DD) && (g.c == CD) && (((uintptr_t)x | (uintptr_t)out_x) & 15) == 0;
@@ -339,7 +343,9 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
         return wp + ((size_t)l * 2 * g.NCH + rem) * g.SD;
     };
     float wave_sum = 0.f;
-    if ((int64_t)blockIdx.x < ngroups) issue_stage(stage_src(0), lds, g.NP, wave, lane);
+    if constexpr (STAGED) {
+        if ((int64_t)blockIdx.x < ngroups) issue_stage<WAVES>(stage_src(0), lds, g.NP, wave, lane);
+    }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
         float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R];
@@ -362,17 +368,18 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
             }
             ld[rt] = 0.f;
         }
-        const bool more = grp + gridDim.x < ngroups;
+        const bool more = grp + gridDim.x < ngroups; (void)more;
         f4 bin[R][NI];
         f4 out[R][NOUT];
         for (int si = 0; si < nstages; ++si) {
             // stage si has landed (this wave's pieces: vmcnt; every wave's: the barrier), and every wave is done
             // reading the other buffer, which the next stage may now overwrite
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (si + 1 < nstages) issue_stage(stage_src(si + 1), lds + ((si + 1) & 1) * g.SD, g.NP, wave, lane);
-            else if (more) issue_stage(stage_src(0), lds + ((si + 1) & 1) * g.SD, g.NP, wave, lane);
-            const uint32_t *sb = lds + (si & 1) * g.SD;
+            if constexpr (STAGED) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (si + 1 < nstages) issue_stage<WAVES>(stage_src(si + 1), lds + ((si + 1) & 1) * g.SD, g.NP, wave, lane);
+                else if (more) issue_stage<WAVES>(stage_src(0), lds + ((si + 1) & 1) * g.SD, g.NP, wave, lane);
+            }
             const int lp = si / (2 * g.NCH), rem = si % (2 * g.NCH);
             const int l = INVERSE ? L - 1 - lp : lp;
             const int net = rem / g.NCH, ch = rem % g.NCH;
@@ -388,8 +395,15 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
                         else out[rt][u] = *reinterpret_cast<const f4 *>(b2base + (size_t)l * g.b2_floats + (u * 4 + q) * 4);
                     }
             }
-            if (net == 0) run_stage<NF, CQ, R, 0, ACT, NOUT>(sb, g, lane, nt, bin, out);
-            else run_stage<NF, CQ, R, 1, ACT, NOUT>(sb, g, lane, nt, bin, out);
+            if constexpr (STAGED) {
+                const uint32_t *sb = lds + (si & 1) * g.SD;
+                if (net == 0) run_stage<NF, CQ, R, 0, ACT, NOUT>(sb, g, lane, nt, bin, out);
+                else run_stage<NF, CQ, R, 1, ACT, NOUT>(sb, g, lane, nt, bin, out);
+            } else {
+                const uint32_t *__restrict__ sb = stage_src(si);
+                if (net == 0) run_stage<NF, CQ, R, 0, ACT, NOUT>(sb, g, lane, nt, bin, out);
+                else run_stage<NF, CQ, R, 1, ACT, NOUT>(sb, g, lane, nt, bin, out);
+            }
             if (rem == 2 * g.NCH - 1) {                      // layer end: affine update of the transformed features
                 f4 bias2 = f4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (X4) bias2 = *reinterpret_cast<const f4 *>(b2base + (size_t)l * g.b2_floats + q * 4);
@@ -444,7 +458,7 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
             }
         }
     }
-    if (!INVERSE && part && lane == 0) part[blockIdx.x * kWavesBx3 + wave] = wave_sum;
+    if (!INVERSE && part && lane == 0) part[blockIdx.x * WAVES + wave] = wave_sum;
 }
 
 #ifndef RNVP_BX3_R8
@@ -460,23 +474,35 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
 // 2.75 / 3.35 (spills); C3 (NF 4) read-before-use loop R = 2 / 3 / 4: 4.24 / 4.03 / 3.80, pipelined R = 2: 3.93.
 template <int NF, int CQ> struct RowsBx3 { static constexpr int value = NF == 8 ? RNVP_BX3_R8 : (NF == 4 ? RNVP_BX3_R4 : RNVP_BX3_R2); };
 
+#ifndef RNVP_BX3_DIRECT_R2
+#define RNVP_BX3_DIRECT_R2 3
+#endif
+// d <= 16: the barrier-free form (4 waves, stages read from global memory); wider rows: LDS-staged, 8 waves
+template <int NF> struct DirectBx3 { static constexpr bool value = NF == 2 && RNVP_BX3_DIRECT_R2 > 0; };
+
 template <int NF, int CQ, bool INVERSE, int ACT>
 int launch(hipStream_t st, const KShape &k, const Geo3 &g, const uint32_t *packed, const float *x, const float *c,
            const int64_t *row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out, float *part,
-           int *grid_out, uint64_t seed, int64_t row0) {
-    constexpr int R = RowsBx3<NF, CQ>::value;
-    auto kern = k_flow_bx3<NF, CQ, R, INVERSE, ACT>;
+           int *grid_out, int *waves_out, uint64_t seed, int64_t row0) {
+    constexpr bool DIRECT = DirectBx3<NF>::value;
+    constexpr int R = DIRECT ? (RNVP_BX3_DIRECT_R2 > 0 ? RNVP_BX3_DIRECT_R2 : 1) : RowsBx3<NF, CQ>::value;
+    constexpr int WAVES = DIRECT ? 4 : kWavesBx3;
+    auto kern = k_flow_bx3<NF, CQ, R, INVERSE, ACT, WAVES, !DIRECT>;
     static std::atomic<uint64_t> attr_done{0};
-    const size_t lds_bytes = (size_t)2 * g.SD * sizeof(uint32_t);
-    const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
-    if (arc) return arc;
-    const int64_t rows_per_wg = (int64_t)kWavesBx3 * R * 16;
+    const size_t lds_bytes = DIRECT ? 0 : (size_t)2 * g.SD * sizeof(uint32_t);
+    if (!DIRECT) {
+        const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
+        if (arc) return arc;
+    }
+    const int64_t rows_per_wg = (int64_t)WAVES * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
-    const int grid = (int)(ngroups < kMaxGridBx3 ? ngroups : kMaxGridBx3);
+    const int maxgrid = DIRECT ? kMaxGridBx3 * (kWavesBx3 / 4) : kMaxGridBx3;          // same bound on grid * waves
+    const int grid = (int)(ngroups < maxgrid ? ngroups : maxgrid);
     if (grid_out) *grid_out = grid;
+    if (waves_out) *waves_out = WAVES;
     {
         const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWavesBx3 * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt,
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt,
                               x, c, row_index, n, out_x, logdet_out, logp_out, part, seed, row0);
     }
     RNVP_HIP_TRY(hipGetLastError());
@@ -486,14 +512,14 @@ int launch(hipStream_t st, const KShape &k, const Geo3 &g, const uint32_t *packe
 template <bool INVERSE>
 int dispatch(hipStream_t st, const KShape &k, const Geo3 &g, const uint32_t *packed, const float *x, const float *c,
              const int64_t *row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out, float *part,
-             int *grid_out, uint64_t seed, int64_t row0) {
+             int *grid_out, int *waves_out, uint64_t seed, int64_t row0) {
 #define RNVP_CASE(nf, cq)                                                                                          \
     if (g.NF == nf && g.CQ == cq) {                                                                                \
         if (k.act == RNVP_ACT_TANH)                                                                                \
             return launch<nf, cq, INVERSE, 0>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out, part, \
-                                              grid_out, seed, row0);                                               \
+                                              grid_out, waves_out, seed, row0);                                    \
         return launch<nf, cq, INVERSE, 1>(st, k, g, packed, x, c, row_index, n, out_x, logdet_out, logp_out, part,    \
-                                          grid_out, seed, row0);                                                   \
+                                          grid_out, waves_out, seed, row0);                                        \
     }
     RNVP_CASE(2, 1) RNVP_CASE(2, 0) RNVP_CASE(4, 2) RNVP_CASE(8, 4)
 #undef RNVP_CASE
@@ -520,12 +546,12 @@ size_t packed_bytes(const KShape &k) {
 
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
             const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out, float *part,
-            int *grid_out, void *packed) {
+            int *grid_out, int *waves_out, void *packed) {
     const Geo3 g = make_geo3(k.d, k.c, k.nout[0]);
     int rc = pack(st, k, g, params, static_cast<uint32_t *>(packed));
     if (rc) return rc;
     return dispatch<false>(st, k, g, static_cast<const uint32_t *>(packed), x, c, row_index, n, z_out, logdet_out, logp_out,
-                           part, grid_out, 0, 0);
+                           part, grid_out, waves_out, 0, 0);
 }
 
 int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c, int64_t n,
@@ -534,7 +560,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const float *z
     int rc = pack(st, k, g, params, static_cast<uint32_t *>(packed));
     if (rc) return rc;
     return dispatch<true>(st, k, g, static_cast<const uint32_t *>(packed), z, c, nullptr, n, x_out, nullptr, nullptr, nullptr,
-                          nullptr, seed, row0);
+                          nullptr, nullptr, seed, row0);
 }
 
 }  // namespace bx3

@@ -322,8 +322,8 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
     float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + flow_packed_bytes(k));
     int grid = 0, waves = kWaves, rc;
     if (k.prec == RNVP_PREC_BX3) {
-        waves = bx3::kWavesBx3;
-        rc = bx3::forward(st, k, params, x, c, row_index, n, z_out, logdet_out, logp_out, logp_sum ? part : nullptr, &grid, ws);
+        rc = bx3::forward(st, k, params, x, c, row_index, n, z_out, logdet_out, logp_out, logp_sum ? part : nullptr, &grid,
+                          &waves, ws);
     } else {
         rc = pack_weights(st, k, g, params, packed);
         if (rc) return rc;
