@@ -119,17 +119,18 @@ def cpu_baseline(X, C, rows=4 * BATCH):
     1.10x / combined 1.00x the reference's rows/s on the same 8 cores).  Bounded sample: one epoch over `rows` rows of the
     C2 data + sampling `rows` rows (the 1:1 mix of a GPU step), after a one-batch warm-up; two thread counts, best kept."""
     from oracle.torch_cpu import timed_fit_and_sample
-    ncpu = os.cpu_count() or 2
-    cands = sorted({min(64, max(1, ncpu // 2)), min(16, ncpu)})
+    from probaforms_amd._engine import effective_cpus
+    ncpu, grant = os.cpu_count() or 2, effective_cpus()               # CPUs shown / CPUs the cgroup quota grants
+    cands = sorted({max(1, grant), max(1, grant // 2)})
     runs = [timed_fit_and_sample(LAYERS, D, CDIM, HIDDEN, X[:rows], C[:rows], BATCH, t) for t in cands]
     best = max(runs, key=lambda r: r["combined_rows_per_s"])
     import torch
     return dict(value=best["combined_rows_per_s"], unit="rows/s", cores=best["threads"], kind="port",
                 sample="oracle/torch_cpu.py (eager PyTorch %s CPU ops in the reference's order, float32) with %d torch threads "
-                       "on a %d-CPU host: 1 epoch of 65536-row batches over %d rows (%.1f s = %.1f k rows/s) + sampling %d rows "
+                       "on a %d-CPU host (CPU quota of this process: %d): 1 epoch of 65536-row batches over %d rows (%.1f s = %.1f k rows/s) + sampling %d rows "
                        "(%.1f s = %.1f k rows/s); thread counts tried: %s; in the build container this loop runs at 1.00x the "
                        "reference's own combined rate on the same 8 cores"
-                       % (torch.__version__, best["threads"], ncpu, rows, best["t_fit"], best["fit_rows_per_s"] / 1e3, rows,
+                       % (torch.__version__, best["threads"], ncpu, grant, rows, best["t_fit"], best["fit_rows_per_s"] / 1e3, rows,
                           best["t_sample"], best["sample_rows_per_s"] / 1e3,
                           ", ".join("%d: %.1f k" % (r["threads"], r["combined_rows_per_s"] / 1e3) for r in runs)))
 
@@ -141,7 +142,8 @@ def cpu_baseline_oracle(X, C, params, rows_per_thread=8192):
     (ctypes releases the GIL); each computes the gradient of its shard like a data-parallel rank would."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import Oracle, Shape
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    from probaforms_amd._engine import effective_cpus
+    cores = max(1, min(effective_cpus(), 64))
     rows = rows_per_thread * cores
     rows = min(rows, X.shape[0])
     o = Oracle(32)
@@ -190,6 +192,63 @@ def api_level(Xh, Ch, dev):
     return out
 
 
+def secondary_configs(Xh, Ch, dev):
+    """after the timed region, never `value`: BASELINE.json configs[4] (CVAE on the C2 arrays: one fused training step on
+    65 536 rows, device resident) and the C2 flow at the reference's DEFAULT batch size of 32 (realnvp.py:161: a latency
+    regime: one fused step = three launches)."""
+    import torch
+    from probaforms_amd import _engine, _hip
+    from probaforms_amd.models import CVAE, NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    out = {}
+    X = torch.from_numpy(Xh).to(dev); C = torch.from_numpy(Ch).to(dev)
+    # C5
+    torch.manual_seed(0)
+    m = CVAE(latent_dim=2, hidden=HIDDEN, batch_size=BATCH, n_epochs=1, lr=1e-3, noise_rng="device")
+    m.fit(Xh[:BATCH], Ch[:BATCH])
+    core = m._core
+    eps = torch.randn(BATCH, 2, device=dev); idx = torch.randperm(N_ROWS, device=dev)[:BATCH].contiguous()
+    g = core.grads(); ws = core.workspace(BATCH)
+    def cvae_step(t):
+        _hip.cvae_loss_grad(core.shape, core.sync(), X, C, idx, eps, BATCH, 1.0 / BATCH, 0.001, g[:core.P], g[core.P:core.P + 1], ws)
+        _hip.adam_step(core.sync(), g[:core.P], m.opt.exp_avg[:core.P], m.opt.exp_avg_sq[:core.P], core.P, 1e-3, 0.9, 0.999, 1e-8, 0.0, t)
+    for t in range(3):
+        cvae_step(t + 1)
+    torch.cuda.synchronize(dev)
+    _hip.profile_enable(64)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = 20
+    e0.record()
+    for t in range(K):
+        cvae_step(t + 4)
+    e1.record(); torch.cuda.synchronize(dev)
+    n_k, k_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
+    _hip.profile_enable(0)
+    flop_row = 3 * 2 * ((D + CDIM) * HIDDEN[0] + HIDDEN[0] * 4 + (2 + CDIM) * HIDDEN[0] + HIDDEN[0] * D)
+    step_ms = e0.elapsed_time(e1) / K
+    out["cvae_c5"] = {"workload": "CVAE latent 2, hidden (128,), d=16 cond=4: loss+grad+Adam on 65536 rows, device resident",
+                      "ms_per_step": step_ms, "rows_per_s": BATCH / (step_ms * 1e-3),
+                      "kernel_ms": k_ms / max(n_k, 1), "useful_flop_per_row": flop_row,
+                      "roofline_frac_f32_mfma": flop_row * BATCH / (k_ms / max(n_k, 1) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    # C2 flow at batch_size 32
+    torch.manual_seed(0)
+    layers = [RealNVPLayer(D, CDIM, (torch.arange(D) + i) % 2, HIDDEN, "tanh") for i in range(LAYERS)]
+    nf = NormalizingFlow(layers, StandardNormalPrior(D, dev, host_rng=False))
+    for p in nf.parameters():
+        p.data = p.data.to(dev)
+    eng = nf.engine(); opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+    n_small = 32 * 512
+    perm = torch.randperm(n_small, device=dev); losses = torch.zeros(512, device=dev)
+    eng.fit_epoch(opt, X[:n_small], C[:n_small], perm, 32, losses)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    eng.fit_epoch(opt, X[:n_small], C[:n_small], perm, 32, losses)
+    e1.record(); torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) / 512 * 1e3
+    out["c2_batch32"] = {"workload": "the C2 flow at the reference's default batch_size=32: 512 fused steps in one rnvp_fit_epoch call",
+                         "us_per_step": us, "rows_per_s": 32 / (us * 1e-6)}
+    return out
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start the N ranks as children (never exec: the parent has not touched
     the GPU and stays alive only to relay the exit code)."""
@@ -224,6 +283,10 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from probaforms_amd._engine import effective_cpus
+    # torch sizes its CPU thread pool from os.cpu_count(); under a cgroup quota (16 of 256 CPUs on the MI355X boxes) one
+    # parallel host op then gets the whole process throttled for tens of milliseconds
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), effective_cpus())))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -380,6 +443,7 @@ def main():
         params = eng.params.detach().cpu().numpy()
         if world == 1 and not force_dist and not args.no_api_level:
             out["api_level"] = api_level(Xh, Ch, dev)
+            out["secondary_configs"] = secondary_configs(Xh, Ch, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Xh, Ch)
             out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(Xh, Ch, params)

@@ -60,6 +60,32 @@ def permutation_from_seed(n, seed):
     return torch.randperm(n, generator=g)
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (containers often
+    show every host CPU in os.cpu_count() while the quota is a fraction of them -- the MI355X boxes: 256 shown, 16 granted;
+    running more threads than that gets the whole process throttled for the rest of each 100 ms period)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 _PERM_POOL = None
 
 
@@ -86,7 +112,7 @@ class PermutationPrefetcher:
         self.n, self.n_epochs = n, n_epochs
         self.seeds = [draw_loader_seed() for _ in range(n_epochs)]
         if workers is None:          # one serial randperm costs ~11 ns per row: enough of them in flight to keep ahead of the GPU
-            workers = max(1, min(12, (os.cpu_count() or 4) // 2))
+            workers = max(1, min(12, effective_cpus() // 2))
         self.lookahead = max(1, lookahead if lookahead is not None else workers)
         self.pool = _perm_pool(max(1, workers)) if n_epochs >= 1 and n >= 65536 else None
         self.futs = {}
