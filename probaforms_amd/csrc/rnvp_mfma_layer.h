@@ -187,7 +187,18 @@ k_sum_segments(const float *__restrict__ gpart, int G, size_t n4, float *__restr
     const int sgi = blockIdx.y;
     if (i >= n4) return;
     f4 a = f4{0.f, 0.f, 0.f, 0.f};
-    for (int b = sgi; b < G; b += gridDim.y) a += reinterpret_cast<const f4 *>(gpart)[(size_t)b * n4 + i];
+    const f4 *src = reinterpret_cast<const f4 *>(gpart) + i;
+    const int S = gridDim.y;
+    int b = sgi;
+    // eight loads in flight per thread (the partials are read exactly once: a pure HBM stream), added in index order
+    for (; b + 7 * S < G; b += 8 * S) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(b + u * S) * n4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; b < G; b += S) a += __builtin_nontemporal_load(src + (size_t)b * n4);
     reinterpret_cast<f4 *>(seg)[(size_t)sgi * n4 + i] = a;
 }
 
