@@ -399,7 +399,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         f4 v = s0[i];
 #pragma unroll
                         for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
-                        dst[i] = first ? v : v + old;
+                        __builtin_nontemporal_store(first ? v : v + old, &dst[i]);   // read once, by another kernel
                     }
                     if (last_tile && tid < NT2 * 16) {
                         const int i = kWaves * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
@@ -421,7 +421,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         f4 v = s0[i];
 #pragma unroll
                         for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
-                        dst[i] = first ? v : v + old;
+                        __builtin_nontemporal_store(first ? v : v + old, &dst[i]);   // read once, by another kernel
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
                         const int i = FT * TBLK + tid;
