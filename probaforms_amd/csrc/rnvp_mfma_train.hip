@@ -399,7 +399,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         f4 v = s0[i];
 #pragma unroll
                         for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
-                        __builtin_nontemporal_store(first ? v : v + old, &dst[i]);   // read once, by another kernel
+                        dst[i] = first ? v : v + old;
                     }
                     if (last_tile && tid < NT2 * 16) {
                         const int i = kWaves * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
@@ -421,7 +421,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         f4 v = s0[i];
 #pragma unroll
                         for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
-                        __builtin_nontemporal_store(first ? v : v + old, &dst[i]);   // read once, by another kernel
+                        dst[i] = first ? v : v + old;
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
                         const int i = FT * TBLK + tid;
@@ -676,7 +676,15 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, int w2c, const float 
     if (loc >= 0) {
         const float *src = seg + (size_t)l * glayer_floats + loc;
         const size_t stride = (size_t)glayer_floats * k.L;
-        for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];      // segment order: deterministic
+        if (S == kSeg) {            // the usual case: all sixteen loads in flight, then added in segment order
+            float v[kSeg];
+#pragma unroll
+            for (int b = 0; b < kSeg; ++b) v[b] = __builtin_nontemporal_load(src + (size_t)b * stride);
+#pragma unroll
+            for (int b = 0; b < kSeg; ++b) a += v[b];
+        } else {
+            for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];      // segment order: deterministic
+        }
     }
     grad[p] = a;
     if (adam_p) adam_one(adam_p[p], a, adam_m[p], adam_v[p], adam);  // fused optimizer (rnvp_train_step)
