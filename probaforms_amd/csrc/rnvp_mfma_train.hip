@@ -116,7 +116,11 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
                                           const float *__restrict__ scr, float *lds, float *tb,
                                           float *gp_layer, bool first, Stamps &stp, float *xown,
-                                          const float *xother) {
+                                          const float *xother, int tile_lo = 0, int tile_hi = -1) {
+    // NS == 2 (tile split, k_mfma_train_ts): every wave of the workgroup holds the same row tiles; this wave owns net
+    // wave >> 2 and the hidden tiles [tile_lo, tile_hi) of it, writes their weight gradients straight to gp_layer (no
+    // other wave has them) and adds its input-gradient share to those of all kTsWaves waves (xother = the record base).
+    constexpr bool TS = NS == 2;
     unsigned long long t0 = 0; (void)t0;
     STAMP(t0);
     using D = Dims<NF, CQ>;
@@ -125,6 +129,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int q = lane >> 4, r = lane & 15, tid = wave * 64 + lane;
     const int role = NS ? (wave >> 2) : 0;
     const int HT = g.HT;
+    const int ht_lo = TS ? tile_lo : 0, ht_hi = TS ? tile_hi : HT;
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
@@ -211,14 +216,14 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         const float *pA1T = W + (X4 ? g.oA1X : g.oA1T) + ((size_t)net * HT * NGI * 64 + lane) * 4;
         f4 a1[K4], a2t[OTL], a1t[NGI], b1;
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
-        b1 = *reinterpret_cast<const f4 *>(pB1);
+        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)ht_lo * K4 + k4) * 256);
+        b1 = *reinterpret_cast<const f4 *>(pB1 + ht_lo * 16);
 #pragma unroll
-        for (int o = 0; o < OTL; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + o * 256);
+        for (int o = 0; o < OTL; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)ht_lo * OTL + o) * 256);
 #pragma unroll
-        for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + m * 256);
-        for (int ht = 0; ht < HT; ++ht) {
-            const int nx = (kAblate & 64) ? 0 : ((ht + 1 < HT) ? ht + 1 : ht);
+        for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)ht_lo * NGI + m) * 256);
+        for (int ht = ht_lo; ht < ht_hi; ++ht) {
+            const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
             f4 na1[K4], na2t[OTL], na1t[NGI], nb1;
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
@@ -347,7 +352,13 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.p4, t0);
             }
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
-            if (!(kAblate & 2)) {
+            if constexpr (TS) {      // the only share there is: straight to the gradient record
+                float *gd = gp_layer + (size_t)net * netblock + (size_t)ht * TBLK + lane * 4;
+#pragma unroll
+                for (int nt = 0; nt < NTI; ++nt) *reinterpret_cast<f4 *>(gd + nt * 256) = gW1[nt];
+#pragma unroll
+                for (int o = 0; o < OTL; ++o) *reinterpret_cast<f4 *>(gd + (NTI + o) * 256) = gW2[o];
+            } else if (!(kAblate & 2)) {
                 float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) *reinterpret_cast<f4 *>(sb + nt * 256) = gW1[nt];
@@ -371,7 +382,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             }
             const bool last_tile = (ht + 1 == HT);
             STAMP_ADD(stp.p5, t0);
-            if (((ht + 1) % FT == 0 || last_tile) && !(kAblate & 4)) {
+            if (!TS && ((ht + 1) % FT == 0 || last_tile) && !(kAblate & 4)) {
                 if (last_tile && net == 1) {
                     // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
 #pragma unroll
@@ -445,7 +456,22 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
         }
     };
-    if constexpr (NS) {
+    if constexpr (TS) {
+        if (ht_lo < ht_hi) {
+            if (role == 0) net_pass(std::integral_constant<int, 0>{});
+            else net_pass(std::integral_constant<int, 1>{});
+        }
+        if (wave == 0) {         // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
+#pragma unroll
+            for (int ot = 0; ot < NT2; ++ot)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v = gb2[ot][u];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    if (r == 0) gp_layer[2 * (size_t)netblock + (ot * 4 + q) * 4 + u] = v;
+                }
+        }
+    } else if constexpr (NS) {
         if (role == 0) net_pass(std::integral_constant<int, 0>{});
         else net_pass(std::integral_constant<int, 1>{});
     } else {
@@ -467,7 +493,22 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             for (int f = 0; f < NF; ++f) gi[rt][f] = (NF >= 4) ? gin[rt][f >> 2][f & 3] : gin[rt][0][f & 1];
         }
     }
-    if constexpr (NS) {          // this wave summed its own net only: add the partner's share (t + s, both waves alike)
+    if constexpr (TS) {          // every wave's share of the input gradient, added in wave order
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = gi[rt][f];
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < kTsWaves; ++w) a += xother[(w * R * NF + rt * NF + f) * 64 + lane];
+                gi[rt][f] = a;
+            }
+    } else if constexpr (NS) {   // this wave summed its own net only: add the partner's share (t + s, both waves alike)
 #pragma unroll
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
@@ -595,6 +636,90 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
                    (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.p1, stp.p2, stp.p3, stp.p4, stp.p5, stp.fb1, stp.fsum, stp.bflush, stp.btail);
     }
 #endif
+}
+
+
+// ---- tile-split step: a batch of at most 32 rows of a d <= 16 flow --------------------------------------------------
+// One workgroup of kTsWaves waves, all holding the same R row tiles (R = 1 / 2); wave w runs a quarter of the hidden
+// tiles of net w >> 2 (layer_forward_ts / layer_bwd with NS == 2).  Against the row-parallel kernel above, where such a
+// batch keeps one or two wave pairs busy for 2 * HT dependent tile steps per layer, a layer is HT / 4 tile steps plus one
+// LDS rendezvous: the reference's default batch_size = 32 (realnvp.py:161) with hidden = (128,): 103 -> 63 us per step.
+// Writes the same gradient records (one "partial") and loss partials as k_mfma_train, so k_mfma_reduce follows unchanged.
+template <int CQ, int R, int ACT>
+__global__ void __launch_bounds__(kTsWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+                const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
+                float *gpart, float *losspart, float *scratch, int glayer_floats, const float *__restrict__ gz) {
+    constexpr int NF = 2;
+    using DM = Dims<NF, CQ>;
+    constexpr int D = 8 * NF, CD = 4 * CQ;
+    constexpr int XW = R * NF * 64, TBN = DM::template tbn<R, 0>();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    float *tb = lds + wave * TBN;
+    float *red = lds + kTsWaves * TBN;                    // 2 x kTsWaves x XW, double buffered by layer parity
+    const int tps = (g.HT + kTsSlices - 1) / kTsSlices, slice = wave & (kTsSlices - 1);
+    const int tile_lo = slice * tps < g.HT ? slice * tps : g.HT;
+    const int tile_hi = tile_lo + tps < g.HT ? tile_lo + tps : g.HT;
+    const float prior_c = 0.5f * (float)g.d * kLog2Pi;
+    const bool full = (g.d == D) && (g.c == CD) && ((uintptr_t)x & 15) == 0;
+    Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R], gy[R][2 * NF], gld[R];
+    bool valid[R];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+        const int64_t row = rt * 16 + r;
+        valid[rt] = row < n;
+        const int64_t src = valid[rt] ? (row_index ? row_index[row] : row) : 0;
+        load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
+        ld[rt] = 0.f;
+    }
+    for (int l = 0; l < L; ++l) {
+        const float *W = wp + (size_t)l * g.layer_floats;
+        float *scr = scratch + (size_t)l * R * 2 * NF * 64;
+        float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
+        if ((l + alt) & 1) layer_forward_ts<CQ, R, 1, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+        else layer_forward_ts<CQ, R, 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+    }
+    __syncthreads();        // wave 0's scratch records; the rendezvous buffers change hands
+    float wave_sum = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < 2 * NF; ++v) ss = fmaf(xr[rt][v], xr[rt][v], ss);
+        float l1 = ld[rt];
+        l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+        const float lp = gz ? l1 : l1 + (-0.5f * ss - prior_c);
+        float v = (valid[rt] && q == 0) ? lp : 0.f;
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        wave_sum += v;
+        const float sc = valid[rt] ? inv_B : 0.f;
+        if (gz) {
+            const int64_t row = rt * 16 + r;
+#pragma unroll
+            for (int u = 0; u < 2 * NF; ++u) {
+                const int j = q * 2 * NF + u;
+                gy[rt][u] = (valid[rt] && j < g.d) ? gz[row * g.d + j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
+        }
+        gld[rt] = -sc;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const float *W = wp + (size_t)l * g.layer_floats;
+        const float *scr = scratch + (size_t)l * R * 2 * NF * 64;
+        float *gpl = gpart + (size_t)l * glayer_floats;
+        float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
+        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
+        else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
+    }
+    // the loss: every wave computed the same sum; k_mfma_reduce adds kWaves partials per workgroup
+    if (lane == 0 && wave < kWaves) losspart[wave] = wave == 0 ? wave_sum : 0.f;
 }
 
 // ---- stage 2: segment sums -> flat reference-order gradient -----------------------------------------
@@ -773,6 +898,31 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 #define RNVP_NET_SPLIT 1
 #endif
 
+#ifndef RNVP_TILE_SPLIT
+#define RNVP_TILE_SPLIT 1
+#endif
+template <int CQ, int R>
+int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
+                    const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
+                    float *scratch, const float *gz) {
+    using DM = Dims<2, CQ>;
+    const size_t lds_bytes = ((size_t)kTsWaves * DM::template tbn<R, 0>() + 2 * (size_t)kTsWaves * R * 2 * 64) * sizeof(float);
+    static std::atomic<uint64_t> attr_done[2] = {{0}, {0}};
+    const int arc = k.act == RNVP_ACT_TANH
+                        ? allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<CQ, R, 0>), 160 * 1024, attr_done[0])
+                        : allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<CQ, R, 1>), 160 * 1024, attr_done[1]);
+    if (arc) return arc;
+    const KernelEvents ev(RNVP_PROFILE_TRAIN);
+    if (k.act == RNVP_ACT_TANH)
+        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 0>), dim3(1), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
+                              packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
+    else
+        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 1>), dim3(1), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
+                              packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
 // layout of the partials a launch wrote (the net-split launches of d <= 16 use the compact dW2 records)
 struct PartialLayout { int glayer_floats, w2c; };
 
@@ -809,6 +959,18 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
                  const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
                  float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
     constexpr int RMAX = TrainRows<NF, CQ>::value;
+    if constexpr (NF == 2 && RNVP_TILE_SPLIT) {
+        // measured (C2 flow, us per fused step, tile split / row parallel): 16 rows 47 / 103, 32 rows 63 / 103, 64 rows
+        // 101 / 103 (four row tiles per wave make the tile step as long as the chain it shortens); h = 256: 95 / 180,
+        // h = 64: 48 / 66, h = 32: 47 / 48
+        if (n <= 32 && g.HT >= 3) {
+            lay->w2c = 0;
+            lay->glayer_floats = pl.glayer_floats;
+            *grid_out = 1;
+            if (n <= 16) return launch_train_ts<CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz);
+            return launch_train_ts<CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz);
+        }
+    }
     const int R = pick_rows(RMAX, n);
 #define RNVP_ROWS(r)                                                                                              \
     if constexpr (RMAX >= r) {                                                                                    \

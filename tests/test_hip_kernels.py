@@ -650,3 +650,40 @@ def test_lmm_row_chunks_add_up():
     xg, cg = x[perm].contiguous(), cc[perm].contiguous()
     _hip.loss_grad(sh, pd, mk, xg, cg, None, n, 1.0 / n, direct[:P], direct[P:], ws)
     assert torch.equal(direct, full)
+
+
+@pytest.mark.parametrize("n", [1, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("d,c,h,act", [(16, 4, 128, "tanh"), (16, 4, 200, "relu"), (5, 0, 17, "tanh"), (2, 1, 64, "relu"),
+                                       (13, 3, 40, "tanh")])
+def test_tile_split_small_batches_vs_oracle(d, c, h, act, n, oracle64):
+    """batches of at most 32 rows of a d <= 16 flow with three or more hidden tiles run the tile-split training kernel
+    (one workgroup, hidden tiles spread over its waves): loss + gradient against the float64 oracle, bitwise
+    repeatable, and the fused Adam step equal to loss_grad + adam_step"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    L = 5
+    rng = np.random.default_rng(d * 1000 + h * 10 + n)
+    shape = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1)
+    assert _hip.kernel_path(shape, None, _hip.OP_TRAIN) == _hip.PATH_MFMA
+    P = _hip.param_count(shape)
+    params = (rng.uniform(-1, 1, size=P) * min(0.5, 1.5 / np.sqrt(h + d + c))).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32) if c else None
+    s = Shape.make(L, d, c, (h,), act)
+    pd, xd, cd = _dev(params), _dev(X), _dev(C)
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, n)
+    grad = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.loss_grad(shape, pd, None, xd, cd, None, n, 1.0 / n, grad, loss, ws)
+    lo, go = oracle64.loss_grad(s, params.astype(np.float64), X.astype(np.float64), None if C is None else C.astype(np.float64))
+    go = np.asarray(go, np.float64)
+    assert abs(float(loss) - float(lo)) < 1e-5 * max(1.0, abs(float(lo)))
+    assert np.abs(grad.cpu().numpy() - go).max() < 5e-6 * np.abs(go).max() + 1e-9
+    g2 = torch.full((P,), float("nan"), device="cuda"); l2 = torch.empty(1, device="cuda")
+    _hip.loss_grad(shape, pd, None, xd, cd, None, n, 1.0 / n, g2, l2, ws)
+    assert torch.equal(grad, g2) and torch.equal(loss, l2)
+    # gathered rows (row_index) give the same numbers as the contiguous copy
+    perm = torch.randperm(n, device="cuda")
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n, device="cuda")
+    xs = xd[perm].contiguous(); cs_ = None if cd is None else cd[perm].contiguous()
+    g3 = torch.empty(P, device="cuda"); l3 = torch.empty(1, device="cuda")
+    _hip.loss_grad(shape, pd, None, xs, cs_, inv, n, 1.0 / n, g3, l3, ws)
+    assert torch.equal(grad, g3) and torch.equal(loss, l3)
