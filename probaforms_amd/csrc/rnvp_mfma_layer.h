@@ -562,8 +562,8 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
     }
 }
 
-// One layer in tile-split mode (d <= 16, a batch of at most 32 rows = ONE workgroup): all kTsWaves waves hold the SAME
-// row tiles; wave w takes net w >> 2 and the hidden tiles [tile0, tile0 + nt) of that net (a quarter of them each), so
+// One layer in tile-split mode (d <= 16, small and medium batches: k_mfma_train_ts): all kTsWaves waves of a workgroup
+// hold the SAME row tiles; wave w takes net w >> 2 and the hidden tiles [tile0, tile0 + nt) of that net (a quarter of them each), so
 // a layer costs HT / 4 tile steps instead of HT -- these launches are pure latency chains.  The waves' partial t / s
 // outputs meet in LDS (`red`: one record of R * 2 * 64 floats per wave, double buffered by layer parity by the caller,
 // one __syncthreads per layer) and every wave adds the eight records in wave order.  MODE 2: wave 0 also writes the

@@ -639,12 +639,15 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
 }
 
 
-// ---- tile-split step: a batch of at most 32 rows of a d <= 16 flow --------------------------------------------------
-// One workgroup of kTsWaves waves, all holding the same R row tiles (R = 1 / 2); wave w runs a quarter of the hidden
-// tiles of net w >> 2 (layer_forward_ts / layer_bwd with NS == 2).  Against the row-parallel kernel above, where such a
-// batch keeps one or two wave pairs busy for 2 * HT dependent tile steps per layer, a layer is HT / 4 tile steps plus one
-// LDS rendezvous: the reference's default batch_size = 32 (realnvp.py:161) with hidden = (128,): 103 -> 63 us per step.
-// Writes the same gradient records (one "partial") and loss partials as k_mfma_train, so k_mfma_reduce follows unchanged.
+// ---- tile-split step: batches of up to RNVP_TS_MAX_ROWS rows of a d <= 16 flow -------------------------------------
+// A workgroup of kTsWaves waves takes 16 R rows (R = 1 / 2), ALL its waves holding those same row tiles; wave w runs a
+// quarter of the hidden tiles of net w >> 2 (layer_forward_ts / layer_bwd with NS == 2).  Small and medium batches are
+// latency chains: the row-parallel kernel above gives such a batch one wave pair per 16 rows, each walking 2 * HT
+// dependent tile steps per layer; here a layer is HT / 4 tile steps plus one LDS rendezvous, and while the batch needs
+// at most one workgroup per CU the step time is that of one workgroup.  C2 flow, fused step (us, tile split / row
+// parallel): 32 rows 47 / 103, 256: 51 / 106, 1024: 59 / 107, 4096: 66 / 113, 8192: 82 / 116, 16384: 119 / 120.
+// Every workgroup writes the same gradient record and loss partials as k_mfma_train: k_sum_segments / k_mfma_reduce
+// follow unchanged.
 template <int CQ, int R, int ACT>
 __global__ void __launch_bounds__(kTsWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
@@ -665,11 +668,15 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
     const bool full = (g.d == D) && (g.c == CD) && ((uintptr_t)x & 15) == 0;
     Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // workgroup b: rows [16 R b, 16 R (b + 1)), its own gradient record, scratch records and loss partials
+    const int64_t row0 = (int64_t)blockIdx.x * R * 16;
+    gpart += (size_t)blockIdx.x * glayer_floats * L;
+    scratch += (size_t)blockIdx.x * L * R * 2 * NF * 64;
     float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R], gy[R][2 * NF], gld[R];
     bool valid[R];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
-        const int64_t row = rt * 16 + r;
+        const int64_t row = row0 + rt * 16 + r;
         valid[rt] = row < n;
         const int64_t src = valid[rt] ? (row_index ? row_index[row] : row) : 0;
         load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
@@ -698,7 +705,7 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         wave_sum += v;
         const float sc = valid[rt] ? inv_B : 0.f;
         if (gz) {
-            const int64_t row = rt * 16 + r;
+            const int64_t row = row0 + rt * 16 + r;
 #pragma unroll
             for (int u = 0; u < 2 * NF; ++u) {
                 const int j = q * 2 * NF + u;
@@ -719,7 +726,7 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
     }
     // the loss: every wave computed the same sum; k_mfma_reduce adds kWaves partials per workgroup
-    if (lane == 0 && wave < kWaves) losspart[wave] = wave == 0 ? wave_sum : 0.f;
+    if (lane == 0 && wave < kWaves) losspart[blockIdx.x * kWaves + wave] = wave == 0 ? wave_sum : 0.f;
 }
 
 // ---- stage 2: segment sums -> flat reference-order gradient -----------------------------------------
@@ -901,10 +908,13 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 #ifndef RNVP_TILE_SPLIT
 #define RNVP_TILE_SPLIT 1
 #endif
+#ifndef RNVP_TS_MAX_ROWS
+#define RNVP_TS_MAX_ROWS 8192        // 256 workgroups x 32 rows
+#endif
 template <int CQ, int R>
 int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
                     const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
-                    float *scratch, const float *gz) {
+                    float *scratch, const float *gz, int grid) {
     using DM = Dims<2, CQ>;
     const size_t lds_bytes = ((size_t)kTsWaves * DM::template tbn<R, 0>() + 2 * (size_t)kTsWaves * R * 2 * 64) * sizeof(float);
     static std::atomic<uint64_t> attr_done[2] = {{0}, {0}};
@@ -914,10 +924,10 @@ int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
     if (arc) return arc;
     const KernelEvents ev(RNVP_PROFILE_TRAIN);
     if (k.act == RNVP_ACT_TANH)
-        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 0>), dim3(1), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
+        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 0>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
                               packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
     else
-        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 1>), dim3(1), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
+        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 1>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
                               packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -960,15 +970,16 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
                  float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
     constexpr int RMAX = TrainRows<NF, CQ>::value;
     if constexpr (NF == 2 && RNVP_TILE_SPLIT) {
-        // measured (C2 flow, us per fused step, tile split / row parallel): 16 rows 47 / 103, 32 rows 63 / 103, 64 rows
-        // 101 / 103 (four row tiles per wave make the tile step as long as the chain it shortens); h = 256: 95 / 180,
-        // h = 64: 48 / 66, h = 32: 47 / 48
-        if (n <= 32 && g.HT >= 3) {
+        // one workgroup per 16 rows up to 4096 rows, per 32 rows up to 8192 (numbers above k_mfma_train_ts; with two hidden
+        // tiles per net or fewer there is nothing to split: h = 32 measured 47 vs 48 us)
+        if (n <= RNVP_TS_MAX_ROWS && g.HT >= 3) {
+            const int R = n <= RNVP_TS_MAX_ROWS / 2 ? 1 : 2;
+            const int grid = (int)((n + 16 * R - 1) / (16 * R));
             lay->w2c = 0;
             lay->glayer_floats = pl.glayer_floats;
-            *grid_out = 1;
-            if (n <= 16) return launch_train_ts<CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz);
-            return launch_train_ts<CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz);
+            *grid_out = grid;
+            if (R == 1) return launch_train_ts<CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
+            return launch_train_ts<CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
         }
     }
     const int R = pick_rows(RMAX, n);

@@ -652,12 +652,12 @@ def test_lmm_row_chunks_add_up():
     assert torch.equal(direct, full)
 
 
-@pytest.mark.parametrize("n", [1, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("n", [1, 16, 17, 32, 33, 64, 1000, 4096, 4097, 8192])
 @pytest.mark.parametrize("d,c,h,act", [(16, 4, 128, "tanh"), (16, 4, 200, "relu"), (5, 0, 17, "tanh"), (2, 1, 64, "relu"),
                                        (13, 3, 40, "tanh")])
 def test_tile_split_small_batches_vs_oracle(d, c, h, act, n, oracle64):
-    """batches of at most 32 rows of a d <= 16 flow with three or more hidden tiles run the tile-split training kernel
-    (one workgroup, hidden tiles spread over its waves): loss + gradient against the float64 oracle, bitwise
+    """batches of up to 8192 rows of a d <= 16 flow with three or more hidden tiles run the tile-split training kernel
+    (16 or 32 rows per workgroup, hidden tiles spread over its waves): loss + gradient against the float64 oracle, bitwise
     repeatable, and the fused Adam step equal to loss_grad + adam_step"""
     from oracle import Shape
     from probaforms_amd import _hip
