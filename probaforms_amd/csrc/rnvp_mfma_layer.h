@@ -562,45 +562,76 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
     }
 }
 
-// One layer in tile-split mode (d <= 16, small and medium batches: k_mfma_train_ts): all kTsWaves waves of a workgroup
+// One layer in tile-split mode (small and medium batches: k_mfma_train_ts): all kTsWaves waves of a workgroup
 // hold the SAME row tiles; wave w takes net w >> 2 and the hidden tiles [tile0, tile0 + nt) of that net (a quarter of them each), so
 // a layer costs HT / 4 tile steps instead of HT -- these launches are pure latency chains.  The waves' partial t / s
 // outputs meet in LDS (`red`: one record of R * 2 * 64 floats per wave, double buffered by layer parity by the caller,
 // one __syncthreads per layer) and every wave adds the eight records in wave order.  MODE 2: wave 0 also writes the
 // layer input of the transformed features and exp(s) to scr (read by all waves in the backward).
 constexpr int kTsWaves = 8, kTsSlices = 4;
-template <int CQ, int R, int PC, int ACT>
+template <int NF, int CQ, int R, int PC, int ACT>
 __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, const Geo &g, int lane, int wave, int tile0,
-                                                 int nt, float *red, float (&xr)[R][4],
+                                                 int nt, float *red, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
                                                  float *__restrict__ scr) {
-    constexpr int NF = 2;
+    using D = FwdDims<NF, CQ>;
+    constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4, net = wave >> 2;
-    const f4 bias2 = *reinterpret_cast<const f4 *>(W + g.oB2 + q * 4);
-    f4 outx[R][4];
+    float own[R][NF];           // this wave's share of its net's output for the features each lane owns (no bias)
+    if constexpr (NF == 2 && kUseX4) {
+        f4 outx[R][4];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
+        if (nt > 0) {
+            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx);
+            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx);
+        }
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            float s4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                s4[i] = net == 0 ? swap_add32(outx[rt][0][i], outx[rt][1][i]) : swap_add32(outx[rt][2][i], outx[rt][3][i]);
+            own[rt][0] = swap_add16(s4[0], s4[2]);
+            own[rt][1] = swap_add16(s4[1], s4[3]);
+        }
+    } else {
+        f4 out[R][NT2];
+#pragma unroll
+        for (int ot = 0; ot < NT2; ++ot)
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) out[rt][ot] = f4{0.f, 0.f, 0.f, 0.f};
+        if (nt > 0) {
+            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out);
+            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out);
+        }
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                own[rt][f] = net == 0 ? out[rt][f >> 2][f & 3]
+                                      : out[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][(f & 3) + (NF >= 4 ? 0 : 2)];
+    }
 #pragma unroll
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
-    if (nt > 0) {
-        if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx);
-        else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx);
-    }
-#pragma unroll
-    for (int rt = 0; rt < R; ++rt) {
-        float s4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            s4[i] = net == 0 ? swap_add32(outx[rt][0][i], outx[rt][1][i]) : swap_add32(outx[rt][2][i], outx[rt][3][i]);
-        red[(wave * R * NF + rt * NF + 0) * 64 + lane] = swap_add16(s4[0], s4[2]);
-        red[(wave * R * NF + rt * NF + 1) * 64 + lane] = swap_add16(s4[1], s4[3]);
-    }
+        for (int f = 0; f < NF; ++f) red[(wave * R * NF + rt * NF + f) * 64 + lane] = own[rt][f];
     __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            float tv = bias2[f], sv = bias2[2 + f];
+            // bias of the second Linear: the lane's slot of the t tile(s) and of the s tile(s), as layer_forward reads it
+            float tv, sv;
+            if (NF >= 4) {
+                tv = W[g.oB2 + ((f >> 2) * 4 + q) * 4 + (f & 3)];
+                sv = W[g.oB2 + ((OTL + (f >> 2)) * 4 + q) * 4 + (f & 3)];
+            } else {
+                tv = W[g.oB2 + q * 4 + (f & 1)];
+                sv = W[g.oB2 + q * 4 + 2 + (f & 1)];
+            }
 #pragma unroll
             for (int w = 0; w < kTsSlices; ++w) {
                 tv += red[(w * R * NF + rt * NF + f) * 64 + lane];

@@ -639,21 +639,22 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
 }
 
 
-// ---- tile-split step: batches of up to RNVP_TS_MAX_ROWS rows of a d <= 16 flow -------------------------------------
+// ---- tile-split step: batches of up to RNVP_TS_MAX_ROWS rows (d <= 16; half of that for wider rows) ------------------
 // A workgroup of kTsWaves waves takes 16 R rows (R = 1 / 2), ALL its waves holding those same row tiles; wave w runs a
 // quarter of the hidden tiles of net w >> 2 (layer_forward_ts / layer_bwd with NS == 2).  Small and medium batches are
 // latency chains: the row-parallel kernel above gives such a batch one wave pair per 16 rows, each walking 2 * HT
 // dependent tile steps per layer; here a layer is HT / 4 tile steps plus one LDS rendezvous, and while the batch needs
 // at most one workgroup per CU the step time is that of one workgroup.  C2 flow, fused step (us, tile split / row
-// parallel): 32 rows 47 / 103, 256: 51 / 106, 1024: 59 / 107, 4096: 66 / 113, 8192: 82 / 116, 16384: 119 / 120.
+// parallel): 32 rows 47 / 103, 256: 51 / 106, 1024: 59 / 107, 4096: 66 / 113, 8192: 82 / 116, 16384: 119 / 120;
+// C3 flow (d 32, h 256, L 12): 32 rows 134 / 402, 1024: 161 / 419, 4096: 202 / 435; C4 flow (d 64): 114 / 286, 135 / 294,
+// 162 / 305.
 // Every workgroup writes the same gradient record and loss partials as k_mfma_train: k_sum_segments / k_mfma_reduce
 // follow unchanged.
-template <int CQ, int R, int ACT>
+template <int NF, int CQ, int R, int ACT>
 __global__ void __launch_bounds__(kTsWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
                 const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
                 float *gpart, float *losspart, float *scratch, int glayer_floats, const float *__restrict__ gz) {
-    constexpr int NF = 2;
     using DM = Dims<NF, CQ>;
     constexpr int D = 8 * NF, CD = 4 * CQ;
     constexpr int XW = R * NF * 64, TBN = DM::template tbn<R, 0>();
@@ -686,8 +687,8 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         const float *W = wp + (size_t)l * g.layer_floats;
         float *scr = scratch + (size_t)l * R * 2 * NF * 64;
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
-        if ((l + alt) & 1) layer_forward_ts<CQ, R, 1, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
-        else layer_forward_ts<CQ, R, 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+        else layer_forward_ts<NF, CQ, R, 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
     }
     __syncthreads();        // wave 0's scratch records; the rendezvous buffers change hands
     float wave_sum = 0.f;
@@ -911,23 +912,23 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 #ifndef RNVP_TS_MAX_ROWS
 #define RNVP_TS_MAX_ROWS 8192        // 256 workgroups x 32 rows
 #endif
-template <int CQ, int R>
+template <int NF, int CQ, int R>
 int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
                     const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
                     float *scratch, const float *gz, int grid) {
-    using DM = Dims<2, CQ>;
-    const size_t lds_bytes = ((size_t)kTsWaves * DM::template tbn<R, 0>() + 2 * (size_t)kTsWaves * R * 2 * 64) * sizeof(float);
+    using DM = Dims<NF, CQ>;
+    const size_t lds_bytes = ((size_t)kTsWaves * DM::template tbn<R, 0>() + 2 * (size_t)kTsWaves * R * NF * 64) * sizeof(float);
     static std::atomic<uint64_t> attr_done[2] = {{0}, {0}};
     const int arc = k.act == RNVP_ACT_TANH
-                        ? allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<CQ, R, 0>), 160 * 1024, attr_done[0])
-                        : allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<CQ, R, 1>), 160 * 1024, attr_done[1]);
+                        ? allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<NF, CQ, R, 0>), 160 * 1024, attr_done[0])
+                        : allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<NF, CQ, R, 1>), 160 * 1024, attr_done[1]);
     if (arc) return arc;
     const KernelEvents ev(RNVP_PROFILE_TRAIN);
     if (k.act == RNVP_ACT_TANH)
-        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 0>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
+        hipExtLaunchKernelGGL((k_mfma_train_ts<NF, CQ, R, 0>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
                               packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
     else
-        hipExtLaunchKernelGGL((k_mfma_train_ts<CQ, R, 1>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
+        hipExtLaunchKernelGGL((k_mfma_train_ts<NF, CQ, R, 1>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
                               packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -969,17 +970,21 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
                  const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
                  float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
     constexpr int RMAX = TrainRows<NF, CQ>::value;
-    if constexpr (NF == 2 && RNVP_TILE_SPLIT) {
-        // one workgroup per 16 rows up to 4096 rows, per 32 rows up to 8192 (numbers above k_mfma_train_ts; with two hidden
-        // tiles per net or fewer there is nothing to split: h = 32 measured 47 vs 48 us)
-        if (n <= RNVP_TS_MAX_ROWS && g.HT >= 3) {
-            const int R = n <= RNVP_TS_MAX_ROWS / 2 ? 1 : 2;
+    if constexpr (RNVP_TILE_SPLIT) {
+        // d <= 16: one workgroup per 16 rows up to 4096 rows, per 32 rows up to 8192 (numbers above k_mfma_train_ts); wider
+        // rows: 16 rows per workgroup, up to 4096.  With two hidden tiles per net or fewer there is nothing to split
+        // (h = 32 measured 47 vs 48 us).
+        constexpr int64_t kMaxRows = NF == 2 ? RNVP_TS_MAX_ROWS : RNVP_TS_MAX_ROWS / 2;
+        if (n <= kMaxRows && g.HT >= 3) {
+            const int R = (NF == 2 && n > RNVP_TS_MAX_ROWS / 2) ? 2 : 1;
             const int grid = (int)((n + 16 * R - 1) / (16 * R));
             lay->w2c = 0;
             lay->glayer_floats = pl.glayer_floats;
             *grid_out = grid;
-            if (R == 1) return launch_train_ts<CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
-            return launch_train_ts<CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
+            if constexpr (NF == 2) {
+                if (R == 2) return launch_train_ts<NF, CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
+            }
+            return launch_train_ts<NF, CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
         }
     }
     const int R = pick_rows(RMAX, n);
