@@ -71,7 +71,14 @@ typedef struct rnvp_shape {
     int32_t precision;                /* RNVP_PREC_*: arithmetic of the first Linear of the s/t nets in the forward /
                                          inverse / sampling kernels of the MFMA path (the reference computes in
                                          float32 throughout, realnvp.py:226-228; both settings meet its 1e-5 bar) */
+    int32_t small_calls;              /* RNVP_SMALL_*: how forward / inverse / sampling calls of at most 4096 rows run */
 } rnvp_shape;
+
+#define RNVP_SMALL_INVARIANT 0   /* default: a row's result never depends on how the rows are split into calls (chunks
+                                    of a pipelined draw, shards of ranks and the one-shot call agree bit for bit)      */
+#define RNVP_SMALL_LATENCY   1   /* calls of at most 4096 rows run the tile-split kernels (a workgroup's waves share 16 rows
+                                    and split the hidden tiles): 2-4x lower latency; the hidden tiles are summed in
+                                    another order, so results differ from larger calls in the last bits              */
 
 #define RNVP_PREC_AUTO 0         /* the faster of the two for the shape: BX3 for d > 16 or cdim > 4 (measured 1.3-1.4x), F32 else */
 #define RNVP_PREC_F32  1         /* f32-input MFMA (v_mfma_f32_16x16x4_f32): bitwise an fmaf chain          */

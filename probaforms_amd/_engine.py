@@ -238,7 +238,7 @@ class FlowEngine:
     layers: list of RealNVPLayer with identical (var_size, cond_size, hidden, activation).
     """
 
-    def __init__(self, layers, device, precision=None):
+    def __init__(self, layers, device, precision=None, small_calls=None):
         require_hip(device)
         self.device = torch.device(device)
         l0 = layers[0]
@@ -247,7 +247,8 @@ class FlowEngine:
         for l in layers:
             if (l.var_size, l.cond_size, tuple(l.hidden), l.activation) != (self.d, self.c, self.hidden, self.activation):
                 raise ValueError("all coupling layers of a flow must share var_size, cond_size, hidden and activation")
-        self.shape = _hip.RnvpShape.make(self.L, self.d, self.c, self.hidden, self.activation, precision=precision)
+        self.shape = _hip.RnvpShape.make(self.L, self.d, self.c, self.hidden, self.activation, precision=precision,
+                                         small_calls=_hip.SMALL_CALLS[small_calls or 'invariant'])
         self.param_list = [p for l in layers for p in l.parameters()]
         self.P = sum(p.numel() for p in self.param_list)
         if self.P != _hip.param_count(self.shape):

@@ -27,14 +27,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RNVP_HIP_LIB") or os.path.join(_HERE, "csrc", "librnvp_hip.so")
 
 
+# rnvp_shape.small_calls: forward / inverse / sampling calls of at most 4096 rows -- 'invariant' (default): a row's result
+# never depends on how the rows are split into calls; 'latency': tile-split kernels, 2-4x lower latency, last-bit differences
+SMALL_CALLS = {"invariant": 0, "latency": 1}
+
+
 class RnvpShape(C.Structure):
     """mirror of `rnvp_shape` (include/rnvp_hip.h)"""
     _fields_ = [("L", C.c_int32), ("d", C.c_int32), ("c", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
-                ("act", C.c_int32), ("alt_masks", C.c_int32), ("precision", C.c_int32)]
+                ("act", C.c_int32), ("alt_masks", C.c_int32), ("precision", C.c_int32), ("small_calls", C.c_int32)]
 
     @classmethod
-    def make(cls, L, d, c, hidden, activation, alt_masks=0, precision=None):
+    def make(cls, L, d, c, hidden, activation, alt_masks=0, precision=None, small_calls=0):
         hidden = tuple(int(h) for h in hidden)
         if not 1 <= len(hidden) <= MAX_HIDDEN:
             raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
@@ -45,6 +50,7 @@ class RnvpShape(C.Structure):
         s.act = 0 if activation == "tanh" else 1     # anything else is ReLU, realnvp.py:32-37
         s.alt_masks = int(alt_masks)
         s.precision = PRECISIONS[DEFAULT_PRECISION if precision is None else precision]
+        s.small_calls = int(small_calls)             # SMALL_INVARIANT (0) / SMALL_LATENCY (1)
         return s
 
     @staticmethod

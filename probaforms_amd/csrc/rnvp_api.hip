@@ -84,7 +84,7 @@ int rnvp_profile_read(int kind, int *n_launches, float *total_ms) {
     return RNVP_OK;
 }
 
-int rnvp_version(void) { return 200; }
+int rnvp_version(void) { return 201; }
 
 void rnvp_generic_mode(int mode) { rnvp::lmm::set_mode(mode); }
 

@@ -20,7 +20,9 @@ constexpr float kLog2Pi = 1.8378770664093453f;   // ln(2*pi)
 struct KShape {
     int L, d, c, nh, act;
     int alt;                           // rnvp_shape::alt_masks (0 arbitrary, 1/2 alternating)
-    int prec;                          // rnvp_shape::precision (RNVP_PREC_*)
+    int prec;                          // rnvp_shape::precision (RNVP_PREC_*), RNVP_PREC_AUTO resolved
+    int prec_auto;                     // the caller left the choice to the library (RNVP_PREC_AUTO)
+    int small_latency;                 // rnvp_shape::small_calls == RNVP_SMALL_LATENCY
     int nin[kMaxLin], nout[kMaxLin];   // Linear k: [nout, nin]
     int woff[kMaxLin], boff[kMaxLin];  // float offsets inside one net's parameter block
     int npn;                           // parameters per net
@@ -39,6 +41,9 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     if (s->precision < RNVP_PREC_AUTO || s->precision > RNVP_PREC_BX3) return RNVP_EINVAL;
     // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) --
     // measured 1.3-1.4x there; the d <= 16 geometry gains nothing from it and keeps the f32 kernels
+    if (s->small_calls != RNVP_SMALL_INVARIANT && s->small_calls != RNVP_SMALL_LATENCY) return RNVP_EINVAL;
+    k->small_latency = s->small_calls == RNVP_SMALL_LATENCY;
+    k->prec_auto = s->precision == RNVP_PREC_AUTO;
     k->prec = s->precision == RNVP_PREC_AUTO ? ((s->d > 16 || s->c > 4) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;

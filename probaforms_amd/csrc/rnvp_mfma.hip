@@ -224,6 +224,79 @@ k_mfma_flow(const float *__restrict__ wp, Geo g, int L, int alt, const float *x,
     if (!INVERSE && part && lane == 0) part[blockIdx.x * kWaves + wave] = wave_sum;
 }
 
+
+// ---- tile-split forward / inverse: calls of up to kTsFlowMaxRows rows ------------------------------------------------
+// Same idea as k_mfma_train_ts (rnvp_mfma_train.hip): such calls are latency chains of 2 * HT tile steps per layer in the
+// kernel above; here a workgroup of kTsWaves waves takes 16 rows, every wave holds them, wave w runs a quarter of the
+// hidden tiles of net w >> 2 and the partial net outputs meet in LDS once per layer.  Wave 0 writes the results.
+#ifndef RNVP_TILE_SPLIT
+#define RNVP_TILE_SPLIT 1
+#endif
+constexpr int64_t kTsFlowMaxRows = 4096;
+template <int NF, int CQ, bool INVERSE, int ACT>
+__global__ void __launch_bounds__(kTsWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+k_mfma_flow_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float *x, const float *__restrict__ c,
+               const int64_t *__restrict__ row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out,
+               float *part, uint64_t seed, int64_t row0) {
+    constexpr int D = 8 * NF, CD = 4 * CQ, R = 1, XW = R * NF * 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // 2 x kTsWaves x XW, double buffered by layer parity
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int tps = (g.HT + kTsSlices - 1) / kTsSlices, slice = wave & (kTsSlices - 1);
+    const int tile_lo = slice * tps < g.HT ? slice * tps : g.HT;
+    const int tile_hi = tile_lo + tps < g.HT ? tile_lo + tps : g.HT;
+    const float prior_c = 0.5f * (float)g.d * kLog2Pi;
+    const bool full = (g.d == D) && (g.c == CD) && (((uintptr_t)x | (uintptr_t)out_x) & 15) == 0;
+    const bool gen = INVERSE && x == nullptr;
+    const int64_t row = (int64_t)blockIdx.x * 16 + r;
+    const bool valid = row < n;
+    const int64_t src = valid ? (row_index ? row_index[row] : row) : 0;
+    float xr[R][2 * NF], cr[R][CQ > 0 ? CQ : 1], ld[R];
+    if (gen) {
+        load_row<NF, CQ, false>(x, c, src, g.d, g.c, full, q, xr[0], cr[0]);
+#pragma unroll
+        for (int b = 0; b < 2 * NF / 4; ++b) {
+            float z4[4];
+            prior_normal4(seed, row0 + row, (q * 2 * NF) / 4 + b, z4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[0][4 * b + e] = (q * 2 * NF + 4 * b + e < g.d) ? z4[e] : 0.f;
+        }
+    } else {
+        load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[0], cr[0]);
+    }
+    ld[0] = 0.f;
+    for (int lp = 0; lp < L; ++lp) {
+        const int l = INVERSE ? L - 1 - lp : lp;
+        const float *W = wp + (size_t)l * g.layer_floats;
+        float *rb = lds + (size_t)(lp & 1) * kTsWaves * XW;
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, INVERSE ? 1 : 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, nullptr);
+        else layer_forward_ts<NF, CQ, R, 0, INVERSE ? 1 : 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, nullptr);
+    }
+    if (wave != 0) {
+        if (!INVERSE && part && lane == 0 && wave < kWaves) part[blockIdx.x * kWaves + wave] = 0.f;
+        return;
+    }
+    if (out_x && valid) store_row<NF>(out_x, row, g.d, full, q, xr[0]);
+    if (!INVERSE) {
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < 2 * NF; ++v) ss = fmaf(xr[0][v], xr[0][v], ss);
+        float l1 = ld[0];
+        l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+        const float lpv = l1 + (-0.5f * ss - prior_c);          // nflow.py:115
+        if (valid && q == 0) {
+            if (logdet_out) logdet_out[row] = l1;
+            if (logp_out) logp_out[row] = lpv;
+        }
+        if (part) {
+            float v = (valid && q == 0) ? lpv : 0.f;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (lane == 0) part[blockIdx.x * kWaves] = v;
+        }
+    }
+}
+
 #ifndef RNVP_FLOW_R2
 #define RNVP_FLOW_R2 4
 #endif
@@ -246,6 +319,19 @@ template <int NF, int CQ, bool INVERSE, int ACT, int R = RowTiles<NF, CQ>::value
 int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *packed, const float *x,
                 const float *c, const int64_t *row_index, int64_t n, float *out_x, float *logdet_out,
                 float *logp_out, float *part, int *grid_out, uint64_t seed = 0, int64_t row0 = 0) {
+    if constexpr (RNVP_TILE_SPLIT && R == RowTiles<NF, CQ>::value) {
+        if (k.small_latency && n <= kTsFlowMaxRows && g.HT >= 3) {      // whole call, 1024 rows: C2 55 -> 24 us, C3 217 -> 49, C4 70 -> 42
+            const int grid = (int)((n + 15) / 16);
+            *grid_out = grid;
+            const size_t lds_bytes = (size_t)2 * kTsWaves * NF * 64 * sizeof(float);
+            const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
+            hipExtLaunchKernelGGL((k_mfma_flow_ts<NF, CQ, INVERSE, ACT>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start,
+                                  ev.stop, 0, packed, g, k.L, k.alt, x, c, row_index, n, out_x, logdet_out, logp_out, part, seed,
+                                  row0);
+            RNVP_HIP_TRY(hipGetLastError());
+            return RNVP_OK;
+        }
+    }
     // Small calls: 4 row tiles per wave would leave CUs idle and one wave per SIMD; halve the tile
     // count so twice as many workgroups are in flight (measured on C2: 32768 rows 88 -> 63 us; from
     // 65536 rows up R = 4 wins).  A row's result does not depend on R.
@@ -313,6 +399,12 @@ size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
     return flow_packed_bytes(k) + align_up((size_t)kMaxGrid * kWaves * sizeof(float), 256);
 }
 
+// rnvp_shape.small_calls = RNVP_SMALL_LATENCY: short calls run the tile-split f32 kernel whatever `auto` would pick for
+// long ones (the bx3 kernels need whole stages per workgroup; an explicit precision = bx3 is honoured)
+static bool ts_flow(const KShape &k, const Geo &g, int64_t n) {
+    return RNVP_TILE_SPLIT && k.small_latency && n <= kTsFlowMaxRows && g.HT >= 3 && (k.prec != RNVP_PREC_BX3 || k.prec_auto);
+}
+
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
             const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out,
             float *logp_sum, void *ws, size_t ws_bytes) {
@@ -321,7 +413,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
     float *packed = static_cast<float *>(ws);
     float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + flow_packed_bytes(k));
     int grid = 0, waves = kWaves, rc;
-    if (k.prec == RNVP_PREC_BX3) {
+    if (k.prec == RNVP_PREC_BX3 && !ts_flow(k, g, n)) {
         rc = bx3::forward(st, k, params, x, c, row_index, n, z_out, logdet_out, logp_out, logp_sum ? part : nullptr, &grid,
                           &waves, ws);
     } else {
@@ -341,8 +433,8 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
 int inverse(hipStream_t st, const KShape &k, const float *params, const float *z, const float *c,
             int64_t n, float *x_out, void *ws, size_t ws_bytes) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
-    if (k.prec == RNVP_PREC_BX3) return bx3::inverse(st, k, params, z, c, n, x_out, 0, 0, ws);
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    if (k.prec == RNVP_PREC_BX3 && !ts_flow(k, g, n)) return bx3::inverse(st, k, params, z, c, n, x_out, 0, 0, ws);
     float *packed = static_cast<float *>(ws);
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
@@ -354,8 +446,8 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const float *z
 int sample(hipStream_t st, const KShape &k, const float *params, const float *c, int64_t n, uint64_t seed,
            int64_t row0, float *x_out, void *ws, size_t ws_bytes) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
-    if (k.prec == RNVP_PREC_BX3) return bx3::inverse(st, k, params, nullptr, c, n, x_out, seed, row0, ws);
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    if (k.prec == RNVP_PREC_BX3 && !ts_flow(k, g, n)) return bx3::inverse(st, k, params, nullptr, c, n, x_out, seed, row0, ws);
     float *packed = static_cast<float *>(ws);
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;

@@ -566,10 +566,10 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
 // hold the SAME row tiles; wave w takes net w >> 2 and the hidden tiles [tile0, tile0 + nt) of that net (a quarter of them each), so
 // a layer costs HT / 4 tile steps instead of HT -- these launches are pure latency chains.  The waves' partial t / s
 // outputs meet in LDS (`red`: one record of R * 2 * 64 floats per wave, double buffered by layer parity by the caller,
-// one __syncthreads per layer) and every wave adds the eight records in wave order.  MODE 2: wave 0 also writes the
-// layer input of the transformed features and exp(s) to scr (read by all waves in the backward).
+// one __syncthreads per layer) and every wave adds the eight records in wave order.  MODE as layer_forward; MODE 2: wave 0
+// also writes the layer input of the transformed features and exp(s) to scr (read by all waves in the backward).
 constexpr int kTsWaves = 8, kTsSlices = 4;
-template <int NF, int CQ, int R, int PC, int ACT>
+template <int NF, int CQ, int R, int PC, int MODE, int ACT>
 __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, const Geo &g, int lane, int wave, int tile0,
                                                  int nt, float *red, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
@@ -638,13 +638,17 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
                 sv += red[((kTsSlices + w) * R * NF + rt * NF + f) * 64 + lane];
             }
             const int e = 2 * f + 1 - PC;
-            const float es = expf(sv), xv = xr[rt][e];
-            if (wave == 0) {
-                scr[((rt * 2 * NF) + f) * 64 + lane] = xv;
-                scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;
+            if (MODE == 1) {
+                xr[rt][e] = (xr[rt][e] - tv) * expf(-sv);
+            } else {
+                const float es = expf(sv), xv = xr[rt][e];
+                if (MODE == 2 && wave == 0) {
+                    scr[((rt * 2 * NF) + f) * 64 + lane] = xv;
+                    scr[((rt * 2 * NF) + NF + f) * 64 + lane] = es;
+                }
+                xr[rt][e] = fmaf(xv, es, tv);
+                ld[rt] += sv;
             }
-            xr[rt][e] = fmaf(xv, es, tv);
-            ld[rt] += sv;
         }
     }
 }

@@ -687,8 +687,8 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         const float *W = wp + (size_t)l * g.layer_floats;
         float *scr = scratch + (size_t)l * R * 2 * NF * 64;
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
-        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
-        else layer_forward_ts<NF, CQ, R, 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
     }
     __syncthreads();        // wave 0's scratch records; the rendezvous buffers change hands
     float wave_sum = 0.f;

@@ -95,13 +95,17 @@ class NormalizingFlow(nn.Module):
     log_prob_samples(X, C) -> [n] per-row log-density (build-only addition).
     """
 
-    def __init__(self, layers, prior, *, precision=None):
+    def __init__(self, layers, prior, *, precision=None, small_calls=None):
         super().__init__()
         self.layers = nn.ModuleList(layers)
         self.prior = prior
         # build-only, keyword-only: arithmetic of the s/t nets' first Linear in the forward / inverse kernels --
         # None / 'auto' (library picks per shape), 'f32', 'bx3' (_hip.PRECISIONS; both meet the 1e-5 parity bar)
         self.precision = precision
+        # build-only, keyword-only: None / 'invariant' (a row's log_prob / sample never depends on how the rows are split
+        # into calls, chunks or ranks) or 'latency' (calls of at most 4096 rows run the tile-split kernels: 2-4x lower
+        # latency, last-bit differences against larger calls) -- _hip.SMALL_CALLS
+        self.small_calls = small_calls
         self._engine_obj = None
 
     # -- engine ------------------------------------------------------------------------------
@@ -115,7 +119,7 @@ class NormalizingFlow(nn.Module):
         require_hip(dev)
         if self._engine_obj is None or self._engine_obj.device != torch.device(dev) \
                 or len(self._engine_obj.layers) != len(self.layers):
-            self._engine_obj = FlowEngine(list(self.layers), dev, precision=self.precision)
+            self._engine_obj = FlowEngine(list(self.layers), dev, precision=self.precision, small_calls=self.small_calls)
         return self._engine_obj
 
     def _fused_prior(self):

@@ -136,10 +136,12 @@ class RealNVP(GenModel):
 
     def __init__(self, n_layers=8, hidden=(10,), activation='tanh',
                  batch_size=32, n_epochs=10, lr=0.0001, weight_decay=0, verbose=0, *, prior_rng='host',
-                 precision=None):
+                 precision=None, small_calls=None):
         super().__init__()
         # build-only, keyword-only: None / 'auto', 'f32' or 'bx3' -- see NormalizingFlow
         self.precision = precision
+        # build-only, keyword-only: None / 'invariant' or 'latency' -- see NormalizingFlow
+        self.small_calls = small_calls
         # build-only, keyword-only: 'host' draws the prior on the global CPU generator like the
         # reference (bit-identical stream, ~25 ms per million 16-d rows); 'device' draws on the GPU
         self.prior_rng = prior_rng
@@ -173,7 +175,8 @@ class RealNVP(GenModel):
                                    mask=((torch.arange(var_size) + i) % 2),
                                    hidden=self.hidden, activation=self.activation)
                       for i in range(self.n_layers)]
-            self.nf = NormalizingFlow(layers=layers, prior=self.prior, precision=self.precision)
+            self.nf = NormalizingFlow(layers=layers, prior=self.prior, precision=self.precision,
+                                      small_calls=self.small_calls)
             eng = self.nf.engine()                 # moves the parameters into one flat HIP buffer
             _, world = dist_info()
             if world > 1:

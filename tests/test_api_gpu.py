@@ -292,3 +292,26 @@ def test_heterogeneous_layer_list_runs_layer_by_layer(oracle32):
     for layer in nf.layers:
         zz, _ = layer.f(zz, torch.from_numpy(C).cuda())
     assert (zz - z).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_small_calls_latency_keyword():
+    """RealNVP(small_calls='latency') (build-only): short sample / log_prob calls run the tile-split kernels and agree with the
+    default mode to float32 rounding; the default mode keeps a row's result independent of the call size"""
+    import torch
+    from probaforms_amd.models import RealNVP
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((3000, 6)).astype(np.float32); C = rng.standard_normal((3000, 2)).astype(np.float32)
+    out = {}
+    for mode in (None, "latency"):
+        torch.manual_seed(0)
+        m = RealNVP(n_layers=4, hidden=(64,), batch_size=512, n_epochs=1, lr=1e-3, prior_rng="device", small_calls=mode)
+        m.fit(X, C)
+        torch.manual_seed(1)
+        xs = m.sample(C[:1000])
+        lp = m.nf.log_prob_samples(torch.from_numpy(X[:1000]).cuda(), torch.from_numpy(C[:1000]).cuda()).cpu().numpy()
+        out[mode] = (xs, lp)
+    assert np.abs(out[None][0] - out["latency"][0]).max() < 2e-4 and np.abs(out[None][1] - out["latency"][1]).max() < 2e-4
+    assert not np.array_equal(out[None][0], out["latency"][0])            # different kernels did run
+    with pytest.raises(KeyError):
+        RealNVP(small_calls="fast").fit(X[:64], C[:64])

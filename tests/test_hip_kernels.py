@@ -689,3 +689,51 @@ def test_tile_split_small_batches_vs_oracle(d, c, h, act, n, oracle64):
     g3 = torch.empty(P, device="cuda"); l3 = torch.empty(1, device="cuda")
     _hip.loss_grad(shape, pd, None, xs, cs_, inv, n, 1.0 / n, g3, l3, ws)
     assert torch.equal(grad, g3) and torch.equal(loss, l3)
+
+
+@pytest.mark.parametrize("n", [1, 17, 1000, 4096])
+@pytest.mark.parametrize("d,c,h,act,prec", [(16, 4, 128, "tanh", "auto"), (5, 0, 40, "relu", "f32"), (32, 8, 256, "tanh", "auto"),
+                                            (64, 16, 100, "relu", "auto"), (50, 3, 48, "tanh", "f32")])
+def test_small_calls_latency_mode_vs_oracle(d, c, h, act, prec, n, oracle32, oracle64):
+    """rnvp_shape.small_calls = RNVP_SMALL_LATENCY: forward (z, log-prob, sum), inverse and fused sampling of short calls on
+    the tile-split kernels against the oracle; the default mode on the same rows agrees to float32 rounding; an explicit
+    precision = bx3 keeps the bx3 kernels"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    L = 4
+    rng = np.random.default_rng(d * 977 + h * 13 + n)
+    lat = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1, precision=prec, small_calls=_hip.SMALL_CALLS["latency"])
+    inv = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1, precision=prec)
+    P = _hip.param_count(lat)
+    params = (rng.uniform(-1, 1, size=P) * min(0.5, 1.5 / np.sqrt(h + d + c))).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32) if c else None
+    s = Shape.make(L, d, c, (h,), act)
+    pd, xd, cd = _dev(params), _dev(X), _dev(C)
+    out = {}
+    for name, shape in (("latency", lat), ("invariant", inv)):
+        z = torch.empty(n, d, device="cuda"); lp = torch.empty(n, device="cuda"); tot = torch.empty(1, device="cuda")
+        _hip.forward_logprob(shape, pd, None, xd, cd, None, n, z, None, lp, tot, _ws(_hip, shape, _hip.OP_FORWARD, n))
+        back = torch.empty_like(z)
+        _hip.inverse(shape, pd, None, z, cd, n, back, _ws(_hip, shape, _hip.OP_INVERSE, n))
+        xs = torch.empty_like(z); zp = torch.empty_like(z); ref = torch.empty_like(z)
+        _hip.sample(shape, pd, None, cd, n, 5, 11, xs, _ws(_hip, shape, _hip.OP_INVERSE, n))
+        _hip.prior_normal(5, 11, n, d, zp)
+        _hip.inverse(shape, pd, None, zp, cd, n, ref, _ws(_hip, shape, _hip.OP_INVERSE, n))
+        assert torch.equal(xs, ref)
+        out[name] = (z.cpu().numpy(), lp.cpu().numpy(), float(tot), back.cpu().numpy(), xs.cpu().numpy())
+    z64, lp64, _ = oracle64.log_prob(s, params, X, C)
+    z32, lp32, _ = oracle32.log_prob(s, params, X, C)
+    scale = max(1.0, float(np.abs(z64).max()))
+    z, lp, tot, back, xs = out["latency"]
+    assert np.abs(z - z64).max() < max(4 * np.abs(z32 - z64).max(), 4e-6 * scale)
+    assert np.abs(lp - lp64).mean() < max(3 * np.abs(lp32 - lp64).mean(), 3e-6 * max(1.0, np.abs(lp64).max()))
+    assert abs(tot - lp64.sum()) < 1e-5 * max(1.0, np.abs(lp64).sum())
+    assert np.abs(back - X).max() < 5e-4 * max(1.0, np.abs(X).max()) * scale
+    zi, lpi, _, _, xsi = out["invariant"]
+    assert np.abs(z - zi).max() < 1e-5 * scale and np.abs(xs - xsi).max() < 2e-4 * max(1.0, np.abs(xsi).max())
+    pinned = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1, precision="bx3", small_calls=_hip.SMALL_CALLS["latency"])
+    zb = torch.empty(n, d, device="cuda"); zc = torch.empty(n, d, device="cuda")
+    invb = _hip.RnvpShape.make(L, d, c, (h,), act, alt_masks=1, precision="bx3")
+    _hip.forward_logprob(pinned, pd, None, xd, cd, None, n, zb, None, None, None, _ws(_hip, pinned, _hip.OP_FORWARD, n))
+    _hip.forward_logprob(invb, pd, None, xd, cd, None, n, zc, None, None, None, _ws(_hip, invb, _hip.OP_FORWARD, n))
+    assert torch.equal(zb, zc)

@@ -202,13 +202,15 @@ def test_shape_struct_matches_the_c_header():
     from conftest import ROOT
     from probaforms_amd import _hip
     src = ('#include <stdio.h>\n#include <stddef.h>\n#include "include/rnvp_hip.h"\n'
-           'int main(void){printf("%zu %zu %zu %zu", sizeof(rnvp_shape), offsetof(rnvp_shape, hidden), '
-           'offsetof(rnvp_shape, alt_masks), offsetof(rnvp_shape, precision));return 0;}\n')
+           'int main(void){printf("%zu %zu %zu %zu %zu", sizeof(rnvp_shape), offsetof(rnvp_shape, hidden), '
+           'offsetof(rnvp_shape, alt_masks), offsetof(rnvp_shape, precision), offsetof(rnvp_shape, small_calls));return 0;}\n')
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-I", ROOT, c, "-o", exe])
-        size, o_hidden, o_alt, o_prec = map(int, subprocess.check_output([exe]).split())
+        size, o_hidden, o_alt, o_prec, o_small = map(int, subprocess.check_output([exe]).split())
     S = _hip.RnvpShape
-    assert (size, o_hidden, o_alt, o_prec) == (ctypes.sizeof(S), S.hidden.offset, S.alt_masks.offset, S.precision.offset)
+    assert (size, o_hidden, o_alt, o_prec, o_small) == (ctypes.sizeof(S), S.hidden.offset, S.alt_masks.offset,
+                                                        S.precision.offset, S.small_calls.offset)
+    assert _hip.SMALL_CALLS == {"invariant": 0, "latency": 1}
     assert _hip.PRECISIONS == {"auto": 0, "f32": 1, "bx3": 2}
