@@ -28,16 +28,16 @@ typedef struct cvae_shape {
     int32_t n_hidden;     /* len(hidden)                                              */
     int32_t hidden[8];
     int32_t act;          /* 0 tanh, 1 relu                             cvae.py:26-32   */
+    int32_t family;       /* 0: the MFMA kernels where the shape allows; 1: the generic kernels (per call;
+                             test / measurement aid: both are checked against the oracle)                */
 } cvae_shape;
 
 size_t cvae_param_count(const cvae_shape *shape);
 size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows);
 
-/* RNVP_PATH_MFMA (d <= 16, c <= 4, lat <= 4, one tanh hidden layer) or RNVP_PATH_GENERIC: which
- * kernels cvae_loss_grad runs for this shape.  cvae_force_generic(1) pins the generic kernels
- * process-wide (test / measurement aid: both paths are checked against the oracle). */
+/* RNVP_PATH_MFMA (d <= 16, c <= 4, lat <= 4, one tanh hidden layer, shape->family == 0) or RNVP_PATH_GENERIC: which
+ * kernels cvae_loss_grad runs for this shape. */
 int cvae_kernel_path(const cvae_shape *shape);
-void cvae_force_generic(int on);
 
 /* loss = KL_weight * (1/B) sum_b KL_b + (1/(B d)) sum_{b,j} (x - x_rec)^2 with 1/B = inv_B, and its
  * gradient wrt every parameter (grad_out [P]; NULL = loss only, the per-epoch evaluation of

@@ -72,7 +72,14 @@ typedef struct rnvp_shape {
                                          inverse / sampling kernels of the MFMA path (the reference computes in
                                          float32 throughout, realnvp.py:226-228; both settings meet its 1e-5 bar) */
     int32_t small_calls;              /* RNVP_SMALL_*: how forward / inverse / sampling calls of at most 4096 rows run */
+    int32_t family;                   /* RNVP_FAMILY_*: which kernels serve a shape OUTSIDE RNVP_PATH_MFMA (several hidden
+                                         layers, user masks, d > 64, cdim > 16).  Per call, not process state: two threads
+                                         may run different families at once.  Test / measurement aid; 0 in production */
 } rnvp_shape;
+
+#define RNVP_FAMILY_AUTO 0       /* RNVP_PATH_LMM whenever a 16-row tile's LDS image fits, else RNVP_PATH_GENERIC          */
+#define RNVP_FAMILY_VALU 1       /* always RNVP_PATH_GENERIC (one thread per row, VALU + LDS)                               */
+#define RNVP_FAMILY_LMM  2       /* as AUTO (kept distinct so that a test can say what it asks for)                          */
 
 #define RNVP_SMALL_INVARIANT 0   /* default: a row's result never depends on how the rows are split into calls (chunks
                                     of a pipelined draw, shards of ranks and the one-shot call agree bit for bit)      */
@@ -90,10 +97,9 @@ typedef struct rnvp_shape {
 #define RNVP_OP_INVERSE  1
 #define RNVP_OP_TRAIN    2
 
+#define RNVP_HIP_VERSION 300     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
+                                    binding must refuse a library that reports another number                      */
 int         rnvp_version(void);
-/* test / measurement aid, process-wide: which kernels serve the shapes outside RNVP_PATH_MFMA --
- * 0 automatic (= 2), 1 always RNVP_PATH_GENERIC, 2 RNVP_PATH_LMM whenever its LDS image fits */
-void        rnvp_generic_mode(int mode);
 const char *rnvp_status_string(int status);
 
 /* number of float32 parameters of the whole flow (2 nets x L layers). */

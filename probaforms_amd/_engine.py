@@ -6,6 +6,7 @@ decides WHICH rows each call sees and keeps the buffers the kernels read and wri
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -87,16 +88,34 @@ def effective_cpus():
 
 
 _PERM_POOL = None
+_PERM_POOL_LOCK = threading.Lock()
+
+
+def _reset_perm_pool_after_fork():
+    """a forked child inherits the executor object but none of its worker threads: submit() would wait forever"""
+    global _PERM_POOL, _PERM_POOL_LOCK
+    _PERM_POOL = None
+    _PERM_POOL_LOCK = threading.Lock()
+
+
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(after_in_child=_reset_perm_pool_after_fork)
 
 
 def _perm_pool(workers):
     """One process-wide pool for the permutation workers: starting a thread costs ~3 ms on the MI355X hosts (measured:
-    12 threads = 39 ms, a quarter of a 32-epoch fit at n = 1M), so the threads are started once and kept."""
+    12 threads = 39 ms, a quarter of a 32-epoch fit at n = 1M), so the threads are started once and kept.  Called from
+    the fitting thread and from CVAE's draw worker: creation is serialised, a pool that has to grow replaces the old one
+    (which finishes what it holds and is shut down without waiting)."""
     global _PERM_POOL
-    if _PERM_POOL is None or _PERM_POOL[1] < workers:
-        from concurrent.futures import ThreadPoolExecutor
-        _PERM_POOL = (ThreadPoolExecutor(max_workers=workers, thread_name_prefix="rnvp-perm"), workers)
-    return _PERM_POOL[0]
+    with _PERM_POOL_LOCK:
+        if _PERM_POOL is None or _PERM_POOL[1] < workers:
+            from concurrent.futures import ThreadPoolExecutor
+            old = _PERM_POOL
+            _PERM_POOL = (ThreadPoolExecutor(max_workers=workers, thread_name_prefix="rnvp-perm"), workers)
+            if old is not None:
+                old[0].shutdown(wait=False)
+        return _PERM_POOL[0]
 
 
 class PermutationPrefetcher:
@@ -451,8 +470,10 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     dev = engine.device
     # the module parameters may have been re-allocated since the last call (nf.cpu(), .float(),
     # load_state_dict(assign=True)): train what the modules hold now, not a stale flat buffer
-    old = engine.flat
-    if engine.sync_params() is not old and world > 1:
+    # Data parallel: rank 0's flat buffer is broadcast at the start of EVERY fit -- P floats once per call.  Whether a
+    # rank re-allocated its parameters is a rank-local fact and must not decide whether a collective is entered.
+    engine.sync_params()
+    if world > 1:
         broadcast_(engine.flat, src=0)
     if perms is None:
         perms = PermutationPrefetcher(n, n_epochs)
@@ -497,6 +518,7 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
     # so the GPU never waits for the host between epochs; loss_history / the progress hook trail by one epoch.
     pending = None
     nxt = upload(0) if n_epochs > 0 else None
+    ok = False
     try:
         for epoch in range(n_epochs):
             perm, ev = nxt
@@ -525,6 +547,10 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
                 done, pending = pending, None
                 read_back(*done)
             pending = (epoch, losses)
+        ok = True
     finally:
-        if pending is not None:
+        # the last epoch's losses; while an exception unwinds (a HIP error, KeyboardInterrupt) nothing is read back: a
+        # device sync could block or raise again and hide the original failure, and a partial epoch must not reach
+        # loss_history or the user's hook
+        if ok and pending is not None:
             read_back(*pending)

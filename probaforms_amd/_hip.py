@@ -12,6 +12,7 @@ import threading
 import torch
 
 MAX_HIDDEN = 8
+ABI_VERSION = 300          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA, PATH_LMM = 0, 1, 2
@@ -30,16 +31,20 @@ LIB_PATH = os.environ.get("RNVP_HIP_LIB") or os.path.join(_HERE, "csrc", "librnv
 # rnvp_shape.small_calls: forward / inverse / sampling calls of at most 4096 rows -- 'invariant' (default): a row's result
 # never depends on how the rows are split into calls; 'latency': tile-split kernels, 2-4x lower latency, last-bit differences
 SMALL_CALLS = {"invariant": 0, "latency": 1}
+# rnvp_shape.family (per call; test / measurement aid): kernels for shapes outside the register-chained MFMA path --
+# 'auto' / 'lmm': the any-shape MFMA kernels whenever their LDS image fits; 'valu': always the one-thread-per-row kernels
+FAMILIES = {"auto": 0, "valu": 1, "lmm": 2}
 
 
 class RnvpShape(C.Structure):
     """mirror of `rnvp_shape` (include/rnvp_hip.h)"""
     _fields_ = [("L", C.c_int32), ("d", C.c_int32), ("c", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
-                ("act", C.c_int32), ("alt_masks", C.c_int32), ("precision", C.c_int32), ("small_calls", C.c_int32)]
+                ("act", C.c_int32), ("alt_masks", C.c_int32), ("precision", C.c_int32), ("small_calls", C.c_int32),
+                ("family", C.c_int32)]
 
     @classmethod
-    def make(cls, L, d, c, hidden, activation, alt_masks=0, precision=None, small_calls=0):
+    def make(cls, L, d, c, hidden, activation, alt_masks=0, precision=None, small_calls=0, family="auto"):
         hidden = tuple(int(h) for h in hidden)
         if not 1 <= len(hidden) <= MAX_HIDDEN:
             raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
@@ -51,6 +56,7 @@ class RnvpShape(C.Structure):
         s.alt_masks = int(alt_masks)
         s.precision = PRECISIONS[DEFAULT_PRECISION if precision is None else precision]
         s.small_calls = int(small_calls)             # SMALL_INVARIANT (0) / SMALL_LATENCY (1)
+        s.family = FAMILIES[family]                  # which kernels serve a shape outside the register-chained MFMA path
         return s
 
     @staticmethod
@@ -75,10 +81,10 @@ class RnvpShape(C.Structure):
 class CvaeShape(C.Structure):
     """mirror of `cvae_shape` (include/cvae_hip.h)"""
     _fields_ = [("d", C.c_int32), ("c", C.c_int32), ("lat", C.c_int32), ("n_hidden", C.c_int32),
-                ("hidden", C.c_int32 * MAX_HIDDEN), ("act", C.c_int32)]
+                ("hidden", C.c_int32 * MAX_HIDDEN), ("act", C.c_int32), ("family", C.c_int32)]
 
     @classmethod
-    def make(cls, d, c, lat, hidden, activation):
+    def make(cls, d, c, lat, hidden, activation, family="auto"):
         hidden = tuple(int(h) for h in hidden)
         if not 1 <= len(hidden) <= MAX_HIDDEN:
             raise ValueError("hidden must have 1..%d entries, got %r" % (MAX_HIDDEN, hidden))
@@ -87,6 +93,7 @@ class CvaeShape(C.Structure):
         for i, h in enumerate(hidden):
             s.hidden[i] = h
         s.act = 0 if activation == "tanh" else 1       # cvae.py:26-32
+        s.family = {"auto": 0, "generic": 1}[family]   # per call: pin the generic kernels (test / measurement aid)
         return s
 
 
@@ -103,7 +110,6 @@ _SP = C.POINTER(RnvpShape)
 _SIGNATURES = {
     "rnvp_version": (C.c_int, []),
     "rnvp_status_string": (C.c_char_p, [C.c_int]),
-    "rnvp_generic_mode": (None, [C.c_int]),
     "rnvp_param_count": (_SZ, [_SP]),
     "rnvp_workspace_bytes": (_SZ, [_SP, C.c_int, _I64]),
     "rnvp_kernel_path": (C.c_int, [_SP, _VP, C.c_int]),
@@ -122,7 +128,6 @@ _SIGNATURES = {
     "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
     "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
-    "cvae_force_generic": (None, [C.c_int]),
     "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
     "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
@@ -144,6 +149,13 @@ def lib():
                         "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                         "probaforms_amd has no CPU fallback." % LIB_PATH)
                 L = C.CDLL(LIB_PATH)
+                L.rnvp_version.restype, L.rnvp_version.argtypes = C.c_int, []
+                have = int(L.rnvp_version())
+                if have != ABI_VERSION:
+                    # an older / newer build of the same library (RNVP_HIP_LIB, a stale A/B variant): struct layouts and
+                    # argument lists differ between versions, calling through would corrupt memory silently
+                    raise HipLibraryMissing("%s reports rnvp_version() = %d, this binding is written for %d: rebuild it "
+                                            "(`make -C probaforms_amd/csrc`)" % (LIB_PATH, have, ABI_VERSION))
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(L, name)
                     fn.restype, fn.argtypes = res, args
@@ -193,12 +205,6 @@ def profile_read(kind=PROFILE_TRAIN):
     n, ms = C.c_int(0), C.c_float(0.0)
     check(lib().rnvp_profile_read(int(kind), C.byref(n), C.byref(ms)), "rnvp_profile_read")
     return n.value, ms.value
-
-
-def generic_mode(mode):
-    """test / measurement aid (process-wide): 0 automatic, 1 the VALU kernels, 2 the lmm kernels for every shape outside
-    the register-chained MFMA path"""
-    lib().rnvp_generic_mode(int(mode))
 
 
 def param_count(shape):
@@ -305,11 +311,6 @@ def cvae_workspace_bytes(shape, max_rows):
 def cvae_kernel_path(shape):
     """PATH_MFMA / PATH_GENERIC: the kernels cvae_loss_grad runs for this shape"""
     return int(lib().cvae_kernel_path(C.byref(shape)))
-
-
-def cvae_force_generic(on):
-    """test / measurement aid: pin the generic CVAE kernels process-wide"""
-    lib().cvae_force_generic(1 if on else 0)
 
 
 def cvae_loss_grad(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out, ws):

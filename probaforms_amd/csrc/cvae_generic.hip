@@ -188,14 +188,13 @@ size_t cvae_param_count(const cvae_shape *shape) {
     return (size_t)k.enc.npn + k.dec.npn;
 }
 
-static std::atomic<int> g_force_generic{0};
-
-void cvae_force_generic(int on) { g_force_generic.store(on ? 1 : 0); }
+// shape->family == 1 pins the generic kernels for this call (cvae_hip.h)
+static bool use_mfma(const cvae_shape *shape) { return shape->family == 0 && cvae_mfma::supported(shape); }
 
 int cvae_kernel_path(const cvae_shape *shape) {
     CvaeK k;
     if (make_cvae(shape, &k) != RNVP_OK) return RNVP_EINVAL;
-    return (!g_force_generic.load() && cvae_mfma::supported(shape)) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
+    return use_mfma(shape) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
 }
 
 static size_t generic_cvae_workspace(const CvaeK &k) {
@@ -207,7 +206,7 @@ size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows) {
     (void)max_rows;
     CvaeK k;
     if (make_cvae(shape, &k) != RNVP_OK) return 0;
-    size_t b = generic_cvae_workspace(k);                       // either path may run (cvae_force_generic)
+    size_t b = generic_cvae_workspace(k);                       // either path may run (shape->family)
     if (cvae_mfma::supported(shape)) { const size_t m = cvae_mfma::workspace_bytes(shape) + 256; if (m > b) b = m; }
     return b;
 }
@@ -228,7 +227,7 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, c
     }
     if (!params || !x || (k.c > 0 && !c) || !eps) return RNVP_EINVAL;
     if (!workspace || workspace_bytes < cvae_workspace_bytes(shape, n_rows)) return RNVP_EWORKSPACE;
-    if (!g_force_generic.load() && cvae_mfma::supported(shape))
+    if (use_mfma(shape))
         return cvae_mfma::loss_grad(st, shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out,
                                     workspace, workspace_bytes);
     int TB; size_t lds;
@@ -258,7 +257,7 @@ int cvae_decode(void *stream, const cvae_shape *shape, const float *params, cons
     if (n_rows < 0) return RNVP_EINVAL;
     if (n_rows == 0) return RNVP_OK;
     if (!params || !z || (k.c > 0 && !c) || !x_out) return RNVP_EINVAL;
-    if (workspace && !g_force_generic.load() && cvae_mfma::supported(shape))
+    if (workspace && use_mfma(shape))
         return cvae_mfma::forward(static_cast<hipStream_t>(stream), shape, params, false, z, c, n_rows, x_out, nullptr,
                                   workspace, workspace_bytes);
     int TB; size_t lds;
@@ -281,7 +280,7 @@ int cvae_encode(void *stream, const cvae_shape *shape, const float *params, cons
     if (n_rows < 0) return RNVP_EINVAL;
     if (n_rows == 0) return RNVP_OK;
     if (!params || !x || (k.c > 0 && !c) || !mu_out || !log_sigma_out) return RNVP_EINVAL;
-    if (workspace && !g_force_generic.load() && cvae_mfma::supported(shape))
+    if (workspace && use_mfma(shape))
         return cvae_mfma::forward(static_cast<hipStream_t>(stream), shape, params, true, x, c, n_rows, mu_out, log_sigma_out,
                                   workspace, workspace_bytes);
     int TB; size_t lds;

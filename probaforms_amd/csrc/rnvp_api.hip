@@ -71,22 +71,28 @@ int rnvp_profile_enable(int capacity) {
 int rnvp_profile_read(int kind, int *n_launches, float *total_ms) {
     if (kind < 0 || kind >= rnvp::kKinds) return RNVP_EINVAL;
     std::lock_guard<std::mutex> lk(rnvp::g_ev_mu);
+    // A slot is taken before its launch is known to have succeeded: a failed launch (or another thread's launch still
+    // between its two records) leaves a pair whose stop event was never recorded.  Such pairs are skipped, and the table
+    // is reset whatever happened, so one bad pair cannot poison every later read.
     float tot = 0.f;
+    int good = 0;
     for (int i = 0; i < rnvp::g_ev_used[kind]; ++i) {
-        RNVP_HIP_TRY(hipEventSynchronize(rnvp::g_ev[kind][2 * i + 1]));
         float ms = 0.f;
-        RNVP_HIP_TRY(hipEventElapsedTime(&ms, rnvp::g_ev[kind][2 * i], rnvp::g_ev[kind][2 * i + 1]));
+        if (hipEventSynchronize(rnvp::g_ev[kind][2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, rnvp::g_ev[kind][2 * i], rnvp::g_ev[kind][2 * i + 1]) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
         tot += ms;
+        ++good;
     }
-    if (n_launches) *n_launches = rnvp::g_ev_used[kind];
+    if (n_launches) *n_launches = good;
     if (total_ms) *total_ms = tot;
     rnvp::g_ev_used[kind] = 0;
     return RNVP_OK;
 }
 
-int rnvp_version(void) { return 201; }
-
-void rnvp_generic_mode(int mode) { rnvp::lmm::set_mode(mode); }
+int rnvp_version(void) { return RNVP_HIP_VERSION; }
 
 const char *rnvp_status_string(int status) {
     switch (status) {

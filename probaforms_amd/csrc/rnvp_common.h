@@ -23,6 +23,7 @@ struct KShape {
     int prec;                          // rnvp_shape::precision (RNVP_PREC_*), RNVP_PREC_AUTO resolved
     int prec_auto;                     // the caller left the choice to the library (RNVP_PREC_AUTO)
     int small_latency;                 // rnvp_shape::small_calls == RNVP_SMALL_LATENCY
+    int family;                        // rnvp_shape::family (RNVP_FAMILY_*)
     int nin[kMaxLin], nout[kMaxLin];   // Linear k: [nout, nin]
     int woff[kMaxLin], boff[kMaxLin];  // float offsets inside one net's parameter block
     int npn;                           // parameters per net
@@ -43,6 +44,8 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     // measured 1.3-1.4x there; the d <= 16 geometry gains nothing from it and keeps the f32 kernels
     if (s->small_calls != RNVP_SMALL_INVARIANT && s->small_calls != RNVP_SMALL_LATENCY) return RNVP_EINVAL;
     k->small_latency = s->small_calls == RNVP_SMALL_LATENCY;
+    if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM) return RNVP_EINVAL;
+    k->family = s->family;
     k->prec_auto = s->precision == RNVP_PREC_AUTO;
     k->prec = s->precision == RNVP_PREC_AUTO ? ((s->d > 16 || s->c > 4) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
     int in = s->d + s->c, off = 0;

@@ -21,8 +21,7 @@ struct LGeo {
 };
 
 LGeo make_lgeo(const KShape &k);
-bool use_lmm(const KShape &k, int op);     // policy (rnvp_generic_mode: 0 auto, 1 never, 2 whenever the LDS image fits)
-void set_mode(int mode);
+bool use_lmm(const KShape &k, int op);     // policy (rnvp_shape::family: VALU never, otherwise whenever the LDS image fits)
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows);
 int forward(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
             const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out, float *logp_sum,

@@ -502,7 +502,6 @@ k_lmm_reduce(KShape s, LGeo g, const float *__restrict__ gpart, int S, const uin
 }
 
 std::atomic<uint64_t> g_attr_fwd{0}, g_attr_inv{0}, g_attr_train{0};
-std::atomic<int> g_mode{0};
 
 int grid_for(int64_t ntiles) { return (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid); }
 
@@ -537,15 +536,12 @@ LGeo make_lgeo(const KShape &k) {
     return g;
 }
 
-void set_mode(int mode) { g_mode.store(mode, std::memory_order_relaxed); }
-
 // auto: whenever a tile's LDS image leaves room for at least two workgroups per CU.  Measured against the VALU kernels
 // (rnvp_generic.hip) the MFMA form wins at every width and batch size tried -- hidden=(10,20,15), d=2, batch 32:
 // 245 vs 1368 us per training step; hidden=(128,128), 65536 rows: 3.9 vs 217 ms -- so those remain only for shapes whose
 // image does not fit (and as the second implementation the tests pin this one against).
 bool use_lmm(const KShape &k, int op) {
-    const int mode = g_mode.load(std::memory_order_relaxed);
-    if (mode == 1) return false;
+    if (k.family == RNVP_FAMILY_VALU) return false;
     const LGeo g = make_lgeo(k);
     const size_t need = op == RNVP_OP_TRAIN ? g.lds_train : g.lds_flow;
     return need <= 76 * 1024;

@@ -21,21 +21,20 @@ for (d, c, lat, h) in shapes:
         ws = torch.empty(_hip.cvae_workspace_bytes(shp, n), dtype=torch.uint8, device="cuda")
         res = {}
         for path in ("mfma", "generic"):
-            _hip.cvae_force_generic(path == "generic")
+            shp.family = 1 if path == "generic" else 0
             g = torch.full((P,), float("nan"), device="cuda"); l = torch.empty(1, device="cuda")
             _hip.cvae_loss_grad(shp, dev(p), dev(X), dev(Cc), None, dev(eps), n, 1.0 / n, 0.3, g, l, ws)
             torch.cuda.synchronize()
             gg = g.cpu().numpy()
             res[path] = (abs(float(l) - lo) / max(1, abs(lo)), np.abs(gg - go).max() / np.abs(go).max())
         print((d, c, lat, h), n, "path", _hip.cvae_kernel_path(shp), "mfma: loss %.2e grad %.2e | generic: loss %.2e grad %.2e" % (res["mfma"] + res["generic"]), flush=True)
-_hip.cvae_force_generic(False)
 # timing at config 5
 d, c, lat, h, n = 16, 4, 2, 128, 65536
 shp = _hip.CvaeShape.make(d, c, lat, (h,), "tanh"); P = _hip.cvae_param_count(shp)
 p = dev((rng.standard_normal(P) * 0.1).astype(np.float32)); X = torch.randn(n, d, device="cuda"); Cc = torch.randn(n, c, device="cuda"); eps = torch.randn(n, lat, device="cuda")
 ws = torch.empty(_hip.cvae_workspace_bytes(shp, n), dtype=torch.uint8, device="cuda"); g = torch.empty(P, device="cuda"); l = torch.empty(1, device="cuda")
 for path in ("mfma", "generic"):
-    _hip.cvae_force_generic(path == "generic")
+    shp.family = 1 if path == "generic" else 0
     for _ in range(5): _hip.cvae_loss_grad(shp, p, X, Cc, None, eps, n, 1.0 / n, 0.001, g, l, ws)
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(50): _hip.cvae_loss_grad(shp, p, X, Cc, None, eps, n, 1.0 / n, 0.001, g, l, ws)

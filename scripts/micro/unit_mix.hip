@@ -1,0 +1,340 @@
+// Microbenchmark (gfx950): candidate instruction mixes of ONE "unit" of the RealNVP training kernel
+// (16 hidden units of one net x 16 rows, C2 geometry: 12 inputs, 8 outputs per net), to choose between
+// the f32-MFMA forms of rnvp_mfma_train.hip and split-bf16 (bx3) forms before building the kernel.
+// Every variant runs `tiles` weight tiles x R row tiles per wave, weights streamed from an L2-resident
+// buffer one tile ahead, 2 waves per SIMD (512-thread workgroups, one per CU) unless WAVES says otherwise.
+// Build: hipcc -O3 --offload-arch=gfx950 unit_mix.hip -o unit_mix ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+using f4 = __attribute__((ext_vector_type(4))) float;
+using f2 = __attribute__((ext_vector_type(2))) float;
+using u2 = __attribute__((ext_vector_type(2))) unsigned;
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma32(u4 a, u4 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ f4 tanh4(f4 u) {
+    f2 e0, e1;
+    e0[0] = __builtin_amdgcn_exp2f(u[0]); e0[1] = __builtin_amdgcn_exp2f(u[1]);
+    e1[0] = __builtin_amdgcn_exp2f(u[2]); e1[1] = __builtin_amdgcn_exp2f(u[3]);
+    e0 = e0 + 1.0f; e1 = e1 + 1.0f;
+    f2 r0, r1;
+    r0[0] = __builtin_amdgcn_rcpf(e0[0]); r0[1] = __builtin_amdgcn_rcpf(e0[1]);
+    r1[0] = __builtin_amdgcn_rcpf(e1[0]); r1[1] = __builtin_amdgcn_rcpf(e1[1]);
+    r0 = __builtin_elementwise_fma(r0, f2{-2.0f, -2.0f}, f2{1.0f, 1.0f});
+    r1 = __builtin_elementwise_fma(r1, f2{-2.0f, -2.0f}, f2{1.0f, 1.0f});
+    return f4{r0[0], r0[1], r1[0], r1[1]};
+}
+
+// three bf16 term planes of 4 values: T[k] = {pack(tk(v0), tk(v1)), pack(tk(v2), tk(v3))}
+__device__ __forceinline__ void split_planes(f4 v, u2 (&T)[3]) {
+    unsigned u[4], u1[4], u2_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u[i] = __float_as_uint(v[i]);
+        const float r1 = v[i] - __uint_as_float(u[i] & 0xffff0000u);
+        u1[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[i] & 0xffff0000u);
+        u2_[i] = __float_as_uint(r2);
+    }
+    T[0] = u2{__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u)};
+    T[1] = u2{__builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u), __builtin_amdgcn_perm(u1[3], u1[2], 0x07060302u)};
+    T[2] = u2{__builtin_amdgcn_perm(u2_[1], u2_[0], 0x07060302u), __builtin_amdgcn_perm(u2_[3], u2_[2], 0x07060302u)};
+}
+// the B operands {T1,T1}, {T1,T2}, {T2,T3} (weights carry {a1,a2}, {a3,a1}, {a2,a1})
+__device__ __forceinline__ void planes_to_ops(const u2 (&T)[3], u4 (&B)[3]) {
+    B[0] = u4{T[0].x, T[0].y, T[0].x, T[0].y};
+    B[1] = u4{T[0].x, T[0].y, T[1].x, T[1].y};
+    B[2] = u4{T[1].x, T[1].y, T[2].x, T[2].y};
+}
+
+typedef const __attribute__((address_space(1))) u4 *gu4_ptr;
+__device__ __forceinline__ gu4_ptr opaque(const unsigned *p) { asm volatile("" : "+v"(p)); return (gu4_ptr)p; }
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ u2 tr_read(const unsigned short *p) {
+    v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)p);
+    return __builtin_bit_cast(u2, r);
+}
+
+constexpr int PS = 20;        // row stride (16-bit elements) of a transposition plane: 40 B
+constexpr int kTS = 20;
+
+// V: 0 f32 backward unit (as rnvp_mfma_train.hip, C2 net-split form)   1 bx3 backward unit, all products on bf16 MFMA
+//    2 bx3 backward unit with dW2 on the f32 4x4x1 form                3 f32 forward unit   4 bx3 GEMM1 + f32 4x4x1 GEMM2
+//    5 all-bx3 forward unit     6: V1 without the weight-gradient products   7: V1 without any LDS traffic (operands reused)
+//    8: V1 MFMAs only (no tanh / split)  9: V1 VALU only (no MFMAs)
+template <int V, int R, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4)))
+k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long long *clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+    unsigned char *wl = lds_raw + wave * 8192;
+    unsigned short *planeH = reinterpret_cast<unsigned short *>(wl);                 // 3 planes x 16 x PS
+    unsigned short *planeP = planeH + 3 * 16 * PS;
+    float *bufH = reinterpret_cast<float *>(wl + 4096);                             // f32 transposition tiles (V0, V2)
+    float *bufP = bufH + 16 * kTS;
+    float *bufG = bufP + 16 * kTS;
+    u4 *opsT = reinterpret_cast<u4 *>(wl + 4096 + 3 * 16 * kTS * 4);                // inT / goutT operands: 6 x 64 u4 = 6 KB?  (kept small: 1 KB reused)
+    // per-row-tile persistent state
+    u4 bin[R][3], gob[R][2];
+    f4 gin[R], acc_out[R];
+    float xin[R][3], go[R][4];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { bin[rt][i] = u4{0x3f803f80u + lane + i, 0x3f003f80u, 0x3e803f80u + rt, 0x3f803e00u}; xin[rt][i] = 0.01f * (lane + i + rt); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gob[rt][i] = u4{0x3f803f80u + lane, 0x3f003f80u + i, 0x3e803f80u, 0x3f803e00u + rt};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) go[rt][i] = 0.001f * (lane + i);
+        gin[rt] = f4{0, 0, 0, 0}; acc_out[rt] = f4{0, 0, 0, 0};
+    }
+    f4 gW1 = f4{0, 0, 0, 0}, gW2 = f4{0, 0, 0, 0}, gW2b = f4{0, 0, 0, 0};
+    unsigned long long t0 = 0, t1 = 0, rt0 = 0, rt1 = 0;
+    constexpr int NFR = (V == 3 || V == 4) ? 5 : (V == 5 ? 6 : 8);                  // u4 fragments per weight tile
+    const unsigned *wp = w + lane * 4;
+    for (int rep = 0; rep < reps; ++rep) {
+        if (rep == 1) { t0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+        u4 fr[NFR];
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) fr[i] = *reinterpret_cast<const u4 *>(wp + i * 256);
+        for (int t = 0; t < tiles; ++t) {
+            const int nx = (t + 1 < tiles) ? t + 1 : t;
+            u4 nf[NFR];
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) nf[i] = *opaque(wp + ((size_t)nx * NFR + i) * 256);
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                if constexpr (V == 3 || V == 4 || V == 5) {
+                    // ---- forward unit: GEMM1 -> tanh -> GEMM2
+                    f4 acc = f4{0, 0, 0, 0};
+                    if constexpr (V == 3) {
+#pragma unroll
+                        for (int kk = 0; kk < 3; ++kk) acc = mfma16(__uint_as_float(fr[0][kk]), xin[rt][kk], acc);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc = mfma32(fr[i], bin[rt][i], acc);
+                    }
+                    const f4 hv = tanh4(acc);
+                    if constexpr (V == 5) {
+                        u2 T[3]; u4 B[3];
+                        split_planes(hv, T); planes_to_ops(T, B);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc_out[rt] = mfma32(fr[3 + i], B[i], acc_out[rt]);
+                    } else {
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho) {
+                            acc_out[rt] = mfma4(__uint_as_float(fr[3][rho]), hv[rho], acc_out[rt]);
+                            gin[rt] = mfma4(__uint_as_float(fr[4][rho]), hv[rho], gin[rt]);
+                        }
+                    }
+                } else if constexpr (V == 0) {
+                    // ---- f32 backward unit
+                    f4 acc = f4{0, 0, 0, 0}, gh = f4{0, 0, 0, 0};
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) acc = mfma16(__uint_as_float(fr[0][kk]), xin[rt][kk], acc);
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) gh = mfma16(__uint_as_float(fr[1][v]), go[rt][v], gh);
+                    const f4 hv = tanh4(acc);
+                    const f4 gp = gh * (1.0f - hv * hv);
+                    wave_lds_fence();
+                    *reinterpret_cast<f4 *>(bufH + r * kTS + 4 * q) = hv;
+                    *reinterpret_cast<f4 *>(bufP + r * kTS + 4 * q) = gp;
+                    wave_lds_fence();
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho) {
+                        gin[rt] = mfma4(__uint_as_float(fr[2][rho]), gp[rho], gin[rt]);
+                        acc_out[rt] = mfma4(__uint_as_float(fr[3][rho]), gp[rho], acc_out[rt]);
+                    }
+                    float hT[4], pT[4]; f2 gB[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        hT[ks] = bufH[(4 * ks + q) * kTS + r];
+                        pT[ks] = bufP[(4 * ks + q) * kTS + r];
+                        gB[ks] = *reinterpret_cast<const f2 *>(bufG + (4 * ks + q) * 10 + 2 * (r & 3));
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        gW2 = mfma4(hT[ks], gB[ks].x, gW2);
+                        gW2b = mfma4(hT[ks], gB[ks].y, gW2b);
+                        gW1 = mfma16(pT[ks], xin[rt][ks & 1] + ks, gW1);
+                    }
+                } else {
+                    // ---- bx3 backward unit
+                    f4 acc = f4{0, 0, 0, 0}, gh = f4{0, 0, 0, 0};
+                    if constexpr (V != 9) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc = mfma32(fr[i], bin[rt][i], acc);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) gh = mfma32(fr[3 + i], gob[rt][i], gh);
+                    } else {
+                        acc = f4{xin[rt][0], xin[rt][1], xin[rt][2], gin[rt][0]}; gh = f4{go[rt][0], go[rt][1], go[rt][2], go[rt][3]};
+                    }
+                    f4 hv, gp;
+                    u2 TH[3], TP[3]; u4 BP[3];
+                    if constexpr (V != 8) {
+                        hv = tanh4(acc);
+                        gp = gh * (1.0f - hv * hv);
+                        if constexpr (V != 2) split_planes(hv, TH);
+                        split_planes(gp, TP); planes_to_ops(TP, BP);
+                    } else {
+                        hv = acc; gp = gh;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            TH[i] = u2{__float_as_uint(acc[i]), __float_as_uint(acc[3])};
+                            TP[i] = u2{__float_as_uint(gh[i]), __float_as_uint(gh[3])};
+                        }
+                        planes_to_ops(TP, BP);
+                    }
+                    if constexpr (V != 9) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) gin[rt] = mfma32(fr[5 + i], BP[i], gin[rt]);
+                    } else {
+                        gin[rt][0] += __uint_as_float(BP[0].x ^ BP[1].z ^ BP[2].w); gin[rt][1] += __uint_as_float(BP[0].z ^ BP[1].x ^ BP[2].y);
+                    }
+                    if constexpr (V == 6) {
+                        gW1[0] += __uint_as_float(TH[0].x ^ TH[1].y ^ TH[2].x) + __uint_as_float(TP[0].y ^ TP[1].x ^ TP[2].y);
+                    } else {
+                        u4 AH[3], AP[3], BI[3], BG[3];
+                        if constexpr (V == 7) {
+                            planes_to_ops(TH, AH); planes_to_ops(TP, AP);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) { BI[i] = bin[rt][i]; BG[i] = bin[rt][2 - i]; }
+                        } else {
+                            wave_lds_fence();
+                            if constexpr (V != 2) {
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) *reinterpret_cast<u2 *>(planeH + (i * 16 + r) * PS + 4 * q) = TH[i];
+                            } else {
+                                *reinterpret_cast<f4 *>(bufH + r * kTS + 4 * q) = hv;
+                            }
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) *reinterpret_cast<u2 *>(planeP + (i * 16 + r) * PS + 4 * q) = TP[i];
+                            wave_lds_fence();
+                            // lane (q, i = r): rows 4q .. 4q+3 of column i: lane 4qq + p of a 16-lane group addresses row qq, columns 4p..
+                            const int qq = r >> 2, p = r & 3;
+                            const unsigned short *ph = planeH + (4 * q + qq) * PS + 4 * p;
+                            const unsigned short *pp = planeP + (4 * q + qq) * PS + 4 * p;
+                            if constexpr (V != 2) {
+                                const u2 h0 = tr_read(ph), h0b = tr_read(ph), h0c = tr_read(ph), h1 = tr_read(ph + 16 * PS), h1b = tr_read(ph + 16 * PS), h2 = tr_read(ph + 32 * PS);
+                                AH[0] = u4{h0.x, h0.y, h0b.x, h0b.y}; AH[1] = u4{h0c.x, h0c.y, h1.x, h1.y}; AH[2] = u4{h1b.x, h1b.y, h2.x, h2.y};
+                            }
+                            const u2 p0 = tr_read(pp), p0b = tr_read(pp), p0c = tr_read(pp), p1 = tr_read(pp + 16 * PS), p1b = tr_read(pp + 16 * PS), p2 = tr_read(pp + 32 * PS);
+                            AP[0] = u4{p0.x, p0.y, p0b.x, p0b.y}; AP[1] = u4{p0c.x, p0c.y, p1.x, p1.y}; AP[2] = u4{p1b.x, p1b.y, p2.x, p2.y};
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                BI[i] = opsT[(rt * 6 + i) * 0 + i * 64 + lane];
+                                if constexpr (V != 2) BG[i] = opsT[(3 + i) * 64 + lane];
+                            }
+                        }
+                        if constexpr (V != 9) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) gW1 = mfma32(AP[i], BI[i], gW1);
+                            if constexpr (V != 2) {
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) gW2 = mfma32(AH[i], BG[i], gW2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) { gW1[i] += __uint_as_float(AP[i].x ^ BI[i].y ^ AP[i].z ^ AP[i].w); gW2[i] += __uint_as_float(AH[i].x ^ BG[i].y ^ AH[i].z ^ AH[i].w); }
+                        }
+                        if constexpr (V == 2) {
+                            float hT[4]; f2 gB[4];
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) {
+                                hT[ks] = bufH[(4 * ks + q) * kTS + r];
+                                gB[ks] = *reinterpret_cast<const f2 *>(bufG + (4 * ks + q) * 10 + 2 * (r & 3));
+                            }
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) { gW2 = mfma4(hT[ks], gB[ks].x, gW2); gW2b = mfma4(hT[ks], gB[ks].y, gW2b); }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) fr[i] = nf[i];
+        }
+    }
+    t1 = __builtin_readcyclecounter(); rt1 = __builtin_amdgcn_s_memrealtime();
+    float s = gW1[0] + gW1[1] + gW1[2] + gW1[3] + gW2[0] + gW2[1] + gW2[2] + gW2[3] + gW2b[0] + gW2b[1];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) s += gin[rt][0] + gin[rt][1] + gin[rt][2] + gin[rt][3] + acc_out[rt][0] + acc_out[rt][1] + acc_out[rt][2] + acc_out[rt][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = rt1 - rt0; }
+}
+
+template <int V, int R, int WAVES> void run(const unsigned *w, float *d, unsigned long long *clk, const char *name) {
+    const int tiles = 64, reps = 41;
+    auto kern = k<V, R, WAVES>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * 8192);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), WAVES * 8192, 0, w, d, tiles, 3, clk);
+    float best = 1e9f;
+    for (int i = 0; i < 3; ++i) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), WAVES * 8192, 0, w, d, tiles, reps, clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double units_per_wave = (double)tiles * reps * R, units_timed = (double)tiles * (reps - 1) * R;
+    const double ghz = (double)h[0] / ((double)h[1] * 10.0);          // s_memrealtime ticks at 100 MHz
+    printf("  %-58s R=%d waves/SIMD=%d: %7.1f ns/unit/wave, %6.0f cycles per unit per SIMD, clock %.2f GHz (wall %.3f ms)\n", name, R,
+           WAVES / 4, best * 1e6 / units_per_wave, (double)h[0] / units_timed / (WAVES / 4), ghz, best);
+}
+
+int main() {
+    unsigned *w; float *d; unsigned long long *clk;
+    const size_t wn = (size_t)65 * 8 * 256;
+    hipMalloc(&w, wn * 4); hipMalloc(&d, 256 * 1024 * 4); hipMalloc(&clk, 16);
+    unsigned *hw = new unsigned[wn];
+    for (size_t i = 0; i < wn; ++i) hw[i] = 0x3c003c00u + (unsigned)(i * 2654435761u >> 20) % 0x01000100u;      // small bf16 pairs
+    hipMemcpy(w, hw, wn * 4, hipMemcpyHostToDevice);
+    printf("unit = 16 hidden x 16 rows of one net (C2: 12 inputs, 8 outputs per net); the real kernel's unit = forward + backward\n");
+    run<3, 4, 8>(w, d, clk, "fwd f32: 3 mfma16 + tanh + 8 mfma4");
+    run<4, 4, 8>(w, d, clk, "fwd bx3 GEMM1: 3 mfma32 + tanh + 8 mfma4");
+    run<5, 4, 8>(w, d, clk, "fwd all bx3: 3 mfma32 + tanh + split + 3 mfma32");
+    run<0, 4, 8>(w, d, clk, "bwd f32 (as rnvp_mfma_train)");
+    run<1, 4, 8>(w, d, clk, "bwd all bx3 (LDS planes + tr reads)");
+    run<2, 4, 8>(w, d, clk, "bwd bx3, dW2 on f32 4x4x1");
+    run<6, 4, 8>(w, d, clk, "bwd bx3 without the dW products");
+    run<7, 4, 8>(w, d, clk, "bwd all bx3 without LDS traffic");
+    run<8, 4, 8>(w, d, clk, "bwd all bx3, MFMAs + LDS only");
+    run<9, 4, 8>(w, d, clk, "bwd all bx3, VALU + LDS only");
+    run<1, 2, 8>(w, d, clk, "bwd all bx3");
+    run<5, 2, 8>(w, d, clk, "fwd all bx3");
+    run<1, 4, 4>(w, d, clk, "bwd all bx3");
+    run<5, 4, 4>(w, d, clk, "fwd all bx3");
+    run<1, 8, 4>(w, d, clk, "bwd all bx3");
+    printf("-- occupancy sweep (same units; NOTE ns/unit/wave / (waves/SIMD) = SIMD time per unit)\n");
+    run<3, 2, 8>(w, d, clk, "fwd f32");
+    run<3, 2, 16>(w, d, clk, "fwd f32");
+    run<3, 1, 16>(w, d, clk, "fwd f32");
+    run<4, 2, 16>(w, d, clk, "fwd bx3 GEMM1 + f32 4x4x1 GEMM2");
+    run<4, 1, 16>(w, d, clk, "fwd bx3 GEMM1 + f32 4x4x1 GEMM2");
+    run<5, 2, 16>(w, d, clk, "fwd all bx3");
+    run<0, 2, 8>(w, d, clk, "bwd f32");
+    run<0, 2, 16>(w, d, clk, "bwd f32");
+    run<0, 1, 16>(w, d, clk, "bwd f32");
+    run<2, 2, 8>(w, d, clk, "bwd bx3, dW2 on f32 4x4x1");
+    run<2, 2, 16>(w, d, clk, "bwd bx3, dW2 on f32 4x4x1");
+    run<2, 1, 16>(w, d, clk, "bwd bx3, dW2 on f32 4x4x1");
+    run<1, 2, 16>(w, d, clk, "bwd all bx3");
+    run<1, 1, 16>(w, d, clk, "bwd all bx3");
+    run<9, 2, 16>(w, d, clk, "bwd all bx3, VALU + LDS only");
+    run<8, 2, 16>(w, d, clk, "bwd all bx3, MFMAs + LDS only");
+    return 0;
+}

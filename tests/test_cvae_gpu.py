@@ -18,11 +18,11 @@ def _dev(a):
     return None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda().contiguous()
 
 
-def _load(name):
+def _load(name, family="auto"):
     from probaforms_amd import _hip
     d, c, lat, hidden, act, klw = CASES[name]
     g = np.load(os.path.join(GOLDEN, "cvae_%s.npz" % name))
-    shape = _hip.CvaeShape.make(d, c, lat, hidden, act)
+    shape = _hip.CvaeShape.make(d, c, lat, hidden, act, family=family)
     assert _hip.cvae_param_count(shape) == g["init_params"].size
     return _hip, g, shape, klw, (g["C"] if c else None)
 
@@ -45,11 +45,9 @@ def test_encode_decode(name, with_ws):
 
 @pytest.fixture(params=["auto", "generic"])
 def path(request):
-    """run the step on the kernels the library picks (MFMA where supported) and pinned to the generic ones"""
-    from probaforms_amd import _hip
-    _hip.cvae_force_generic(request.param == "generic")
-    yield request.param
-    _hip.cvae_force_generic(False)
+    """run the step on the kernels the library picks (MFMA where supported) and pinned to the generic ones
+    (cvae_shape.family, per call)"""
+    return request.param
 
 
 def test_kernel_path_selection():
@@ -60,11 +58,7 @@ def test_kernel_path_selection():
     assert _hip.cvae_kernel_path(_hip.CvaeShape.make(17, 4, 2, (128,), "tanh")) == _hip.PATH_GENERIC
     assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 5, 2, (128,), "tanh")) == _hip.PATH_GENERIC
     assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 5, (128,), "tanh")) == _hip.PATH_GENERIC
-    _hip.cvae_force_generic(True)
-    try:
-        assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 2, (128,), "tanh")) == _hip.PATH_GENERIC
-    finally:
-        _hip.cvae_force_generic(False)
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 2, (128,), "tanh", family="generic")) == _hip.PATH_GENERIC
 
 
 @pytest.mark.parametrize("d,c,lat,h", [(1, 0, 1, 1), (13, 1, 3, 37), (16, 2, 4, 200), (7, 4, 1, 16), (2, 2, 2, 300),
@@ -104,7 +98,7 @@ def test_mfma_step_shapes_vs_oracle(d, c, lat, h, n):
 @pytest.mark.parametrize("name", list(CASES))
 def test_loss_grad_and_adam(name, path):
     from oracle import CvaeOracle, CvaeShape
-    _hip, g, shape, klw, C = _load(name)
+    _hip, g, shape, klw, C = _load(name, family=path)
     d, c, lat, hidden, act, _ = CASES[name]
     n = g["X"].shape[0]; P = g["init_params"].size
     x, cc = _dev(g["X"]), _dev(C)

@@ -20,13 +20,6 @@ def _dev(a, dtype=torch.float32):
 PATHS = ["declared", "table", "table/lmm"]
 
 
-@pytest.fixture(autouse=True)
-def _reset_generic_mode():
-    yield
-    from probaforms_amd import _hip
-    _hip.generic_mode(0)
-
-
 # "declared/bx3": same masks declaration, GEMM1 of the forward / inverse kernels on the split-bf16 path with
 # LDS-staged weights (rnvp_shape.precision = RNVP_PREC_BX3); "declared" pins RNVP_PREC_F32
 FLOW_PATHS = ["declared", "declared/bx3", "table", "table/lmm"]
@@ -40,9 +33,9 @@ def _setup(name, path="declared"):
     prec = "bx3" if path.endswith("/bx3") else "f32"
     lmm = path.endswith("/lmm")
     path = path.split("/")[0]
-    _hip.generic_mode(2 if lmm else (1 if path == "table" else 0))
+    # rnvp_shape.family (per call): "table" pins the VALU kernels, "table/lmm" asks for the any-shape MFMA kernels
     shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=alt if path == "declared" else 0,
-                                precision=prec)
+                                precision=prec, family="lmm" if lmm else ("valu" if path == "table" else "auto"))
     assert _hip.param_count(shape) == cs["params"].size
     if path == "table":
         assert _hip.kernel_path(shape, cs["masks"], _hip.OP_TRAIN) == (_hip.PATH_LMM if lmm else _hip.PATH_GENERIC)
@@ -455,7 +448,7 @@ def test_user_masks_and_wide_shapes_vs_oracle(kind, family, oracle32, oracle64):
     else:
         masks = ((np.arange(d)[None] // 3 + np.arange(L)[:, None]) % 2).astype(np.uint8)
     assert _hip.RnvpShape.classify_masks(masks) == 0
-    _hip.generic_mode(2 if family == "lmm" else 1)
+    sh.family = _hip.FAMILIES[family]
     assert _hip.kernel_path(sh, masks, _hip.OP_TRAIN) == (_hip.PATH_LMM if family == "lmm" else _hip.PATH_GENERIC)
     X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
     so = Shape.make(L, d, c, hidden, act)
@@ -592,7 +585,6 @@ def test_auto_mode_takes_lmm_for_generic_shapes_and_is_bitwise_reproducible():
     """several hidden layers / user masks / wide rows go to the any-shape MFMA kernels by default; their training step
     (input-gradient chain in-kernel, weight gradients over fixed row splits) gives identical bits run to run"""
     from probaforms_amd import _hip
-    _hip.generic_mode(0)
     for L, d, c, hidden, n in [(4, 6, 2, (12, 20), 5000), (3, 80, 20, (24,), 3000), (8, 16, 4, (128, 128), 20000)]:
         sh, p, rng = _rand_flow(L, d, c, hidden, "tanh", 5)
         masks = rng.integers(0, 2, (L, d)).astype(np.uint8)

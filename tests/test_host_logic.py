@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _hip.lib().rnvp_version() >= 100
+    assert _hip.lib().rnvp_version() == _hip.ABI_VERSION
+    assert int(re.search(r"#define RNVP_HIP_VERSION (\d+)", hdr).group(1)) == _hip.ABI_VERSION
     assert b"workspace" in _hip.lib().rnvp_status_string(-3)
 
 
@@ -201,16 +202,19 @@ def test_shape_struct_matches_the_c_header():
     import ctypes, os, subprocess, tempfile
     from conftest import ROOT
     from probaforms_amd import _hip
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "include/rnvp_hip.h"\n'
-           'int main(void){printf("%zu %zu %zu %zu %zu", sizeof(rnvp_shape), offsetof(rnvp_shape, hidden), '
-           'offsetof(rnvp_shape, alt_masks), offsetof(rnvp_shape, precision), offsetof(rnvp_shape, small_calls));return 0;}\n')
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "include/rnvp_hip.h"\n#include "include/cvae_hip.h"\n'
+           'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu", sizeof(rnvp_shape), offsetof(rnvp_shape, hidden), '
+           'offsetof(rnvp_shape, alt_masks), offsetof(rnvp_shape, precision), offsetof(rnvp_shape, small_calls), '
+           'offsetof(rnvp_shape, family), sizeof(cvae_shape), offsetof(cvae_shape, family));return 0;}\n')
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-I", ROOT, c, "-o", exe])
-        size, o_hidden, o_alt, o_prec, o_small = map(int, subprocess.check_output([exe]).split())
+        size, o_hidden, o_alt, o_prec, o_small, o_fam, csize, co_fam = map(int, subprocess.check_output([exe]).split())
     S = _hip.RnvpShape
-    assert (size, o_hidden, o_alt, o_prec, o_small) == (ctypes.sizeof(S), S.hidden.offset, S.alt_masks.offset,
-                                                        S.precision.offset, S.small_calls.offset)
+    assert (size, o_hidden, o_alt, o_prec, o_small, o_fam) == (ctypes.sizeof(S), S.hidden.offset, S.alt_masks.offset,
+                                                               S.precision.offset, S.small_calls.offset, S.family.offset)
+    assert (csize, co_fam) == (ctypes.sizeof(_hip.CvaeShape), _hip.CvaeShape.family.offset)
+    assert _hip.FAMILIES == {"auto": 0, "valu": 1, "lmm": 2}
     assert _hip.SMALL_CALLS == {"invariant": 0, "latency": 1}
     assert _hip.PRECISIONS == {"auto": 0, "f32": 1, "bx3": 2}
