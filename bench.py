@@ -42,11 +42,31 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# workload (C2)
+# workloads (BASELINE.json configs[1..3]); per GPU: rows, d, cond, layers, hidden, what one step does.  C3 is quoted on 8M rows
+# over 8 GPUs = 1M rows per GPU, C4 on 16M draws over 8 GPUs = 2M per GPU (L and hidden as SURVEY.md 8 reads them).
+WORKLOADS = {
+    "c2": dict(n=1_000_000, d=16, c=4, L=8, hidden=(128,), fit=True, sample=True, label="C2"),
+    "c3": dict(n=1_000_000, d=32, c=8, L=12, hidden=(256,), fit=True, sample=True, label="C3"),
+    "c4": dict(n=2_000_000, d=64, c=16, L=8, hidden=(128,), fit=False, sample=True, label="C4"),
+}
+# the default workload (C2, the configuration BASELINE.json's metric is quoted on for one GPU); main() rebinds these
 N_ROWS, D, CDIM, LAYERS, HIDDEN = 1_000_000, 16, 4, 8, (128,)
+WORKLOAD_FIT = True
 BATCH = 65_536
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")
+# split-bf16 GEMM1 (precision 'bx3'): six bf16 products per f32 product on the dense bf16 MFMA peak (16x the f32 one)
+BX3_EFFECTIVE_TFLOPS = 16.0 * F32_MFMA_PEAK_TFLOPS / 6.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")
+
+
+def mixed_bound_seconds_per_row(d, c, hidden, L, passes=1):
+    """roofline time per row of a bx3 forward / inverse kernel: GEMM1 (useful 4 h (d/2 + c) flop per layer) on the
+    six-product bf16 form, GEMM2 (4 h d/2) on f32 MFMA -- the bound such a kernel should be priced against, beside the
+    all-f32 one"""
+    h = hidden[0]
+    g1 = 4 * h * (d / 2 + c) * L * passes
+    g2 = 4 * h * (d / 2) * L * passes
+    return g1 / (BX3_EFFECTIVE_TFLOPS * 1e12) + g2 / (F32_MFMA_PEAK_TFLOPS * 1e12)
 
 
 def moons_block(n, rng, noise=0.1):
@@ -123,9 +143,10 @@ def cpu_baseline(X, C, rows=4 * BATCH):
     ncpu, grant = os.cpu_count() or 2, effective_cpus()               # CPUs shown / CPUs the cgroup quota grants
     cands = sorted({max(1, grant), max(1, grant // 2)})
     runs = [timed_fit_and_sample(LAYERS, D, CDIM, HIDDEN, X[:rows], C[:rows], BATCH, t) for t in cands]
-    best = max(runs, key=lambda r: r["combined_rows_per_s"])
+    key = "combined_rows_per_s" if WORKLOAD_FIT else "sample_rows_per_s"        # C4: sampling only
+    best = max(runs, key=lambda r: r[key])
     import torch
-    return dict(value=best["combined_rows_per_s"], unit="rows/s", cores=best["threads"], kind="port",
+    return dict(value=best[key], unit="rows/s", cores=best["threads"], kind="port",
                 sample="oracle/torch_cpu.py (eager PyTorch %s CPU ops in the reference's order, float32) with %d torch threads "
                        "on a %d-CPU host (CPU quota of this process: %d): 1 epoch of 65536-row batches over %d rows (%.1f s = %.1f k rows/s) + sampling %d rows "
                        "(%.1f s = %.1f k rows/s); thread counts tried: %s; in the build container this loop runs at 1.00x the "
@@ -248,6 +269,67 @@ def secondary_configs(Xh, Ch, dev):
         out["c2_batch%d" % bs] = {"workload": "the C2 flow at batch_size=%d%s: %d fused steps in one rnvp_fit_epoch call (tile-split "
                                               "training kernel)" % (bs, " (the reference's default)" if bs == 32 else "", nsteps),
                                   "us_per_step": us, "rows_per_s": bs / (us * 1e-6)}
+    out.update(secondary_c3_c4(dev))
+    return out
+
+
+def secondary_c3_c4(dev):
+    """BASELINE.json configs[2..3] on ONE GPU, after the timed region, never `value`: C3 (d=32, cond=8, L=12, hidden 256) --
+    one fused training step (loss + gradient + Adam, rnvp_train_step) on 65 536 rows, log_prob and sampling on 1M rows;
+    C4 (d=64, cond=16, L=8, hidden 128) -- rnvp_sample of 2M draws (one rank's share of 16M).  Kernel times from the
+    library's own HIP events; roofline fractions against the f32 MFMA peak and, for the kernels whose first Linear runs
+    on split-bf16 MFMA (precision auto = bx3 for these shapes), against the mixed bound."""
+    import torch
+    from probaforms_amd import _engine, _hip
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    out = {}
+    for key in ("c3", "c4"):
+        w = WORKLOADS[key]
+        n, d, c, L, hidden = w["n"], w["d"], w["c"], w["L"], w["hidden"]
+        torch.manual_seed(0)
+        layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, hidden, "tanh") for i in range(L)]
+        nf = NormalizingFlow(layers, StandardNormalPrior(d, dev, host_rng=False))
+        for p in nf.parameters():
+            p.data = p.data.to(dev)
+        eng = nf.engine()
+        gen = torch.Generator(device=dev).manual_seed(3)
+        X = torch.randn(n, d, device=dev, generator=gen); C = torch.randn(n, c, device=dev, generator=gen)
+        xs = torch.empty(n, d, device=dev)
+        f1 = useful_flops_per_row(d, c, hidden, L, 1)
+        res = {"workload": "%s: d=%d cond=%d L=%d hidden=%r, one GPU" % (w["label"], d, c, L, hidden)}
+        _hip.profile_enable(64)
+
+        def timed(kind, fn, reps, rows, passes, bx3):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(dev)
+            _hip.profile_read(kind)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize(dev)
+            nk, kms = _hip.profile_read(kind)
+            kms /= max(nk, 1)
+            r = {"rows": rows, "ms_per_call": e0.elapsed_time(e1) / reps, "kernel_ms": kms,
+                 "rows_per_s": rows / (e0.elapsed_time(e1) / reps * 1e-3), "useful_flop_per_row": passes * f1,
+                 "roofline_frac_f32_mfma": passes * f1 * rows / (kms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+            if bx3:
+                r["roofline_frac_mixed_bound"] = mixed_bound_seconds_per_row(d, c, hidden, L, passes) * rows / (kms * 1e-3)
+            return r
+
+        if w["fit"]:
+            opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+            idx = torch.randperm(n, device=dev, generator=gen)[:BATCH].contiguous()
+            loss = torch.zeros(1, device=dev)
+            res["train_step_65536_rows"] = timed(_hip.PROFILE_TRAIN,
+                                                  lambda: eng.train_step(opt, X, C, idx, BATCH, 1.0 / BATCH, loss), 10, BATCH, 3, False)
+            res["log_prob_1M_rows"] = timed(_hip.PROFILE_FORWARD, lambda: eng.forward(X, C, want_z=False, want_logp=True), 5, n, 1, True)
+        res["sample_%dM_rows" % (n // 1_000_000)] = timed(_hip.PROFILE_INVERSE, lambda: eng.sample(n, C, 77, row_offset=0, out=xs), 5, n, 1, True)
+        _hip.profile_enable(0)
+        out[key] = res
+        del X, C, xs, nf, eng
+        torch.cuda.empty_cache()
     return out
 
 
@@ -272,7 +354,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-level", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 (default: the configuration the metric is quoted on), c3 (fit + sample, d=32 cond=8 L=12 hidden 256, "
+                         "1M rows per GPU) or c4 (sampling only, d=64 cond=16, 2M draws per GPU)")
     args = ap.parse_args()
+    global N_ROWS, D, CDIM, LAYERS, HIDDEN, WORKLOAD_FIT
+    wl = WORKLOADS[args.workload]
+    N_ROWS, D, CDIM, LAYERS, HIDDEN, WORKLOAD_FIT = wl["n"], wl["d"], wl["c"], wl["L"], wl["hidden"], wl["fit"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -327,11 +415,15 @@ def main():
     for p in nf.parameters():
         p.data = p.data.to(dev)
     eng = nf.engine()
+    comm = None
     if dp:
         _engine.broadcast_(eng.flat, 0)
-        # the communicator and the all-reduce of exactly this message size set themselves up here, outside any timing
-        # (with --warmup 0 the first timed step would otherwise carry RCCL's lazy initialisation)
-        dist.all_reduce(torch.zeros(eng.P + 1, device=dev), op=dist.ReduceOp.SUM)
+        # the library's RCCL communicator (what RealNVP.fit uses under torch.distributed over RCCL) and one all-reduce of
+        # exactly this message size, outside any timing; BENCH_FORCE_DIST: a one-rank communicator; gloo jobs: none (the
+        # per-batch loop over torch.distributed, as RealNVP.fit does there)
+        comm = _hip.dp_init(_hip.dp_unique_id(), 0, 1) if force_dist else _engine.dp_communicator(dev)
+        if comm is not None:
+            _hip.dp_all_reduce(comm, torch.zeros(eng.P + 1, device=dev), eng.P + 1)
         torch.cuda.synchronize()
     opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
 
@@ -339,34 +431,40 @@ def main():
     Xh, Ch = make_data(N_ROWS, D, CDIM, seed=rank)
     X = torch.from_numpy(Xh).to(dev); C = torch.from_numpy(Ch).to(dev)
     n_steps = args.steps + args.warmup
+    do_fit, do_sample = wl["fit"], wl["sample"]
     bounds = _engine.batch_bounds(N_ROWS, BATCH)
-    nb = len(bounds)
+    nb = len(bounds) if do_fit else 0
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
-    perms = [torch.randperm(N_ROWS, device=dev, generator=gen) for _ in range(n_steps)]    # one shuffle per epoch
+    perms = []
+    if do_fit:
+        for _ in range(n_steps):                                     # one shuffle per epoch
+            p_loc = torch.randperm(N_ROWS, device=dev, generator=gen)
+            if world == 1:
+                perms.append(p_loc)
+                continue
+            # N ranks, weak scaling: the global data set is the N ranks' 1M-row blocks and a global batch holds 65 536 rows of
+            # each.  RealNVP.fit's data-parallel call takes the permutation of the GLOBAL epoch and reads only this rank's
+            # share of every batch, so the local shuffle is placed at those positions (the other ranks' entries are
+            # never read) and the local block plays the data set.
+            p_glob = torch.zeros(N_ROWS * world, dtype=torch.int64, device=dev)
+            for (s, e) in bounds:
+                b = e - s
+                p_glob[s * world + rank * b: s * world + (rank + 1) * b] = p_loc[s:e]
+            perms.append(p_glob)
     xs = torch.empty(N_ROWS, D, dtype=torch.float32, device=dev)
-    losses = torch.zeros(n_steps, nb, device=dev)
+    losses = torch.zeros(n_steps, max(nb, 1), device=dev)
     P = eng.P
+    gbounds = _engine.batch_bounds(N_ROWS * world, BATCH * world)
 
-    def step_dp(i):
-        """N ranks: per batch the shard's loss + gradient, the all-reduce of [gradient | loss] on RCCL's stream, and --
-        under that all-reduce, which it does not depend on -- the sampling of this batch's 65 536 rows (the 1M sampled
-        rows of the step are drawn batch by batch; the counter-based prior makes the chunks tile the one-shot draw);
-        then loss read-out + Adam in one launch."""
-        perm = perms[i]
-        for k, (s, e) in enumerate(bounds):
-            g = eng.loss_grad(X, C, perm[s:e], e - s, 1.0 / ((e - s) * world))
-            work = dist.all_reduce(g[:P + 1], op=dist.ReduceOp.SUM, async_op=True)
-            eng.sample(e - s, C[s:e], 1000 + i, row_offset=rank * N_ROWS + s, out=xs[s:e])
-            work.wait()
-            eng.finish_dp_step(opt, losses[i, k:k + 1])
-
-    def step_1(i):
-        """single GPU: rnvp_fit_epoch (a fused loss + gradient + Adam step per batch, looped in the library),
-        then the fused prior draw + inverse, as RealNVP.fit / .sample(prior_rng='device') issue them"""
-        eng.fit_epoch(opt, X, C, perms[i], BATCH, losses[i])
-        eng.sample(N_ROWS, C, 1000 + i, row_offset=0, out=xs)
-
-    step = step_dp if dp else step_1
+    def step(i):
+        """what RealNVP.fit and .sample(prior_rng='device') issue for one epoch: _engine.run_epoch -- one GPU:
+        rnvp_fit_epoch (a fused loss + gradient + Adam step per batch, looped in the library); N ranks over RCCL:
+        rnvp_fit_epoch_dp (per batch this rank's rows, the all-reduce of [gradient | loss] on the same stream, loss
+        read-out + Adam) -- then the fused prior draw + inverse over the rank's rows"""
+        if do_fit:
+            _engine.run_epoch(eng, opt, comm, X, C, perms[i], gbounds, BATCH * world, rank, world, losses[i])
+        if do_sample:
+            eng.sample(N_ROWS, C, 1000 + i, row_offset=rank * N_ROWS, out=xs)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -389,9 +487,9 @@ def main():
 
     n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
     n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
-    assert n_train == args.steps * nb and n_inv == args.steps * (nb if dp else 1), (n_train, n_inv, args.steps)
-    final_loss = float(losses[n_steps - 1, nb - 1].item())
-    assert np.isfinite(final_loss), "training diverged"
+    assert n_train == args.steps * nb and n_inv == args.steps * (1 if do_sample else 0), (n_train, n_inv, args.steps)
+    final_loss = float(losses[n_steps - 1, nb - 1].item()) if do_fit else None
+    assert final_loss is None or np.isfinite(final_loss), "training diverged"
 
     if rank == 0:
         # log-prob kernel (not part of fit+sample): measured here, after the timed region
@@ -406,55 +504,78 @@ def main():
     _hip.profile_enable(0)
 
     if rank == 0:
-        rows_per_step = 2 * N_ROWS * world
+        rows_per_step = (int(do_fit) + int(do_sample)) * N_ROWS * world
         f1 = useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 1)
-        train_tf = 3 * f1 * N_ROWS * args.steps / (train_ms * 1e-3) / 1e12          # fwd + dgrad + wgrad
+        train_tf = 3 * f1 * N_ROWS * args.steps / (train_ms * 1e-3) / 1e12 if do_fit else None     # fwd + dgrad + wgrad
         inv_tf = f1 * N_ROWS * args.steps / (inv_ms * 1e-3) / 1e12
         fwd_tf = f1 * N_ROWS * n_fwd / (fwd_ms * 1e-3) / 1e12
         path = _hip.kernel_path(eng.shape, eng.masks_host, _hip.OP_TRAIN)
         kname = "k_mfma_train" if path == _hip.PATH_MFMA else "k_generic_train"
+        flow_bx3 = D > 16 or CDIM > 4                    # precision 'auto': split-bf16 GEMM1 in the forward / inverse kernels
+        flow_kernel = "k_flow_bx3" if flow_bx3 else "k_mfma_flow"
+        mixed = mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS)
+        if do_fit:
+            roof = {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": train_tf / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(kname),
+                    "kernel": "%s (fused forward+backward): %d launches in the timed region, %.3f ms avg (15 of every 16 "
+                              "on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch"
+                              % (kname, n_train, train_ms / n_train, 3 * f1, N_ROWS)}
+        else:           # sampling only (C4): the inverse kernel is the dominant one
+            roof = {"bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(flow_kernel),
+                    "frac_mixed_bound": mixed * N_ROWS * args.steps / (inv_ms * 1e-3) if flow_bx3 else None,
+                    "kernel": "%s inverse with the prior drawn in-kernel: %d launches of %d rows in the timed region, %.3f ms avg, "
+                              "%d useful flop/row; `frac` prices it against the f32 MFMA peak, `frac_mixed_bound` against the "
+                              "bound of what it executes (GEMM1 as six bf16 products per f32 product on the bf16 peak, "
+                              "GEMM2 on f32 MFMA)" % (flow_kernel, n_inv, N_ROWS, inv_ms / n_inv, f1)}
+        sample_entry = {"bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": inv_ms / max(n_inv, 1),
+                        "rows_per_launch": N_ROWS, "launches": n_inv, "where": "timed region"}
+        fwd_entry = {"bound": "mfma", "achieved": fwd_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fwd_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": fwd_ms / n_fwd, "rows_per_launch": N_ROWS,
+                     "launches": n_fwd, "where": "after the timed region"}
+        if flow_bx3:
+            sample_entry["frac_mixed_bound"] = mixed * N_ROWS * args.steps / (inv_ms * 1e-3)
+            fwd_entry["frac_mixed_bound"] = mixed * N_ROWS * n_fwd / (fwd_ms * 1e-3)
+        step_text = ("one fit epoch over the rank's %d rows (%d batches of %d incl. the ragged one: loss+grad+Adam each) + "
+                     % (N_ROWS, nb, BATCH) if do_fit else "") + \
+                    "sampling %d rows (counter-based prior draw inside the inverse kernel)" % N_ROWS
+        if dp and do_fit:
+            step_text += ("; N ranks: _engine.run_epoch, the call RealNVP.fit makes -- " +
+                          ("rnvp_fit_epoch_dp on the library's RCCL communicator (loss+grad, all-reduce, Adam per batch on one stream)"
+                           if comm is not None else "per-batch loop over torch.distributed (no RCCL communicator in this job)"))
         out = {
             "metric": "RealNVP samples/sec (fit+sample)", "value": rows_per_step * args.steps / dt,
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: RealNVP n=1M/GPU d=16 cond=4 L=8 hidden=(128,); one step = one fit epoch over the "
-                                   "rank's 1M rows (16 batches of 65536 incl. the ragged one: loss+grad+Adam each) + "
-                                   "sampling 1M rows (counter-based prior draw inside the inverse kernel)" +
-                                   ("; N > 1: the 1M rows are sampled batch by batch under each gradient all-reduce" if dp else ""),
-                       "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+            "config": {"workload": "%s: RealNVP n=%d/GPU d=%d cond=%d L=%d hidden=%r; one step = %s"
+                                   % (wl["label"], N_ROWS, D, CDIM, LAYERS, HIDDEN, step_text),
+                       "global_batch": BATCH * world if do_fit else None, "parallelism": "dp%d" % world,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
-            "roofline": {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": train_tf / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(kname),
-                         "kernel": "%s (fused forward+backward): %d launches in the timed region, %.3f ms avg (15 of every 16 "
-                                   "on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch"
-                                   % (kname, n_train, train_ms / n_train, 3 * f1, N_ROWS)},
+            "roofline": roof,
             "roofline_kernels": {
-                "sample (k_mfma_flow inverse, prior drawn in-kernel)": {
-                    "bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": inv_ms / n_inv,
-                    "rows_per_launch": N_ROWS * args.steps // n_inv, "launches": n_inv, "where": "timed region"},
-                "log_prob (k_mfma_flow forward)": {
-                    "bound": "mfma", "achieved": fwd_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fwd_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": fwd_ms / n_fwd, "rows_per_launch": N_ROWS,
-                    "launches": n_fwd, "where": "after the timed region"}},
+                "sample (%s inverse, prior drawn in-kernel)" % flow_kernel: sample_entry,
+                "log_prob (%s forward)" % flow_kernel: fwd_entry},
             "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / args.steps * 1e-3),
                                 "note": "sample: kernel time only; fit: ms_per_step minus the sampling kernels' time"},
         }
-        out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / args.steps * 1e-3, 1e-9)
+        if do_fit:
+            out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / args.steps * 1e-3, 1e-9)
         params = eng.params.detach().cpu().numpy()
-        if world == 1 and not force_dist and not args.no_api_level:
+        if world == 1 and not force_dist and not args.no_api_level and args.workload == "c2":
             out["api_level"] = api_level(Xh, Ch, dev)
             out["secondary_configs"] = secondary_configs(Xh, Ch, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Xh, Ch)
-            out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(Xh, Ch, params)
+            if args.workload == "c2":
+                out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(Xh, Ch, params)
             # second half of BASELINE.json's metric: per-row log-prob MAE of the HIP path against the
             # CPU restatement of the reference (float32 oracle, and its float64 referee) on the
             # trained weights, 4096 rows
             from oracle import Oracle, Shape
             rows = 4096
-            lp = nf.log_prob_samples(X[:rows], C[:rows]).cpu().numpy()
+            lp = nf.log_prob_samples(X[:rows], C[:rows]).detach().cpu().numpy()
             sh = Shape.make(LAYERS, D, CDIM, HIDDEN, "tanh")
             _, lp32, _ = Oracle(32).log_prob(sh, params, Xh[:rows], Ch[:rows])
             _, lp64, _ = Oracle(64).log_prob(sh, params, Xh[:rows], Ch[:rows])

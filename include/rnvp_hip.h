@@ -191,6 +191,24 @@ int rnvp_loss_grad_zseed(void *stream, const rnvp_shape *shape,
                          void *workspace, size_t workspace_bytes);
 
 /*
+ * Backward of rnvp_forward_logprob for ANY scalar loss of its outputs: the vector-Jacobian product autograd forms in the
+ * reference when a user differentiates through `layer.f(X, C)` / `nf.log_prob(X, C)` (nflow.py:107-117; the reference's
+ * own fit does exactly this at realnvp.py:246-250).  Given, per batch row r,
+ *   gz  [n_rows, d] = d loss / d z[r]        gld [n_rows] = d loss / d logdet[r]
+ * it returns
+ *   grad_out [rnvp_param_count]  d loss / d params        gx_out [n_rows, d]  d loss / d x[r]   (nullable)
+ * (the gradient w.r.t. the conditions is not formed: the reference's callers pass data there).  Rows are batch rows:
+ * with row_index the inputs are gathered, gz / gld / gx_out are not.  With shape->L == 1 this is the backward of one
+ * RealNVPLayer.f.  Same kernels, workspace (RNVP_OP_TRAIN) and determinism as rnvp_loss_grad.
+ */
+int rnvp_backward(void *stream, const rnvp_shape *shape,
+                  const float *params, const uint8_t *masks,
+                  const float *x, const float *c, const int64_t *row_index,
+                  int64_t n_rows, const float *gz, const float *gld,
+                  float *grad_out, float *gx_out,
+                  void *workspace, size_t workspace_bytes);
+
+/*
  * torch.optim.Adam step over the flat parameter buffer (realnvp.py:205-207,251):
  * betas/eps as given, amsgrad off, L2 weight decay folded into the gradient.
  * `step` is the 1-based step number of THIS update.
@@ -242,6 +260,33 @@ int rnvp_fit_epoch(void *stream, const rnvp_shape *shape,
                    float *exp_avg, float *exp_avg_sq,
                    double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t first_step, void *workspace, size_t workspace_bytes);
+
+/*
+ * Data-parallel fit (the reference has no counterpart: its loop, realnvp.py:235-254, is single-process).
+ * One process per GPU; every rank walks the SAME permutation and takes a contiguous share of each global batch.
+ *
+ * The library owns its RCCL communicator (librccl is dlopen'ed on first use: single-GPU callers never load it):
+ *   rnvp_dp_unique_id   rank 0 fills 128 host bytes; the caller sends them to every rank (e.g. torch.distributed.broadcast)
+ *   rnvp_dp_init        collective over all ranks; *comm_out is the handle for the calls below
+ *   rnvp_dp_destroy     frees it
+ *   rnvp_dp_all_reduce  in-place SUM of `count` floats on `stream` (what rnvp_fit_epoch_dp issues per batch)
+ *
+ * rnvp_fit_epoch_dp: all batches of one epoch, enqueued on ONE stream by one call -- per batch rnvp_loss_grad on this
+ * rank's rows of perm[s0 : s0 + rows] (share [rank * rows / world ...), remainder to the low ranks; gradients scaled by
+ * 1 / rows_global inside the kernel), the all-reduce of grad_loss[0 .. P] (P gradients + this rank's share of the batch
+ * loss), then rnvp_dp_finish_step: the batch loss into loss_hist[k] and the identical Adam step on every rank.
+ * grad_loss [P + 1]; everything else as rnvp_fit_epoch.  comm == NULL runs the same loop for one rank without RCCL.
+ */
+int rnvp_dp_unique_id(void *id_out_128_host_bytes);
+int rnvp_dp_init(const void *id_128_host_bytes, int rank, int world, void **comm_out);
+int rnvp_dp_destroy(void *comm);
+int rnvp_dp_all_reduce(void *stream, void *comm, float *buf, int64_t count);
+int rnvp_fit_epoch_dp(void *stream, void *comm, const rnvp_shape *shape,
+                      float *params, const uint8_t *masks,
+                      const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                      float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                      int64_t first_step, void *workspace, size_t workspace_bytes);
 
 /*
  * Measurement aid (bench.py): while enabled, the hot kernel of each call -- the fused forward+backward

@@ -344,6 +344,14 @@ class FlowEngine:
         _hip.forward_logprob(self.shape, self.params, self.masks, x, c, rows, n, z, ld, lp, tot, ws)
         return z, ld, lp, tot
 
+    def forward_autograd(self, x, c):
+        """(z, logdet) = f(x, c) WITH an autograd graph: `FlowFunction` records the inputs, and its backward is the
+        hand-derived HIP backward (rnvp_backward) -- what torch autograd builds op by op in the reference when a user
+        differentiates nf.log_prob / layer.f (nflow.py:107-117, realnvp.py:246-250)."""
+        self.sync_params()
+        c = self._cond(c, x.shape[0])
+        return FlowFunction.apply(self, x, c, *self.param_list)
+
     def inverse(self, z, c, out=None):
         self.sync_params()
         n = self._rows(z, None)
@@ -422,6 +430,18 @@ class FlowEngine:
                        opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
         opt.step_count += len(batch_bounds(n, batch_size))
 
+    def fit_epoch_dp(self, opt, comm, x, c, perm, batch_size, losses):
+        """data parallel: all batches of one epoch in ONE library call on ONE stream (rnvp_fit_epoch_dp): per batch this
+        rank's loss + gradient, the all-reduce of [gradient | loss] on the library's RCCL communicator, loss read-out +
+        Adam.  comm None: the same loop for a single rank without any exchange."""
+        lr, b1, b2, eps, wd = opt.hyper
+        n = perm.numel()
+        g = self.ensure_gbuf()
+        ws = self.workspace(_hip.OP_TRAIN, min(n, batch_size))
+        _hip.fit_epoch_dp(comm, self.shape, self.params, self.masks, x, c, perm, n, batch_size, g[:self.P + 1], losses,
+                          opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
+        opt.step_count += len(batch_bounds(n, batch_size))
+
     def train_step(self, opt, x, c, rows, n_rows, inv_B, loss_out):
         """single-GPU fused step: loss+grad, Adam; the batch loss lands in loss_out[0:1]."""
         lr, b1, b2, eps, wd = opt.hyper
@@ -430,6 +450,56 @@ class FlowEngine:
         ws = self.workspace(_hip.OP_TRAIN, max(n_rows, 1))
         _hip.train_step(self.shape, self.params, self.masks, x, c, rows, n_rows, inv_B, g[:self.P], loss_out,
                         opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count, ws)
+
+
+class FlowFunction(torch.autograd.Function):
+    """z, logdet = flow.f(x, c) as one autograd node.
+
+    forward : rnvp_forward_logprob (the fused stack; L = 1 for a single RealNVPLayer)
+    backward: rnvp_backward -- (d loss / d z, d loss / d logdet) -> d loss / d x and d loss / d every parameter, the
+              hand-derived backward of SURVEY.md 3.3 (the same kernels RealNVP.fit uses, seeded by the caller).
+    The parameters are passed as inputs only so that autograd routes their gradients; the kernels read the engine's flat
+    buffer, of which every parameter is a view.  The conditions get no gradient (data in every caller of the reference)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, c, *params):
+        n = x.shape[0]
+        x = x.detach().contiguous()
+        z = torch.empty_like(x)
+        ld = torch.empty(n, dtype=torch.float32, device=x.device)
+        if n > 0:
+            _hip.forward_logprob(engine.shape, engine.params, engine.masks, x, c, None, n, z, ld, None, None,
+                                 engine.workspace(_hip.OP_FORWARD, n))
+        ctx.engine, ctx.n = engine, n
+        ctx.save_for_backward(x, c if c is not None else x.new_empty(0))
+        ctx.has_c = c is not None
+        ctx.version = engine.flat._version
+        return z, ld
+
+    @staticmethod
+    def backward(ctx, gz, gld):
+        eng, n = ctx.engine, ctx.n
+        x, c = ctx.saved_tensors
+        c = c if ctx.has_c else None
+        if eng.flat._version != ctx.version:
+            raise RuntimeError("the flow's parameters were modified in place between forward and backward "
+                               "(one of the variables needed for gradient computation has been modified)")
+        dev = x.device
+        gz = torch.zeros_like(x) if gz is None else gz.to(torch.float32).contiguous()
+        gld = torch.zeros(n, dtype=torch.float32, device=dev) if gld is None else gld.to(torch.float32).contiguous()
+        gflat = torch.zeros(eng.P + (-eng.P) % 4, dtype=torch.float32, device=dev)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        if n > 0:
+            _hip.backward(eng.shape, eng.params, eng.masks, x, c, None, n, gz, gld, gflat[:eng.P], gx,
+                          eng.workspace(_hip.OP_TRAIN, n))
+        elif gx is not None:
+            gx.zero_()
+        grads, off = [], 0
+        for i, p in enumerate(eng.param_list):
+            k = p.numel()
+            grads.append(gflat[off:off + k].view(p.shape) if ctx.needs_input_grad[3 + i] else None)
+            off += k
+        return (None, gx, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------
@@ -454,6 +524,53 @@ def broadcast_(t, src=0):
     return t
 
 
+_DP_COMM = {}          # (world, rank, device index) -> the library's RCCL communicator of this process
+
+
+def dp_communicator(device):
+    """The library's own RCCL communicator for the ranks of torch.distributed's default group (one per process, made on
+    first use: rank 0 draws the id, torch.distributed carries it to the others).  None when the job does not run one
+    rank per GPU over RCCL (world 1; gloo test jobs that put several ranks on one GPU) -- callers then take the per-batch
+    Python loop over torch.distributed instead."""
+    import torch.distributed as dist
+    rank, world = dist_info()
+    if world == 1 or dist.get_backend() != "nccl":
+        return None
+    key = (world, rank, torch.device(device).index)
+    if key not in _DP_COMM:
+        box = [_hip.dp_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        with torch.cuda.device(device):
+            _DP_COMM[key] = _hip.dp_init(box[0], rank, world)
+    return _DP_COMM[key]
+
+
+def run_epoch(engine, opt, comm, X, C, perm, bounds, batch_size, rank, world, losses, prior=None):
+    """every batch of one epoch (realnvp.py:237-254), enqueued without waiting for the GPU:
+    one GPU            -> rnvp_fit_epoch (a fused loss + gradient + Adam step per batch, looped in the library);
+    N ranks over RCCL  -> rnvp_fit_epoch_dp (per batch: this rank's share, all-reduce on the same stream, Adam);
+    otherwise (gloo process groups, a user-assigned prior) batch by batch from here with torch.distributed.
+    bench.py times exactly this function."""
+    if world == 1 and prior is None and comm is None:
+        engine.fit_epoch(opt, X, C, perm, batch_size, losses)
+        return
+    if prior is None and (comm is not None or world == 1):
+        engine.fit_epoch_dp(opt, comm, X, C, perm, batch_size, losses)
+        return
+    for k, (s, e) in enumerate(bounds):
+        lo, hi = shard_bounds(s, e, rank, world)
+        if prior is None:
+            g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+        else:
+            g = engine.loss_grad_prior(prior, X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
+        if world == 1:
+            losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
+            engine.adam(opt)
+            continue
+        all_reduce_sum(g[:engine.P + 1])
+        engine.finish_dp_step(opt, losses[k:k + 1])
+
+
 def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None, prior=None, perms=None):
     """The batch loop of RealNVP.fit (realnvp.py:235-262) on device-resident X [n,d], C [n,c].
 
@@ -461,7 +578,9 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     library).  With torch.distributed initialised every
     rank walks the SAME permutation (rank 0's loader seeds are broadcast), takes its contiguous share of each global batch, and the
     flat [gradient | loss] buffer is all-reduced (SUM) before an identical Adam step on every
-    rank -- gradients are scaled by 1/B_global inside the kernel, so the sum is the batch mean.
+    rank -- gradients are scaled by 1/B_global inside the kernel, so the sum is the batch mean.  Over RCCL (one rank per
+    GPU) that loop, too, is one library call per epoch on one stream (rnvp_fit_epoch_dp on the library's own communicator);
+    other process groups (gloo) and user-assigned priors run it batch by batch from here.
     Losses stay on the device; one copy per epoch feeds loss_history (one entry per batch, as
     realnvp.py:254)."""
     rank, world = dist_info()
@@ -494,6 +613,7 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
                      prior=None):
     """prior: None for the fused N(0, I); otherwise the user's prior object (log_prob differentiable by torch)"""
     dev = engine.device
+    comm = dp_communicator(dev) if world > 1 else None
     # The next epoch's permutation (8 bytes per row) is uploaded on a side stream while this epoch's kernels run:
     # the staged copy blocks only the host, which has nothing else to do until the epoch's losses come back.
     side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
@@ -512,7 +632,7 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
         host = losses.cpu()
         loss_history.extend(host[i].clone() for i in range(host.numel()))
         if epoch_hook is not None:
-            epoch_hook(epoch, float(host[-1]))
+            epoch_hook(epoch, host)                      # the epoch's per-batch losses, in batch order
 
     # Epoch e's losses are read back only after epoch e+1 has been enqueued (and its successor's permutation uploaded),
     # so the GPU never waits for the host between epochs; loss_history / the progress hook trail by one epoch.
@@ -526,21 +646,7 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
                 torch.cuda.current_stream(dev).wait_event(ev)
                 perm.record_stream(torch.cuda.current_stream(dev))
             losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
-            if world == 1 and prior is None:
-                engine.fit_epoch(opt, X, C, perm, batch_size, losses)       # every batch, one library call
-            else:
-                for k, (s, e) in enumerate(bounds):
-                    lo, hi = shard_bounds(s, e, rank, world)
-                    if prior is None:
-                        g = engine.loss_grad(X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
-                    else:
-                        g = engine.loss_grad_prior(prior, X, C, perm[lo:hi], hi - lo, 1.0 / (e - s))
-                    if world == 1:
-                        losses[k:k + 1].copy_(g[engine.P:engine.P + 1])
-                        engine.adam(opt)
-                        continue
-                    all_reduce_sum(g[:engine.P + 1])
-                    engine.finish_dp_step(opt, losses[k:k + 1])
+            run_epoch(engine, opt, comm, X, C, perm, bounds, batch_size, rank, world, losses, prior)
             if epoch + 1 < n_epochs:
                 nxt = upload(epoch + 1)
             if pending is not None:

@@ -119,12 +119,19 @@ _SIGNATURES = {
     "rnvp_sample": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _I64, _U64, _I64, _VP, _VP, _SZ]),
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
     "rnvp_loss_grad_zseed": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP, _SZ]),
+    "rnvp_backward": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
     "rnvp_dp_finish_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64, _VP]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "rnvp_fit_epoch": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
                                  _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "rnvp_dp_unique_id": (C.c_int, [_VP]),
+    "rnvp_dp_init": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rnvp_dp_destroy": (C.c_int, [_VP]),
+    "rnvp_dp_all_reduce": (C.c_int, [_VP, _VP, _VP, _I64]),
+    "rnvp_fit_epoch_dp": (C.c_int, [_VP, _VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
+                                    _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
     "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
@@ -265,6 +272,15 @@ def loss_grad_zseed(shape, params, masks, x, c, row_index, n_rows, inv_B, gz, gr
         _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
 
 
+def backward(shape, params, masks, x, c, row_index, n_rows, gz, gld, grad_out, gx_out, ws):
+    """vector-Jacobian product of rnvp_forward_logprob: (d loss / d z, d loss / d logdet) -> (d loss / d params, d loss / d x)"""
+    wp, wn = _ws(ws)
+    _call("rnvp_backward", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
+        int(n_rows), _ptr(gz, torch.float32, "gz"), _ptr(gld, torch.float32, "gld"),
+        _ptr(grad_out, torch.float32, "grad_out"), _ptr(gx_out, torch.float32, "gx_out"), wp, wn))
+
+
 def adam_step(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step):
     _call("rnvp_adam_step", (_ptr(params, torch.float32, "params"), _ptr(grad, torch.float32, "grad"),
         _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), int(n),
@@ -295,6 +311,41 @@ def fit_epoch(shape, params, masks, x, c, perm, n, batch_size, grad_buf, loss_hi
     _call("rnvp_fit_epoch", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
           _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), int(n),
           int(batch_size), _ptr(grad_buf, torch.float32, "grad_buf"), _ptr(loss_hist, torch.float32, "loss_hist"),
+          _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
+          float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn))
+
+
+# ---- data parallel: the library's own RCCL communicator (include/rnvp_hip.h, rnvp_dp_*) --------------------------------
+def dp_unique_id():
+    """128 bytes identifying a new communicator (call on rank 0, send to every rank)"""
+    buf = C.create_string_buffer(128)
+    check(lib().rnvp_dp_unique_id(buf), "rnvp_dp_unique_id")
+    return buf.raw
+
+
+def dp_init(uid, rank, world):
+    """collective: every rank calls it with rank 0's id; returns the opaque communicator handle"""
+    h = C.c_void_p()
+    check(lib().rnvp_dp_init(C.create_string_buffer(bytes(uid), 128), int(rank), int(world), C.byref(h)), "rnvp_dp_init")
+    return h
+
+
+def dp_destroy(comm):
+    if comm is not None:
+        lib().rnvp_dp_destroy(comm)
+
+
+def dp_all_reduce(comm, buf, count):
+    _call("rnvp_dp_all_reduce", (comm, _ptr(buf, torch.float32, "buf"), int(count)))
+
+
+def fit_epoch_dp(comm, shape, params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, exp_avg, exp_avg_sq,
+                 lr, beta1, beta2, eps, weight_decay, first_step, ws):
+    """one epoch of the data-parallel batch loop in one call (comm None: one rank, no exchange)"""
+    wp, wn = _ws(ws)
+    _call("rnvp_fit_epoch_dp", (comm, C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+          _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), int(n),
+          int(batch_size), _ptr(grad_loss, torch.float32, "grad_loss"), _ptr(loss_hist, torch.float32, "loss_hist"),
           _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
           float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn))
 

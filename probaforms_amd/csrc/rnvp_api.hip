@@ -203,12 +203,12 @@ int rnvp_sample(void *stream, const rnvp_shape *shape, const float *params, cons
 
 static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
                          const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
-                         const float *gz, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes);
+                         Seeds sd, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes);
 
 int rnvp_loss_grad(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
                    const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
                    float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
-    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, nullptr, grad_out, loss_out,
+    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, Seeds{}, grad_out, loss_out,
                          workspace, workspace_bytes);
 }
 
@@ -216,13 +216,24 @@ int rnvp_loss_grad_zseed(void *stream, const rnvp_shape *shape, const float *par
                          const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
                          const float *gz, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
     if (!gz && n_rows > 0) return RNVP_EINVAL;
-    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, gz, grad_out, loss_out,
-                         workspace, workspace_bytes);
+    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, inv_B, Seeds{gz, nullptr, nullptr}, grad_out,
+                         loss_out, workspace, workspace_bytes);
+}
+
+int rnvp_backward(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                  const float *x, const float *c, const int64_t *row_index, int64_t n_rows,
+                  const float *gz, const float *gld, float *grad_out, float *gx_out,
+                  void *workspace, size_t workspace_bytes) {
+    if ((!gz || !gld) && n_rows > 0) return RNVP_EINVAL;
+    // the kernels' loss output is the log-det sum scaled by inv_B: with inv_B = 0 nothing but the caller's seeds drives
+    // the backward, and the (unused) loss slot stays finite
+    return loss_grad_any(stream, shape, params, masks, x, c, row_index, n_rows, 0.0f, Seeds{gz, gld, gx_out}, grad_out,
+                         nullptr, workspace, workspace_bytes);
 }
 
 static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
                          const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
-                         const float *gz, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
+                         Seeds sd, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {
     KShape k;
     int rc = make_kshape(shape, &k);
     if (rc) return rc;
@@ -237,13 +248,13 @@ static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *par
     if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
     if (mfma::train_supported(k))
         return mfma::loss_grad(st, k, params, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
-                               workspace_bytes, gz);
+                               workspace_bytes, sd);
     if (!masks) return RNVP_EINVAL;
     if (lmm::use_lmm(k, RNVP_OP_TRAIN))
         return lmm::loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
-                              workspace_bytes, gz);
+                              workspace_bytes, sd);
     return generic_loss_grad(st, k, params, masks, x, c, row_index, n_rows, inv_B, grad_out, loss_out,
-                             workspace, workspace_bytes, gz);
+                             workspace, workspace_bytes, sd);
 }
 
 int rnvp_adam_step(void *stream, float *params, const float *grad, float *exp_avg, float *exp_avg_sq,

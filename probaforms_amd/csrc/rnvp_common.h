@@ -70,6 +70,16 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Optional seeds / outputs of the backward pass (all nullable):
+//   gz  [n_rows, d]  d loss / d z instead of the fused prior's z / B      (rnvp_loss_grad_zseed, rnvp_backward)
+//   gld [n_rows]     d loss / d logdet per row instead of the uniform -1/B (rnvp_backward)
+//   gx  [n_rows, d]  OUT: d loss / d x of the batch rows                   (rnvp_backward)
+struct Seeds {
+    const float *gz = nullptr;
+    const float *gld = nullptr;
+    float *gx = nullptr;
+};
+
 // ---- generic (any-shape) path: rnvp_generic.hip ---------------------------------------
 size_t generic_workspace_bytes(const KShape &k, int op, int64_t max_rows);
 int generic_forward(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks,
@@ -81,7 +91,7 @@ int generic_inverse(hipStream_t st, const KShape &k, const float *params, const 
 int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *row_index, int64_t n,
                       float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
-                      const float *gz = nullptr);
+                      Seeds sd = Seeds{});
 
 int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
                             float loss_scale, float *grad_out, float *loss_out);

@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256)
 k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__restrict__ masks,
                 const float *__restrict__ x, const float *__restrict__ c,
                 const int64_t *__restrict__ row_index, int64_t n, float inv_B,
-                float *gpart, float *losspart, float *xsave, int TB, int TBP, const float *__restrict__ gz) {
+                float *gpart, float *losspart, float *xsave, int TB, int TBP, Seeds sd) {
+    const float *__restrict__ gz = sd.gz;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, d = s.d, cd = s.c, nthreads = blockDim.x;
     float *xcur = lds;
@@ -200,7 +201,7 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
         red[t] = valid ? lp : 0.f;
         __syncthreads();
         if (t == 0) { float a = 0.f; for (int r = 0; r < TB; ++r) a += red[r]; block_sum += a; }
-        const float gld = valid ? -inv_B : 0.f;                       // d loss / d log_det
+        const float gld = valid ? (sd.gld ? sd.gld[row] : -inv_B) : 0.f;      // d loss / d log_det (rnvp_backward: the caller's)
         for (int l = s.L - 1; l >= 0; --l) {
             const uint8_t *m = masks + l * d;
             const float *pl = params + (size_t)l * 2 * s.npn;
@@ -235,6 +236,8 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
                 for (int j = 0; j < d; ++j)
                     gy[j * TBP + t] = gxb[j * TBP + t] + (m[j] ? gin[j * TBP + t] : 0.f);
         }
+        if (sd.gx && valid)                                           // rnvp_backward: d loss / d x of the batch rows
+            for (int j = 0; j < d; ++j) sd.gx[row * d + j] = gy[j * TBP + t];
         first = false;
         __syncthreads();
     }
@@ -361,7 +364,7 @@ int generic_inverse(hipStream_t st, const KShape &k, const float *params, const 
 
 int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *row_index, int64_t n,
-                      float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes, const float *gz) {
+                      float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes, Seeds sd) {
     Tiling tl;
     if (!pick_tiling(k, RNVP_OP_TRAIN, n, &tl)) return RNVP_EUNSUPPORTED;
     if (!ws || ws_bytes < generic_workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
@@ -378,7 +381,7 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
         hipLaunchKernelGGL(k_generic_train, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,
-                           row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP, gz);
+                           row_index, n, inv_B, gpart, losspart, xsave, tl.TB, tl.TBP, sd);
     }
     RNVP_HIP_TRY(hipGetLastError());
     const int rb = 256;

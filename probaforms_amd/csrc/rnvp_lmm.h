@@ -30,7 +30,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
             int64_t n, float *x_out, void *ws, size_t ws_bytes);
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
-              const float *gz);
+              Seeds sd);
 
 }  // namespace lmm
 }  // namespace rnvp

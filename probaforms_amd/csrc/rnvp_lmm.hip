@@ -307,11 +307,12 @@ __device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot,
 __global__ void __launch_bounds__(64 * kW)
 k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
             const uint8_t *__restrict__ masks, const float *__restrict__ x, const float *__restrict__ c,
-            const int64_t *__restrict__ row_index, int64_t n, float inv_B, const float *__restrict__ gz,
+            const int64_t *__restrict__ row_index, int64_t n, float inv_B, Seeds sd,
             float *__restrict__ dump, float *__restrict__ xsave, float *losspart, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
     const int jq = q + 4 * wave, jstep = 4 * kW;           // this lane's features in the elementwise passes
+    const float *__restrict__ gz = sd.gz;
     float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
     float *GA = GIN + d * RS, *GB = GA + g.wmax * RS;
     float *RED = lds + g.lds_train / sizeof(float) - 2 * kW * 16;
@@ -354,7 +355,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             for (int j = jq; j < d; j += jstep)
                 GY[j * RS + r] = valid ? (gz ? gz[row * d + j] : XC[j * RS + r] * inv_B) : 0.f;
         }
-        const float gld = valid ? -inv_B : 0.f;
+        const float gld = valid ? (sd.gld ? sd.gld[row] : -inv_B) : 0.f;      // rnvp_backward: the caller's d loss / d logdet
         __syncthreads();
         for (int l = s.L - 1; l >= 0; --l) {
             const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
@@ -413,6 +414,8 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             }
             __syncthreads();
         }
+        if (sd.gx && valid)                                  // rnvp_backward: d loss / d x of the batch rows
+            for (int j = jq; j < d; j += jstep) sd.gx[row * d + j] = GY[j * RS + r];
     }
     if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;      // chunks run in order on one stream
 }
@@ -616,7 +619,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
-              const float *gz) {
+              Seeds sd) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
     const LGeo g = make_lgeo(k);
     const int64_t cr = chunk_rows(k, g);
@@ -643,8 +646,9 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_
         {
             KernelTimer timer(st, RNVP_PROFILE_TRAIN);
             hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64 * kW), g.lds_train, st, k, g, packed, params, masks, xc, cc,
-                               row_index ? row_index + r0 : nullptr, rows, inv_B, gz ? gz + r0 * k.d : nullptr, dump, xsave,
-                               losspart, first ? 1 : 0);
+                               row_index ? row_index + r0 : nullptr, rows, inv_B,
+                               Seeds{sd.gz ? sd.gz + r0 * k.d : nullptr, sd.gld ? sd.gld + r0 : nullptr, sd.gx ? sd.gx + r0 * k.d : nullptr},
+                               dump, xsave, losspart, first ? 1 : 0);
         }
         RNVP_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)(k.L * 2 * g.quads_per_net), (unsigned)S), dim3(64), 0, st, k, g, dump,

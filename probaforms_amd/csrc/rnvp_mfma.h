@@ -23,6 +23,7 @@
 // (dead work in the reference's dense form) are never computed.
 #pragma once
 #include "rnvp_common.h"
+#include "rnvp_split.h"
 
 namespace rnvp {
 namespace mfma {
@@ -40,6 +41,12 @@ struct Geo {
     int MTI;    // M tiles of the input gradient: max(1, NF / 4)
     // float offsets inside one layer's packed block
     int oA1, oB1, oA2, oB2, oA2T, oA1T, oA2X, oA1X, layer_floats;
+    // split-bf16 fragments of the training kernel's GEMM1 (forward and recompute) and of g_h = W2^T g_out (rnvp_split.h):
+    // present only when make_geo was asked for them (split = true), else NI1 = NI2 = 0 and both offsets = layer_floats
+    int NI1;    // v_mfma_f32_16x16x32_bf16 per GEMM1 tile: ceil(3 KS1 / 4)
+    int NI2;    // the same for g_h (NF values per lane): ceil(3 NF / 4)
+    int oA1S;   // [tile][NI1][lane][4 dwords]
+    int oA2TS;  // [tile][NI2][lane][4 dwords]
 };
 
 // smallest instantiated (NF, CQ) that holds d features and c conditions: (2,0) (2,1) (4,2) (8,4)
@@ -51,7 +58,7 @@ __host__ __device__ inline bool pick_tiles(int d, int c, int *NF, int *CQ) {
     return false;
 }
 
-__host__ __device__ inline Geo make_geo(int d, int c, int h) {
+__host__ __device__ inline Geo make_geo(int d, int c, int h, bool split = false) {
     Geo g;
     g.d = d; g.c = c; g.h = h;
     g.NF = 2; g.CQ = 0;
@@ -72,6 +79,10 @@ __host__ __device__ inline Geo make_geo(int d, int c, int h) {
     // input-gradient product, which avoid the structural zeros of the shared t|s out tile
     g.oA2X = o; o += (g.NF == 2) ? 2 * g.HT * 2 * 256 : 0;   // [tile][og][lane][4 (rho)]
     g.oA1X = o; o += (g.NF == 2) ? 2 * g.HT * 2 * 256 : 0;   // [tile][og][lane][4 (rho)]
+    g.NI1 = split ? split::n_mfma(g.KS1) : 0;
+    g.NI2 = split ? split::n_mfma(g.NF) : 0;
+    g.oA1S = o; o += 2 * g.HT * g.NI1 * 256;
+    g.oA2TS = o; o += 2 * g.HT * g.NI2 * 256;
     g.layer_floats = o;
     return g;
 }
@@ -94,7 +105,7 @@ int sample(hipStream_t st, const KShape &k, const float *params, const float *c,
            int64_t row0, float *x_out, void *ws, size_t ws_bytes);
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes, const float *gz = nullptr);
+              void *ws, size_t ws_bytes, Seeds sd = Seeds{});
 
 int train_step(hipStream_t st, const KShape &k, float *params, const float *x, const float *c,
                const int64_t *row_index, int64_t n, float inv_B, float *grad_buf, float *loss_out,

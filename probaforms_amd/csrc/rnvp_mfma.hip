@@ -73,6 +73,30 @@ __device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const
         const int feat = feat_trans(g.NF, qo, f, pc);
         return feat < k.d ? pl[net * k.npn + k.boff[1] + feat] : 0.f;
     }
+    if (idx >= g.oA2TS) {                                  // A2TS [tile][NI2][lane][4 dwords]: W2^T of ONE net, split bf16
+        // lane (q, i): hidden unit 16t + i; the lane's slot list holds the NF transformed features of lane group q
+        const int j = idx - g.oA2TS;
+        const int e = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int ni = rest % g.NI2, tile = rest / g.NI2;
+        const int D = 4 * ni + e, v = D / 3, p = D % 3;
+        if (v >= g.NF) return 0.f;
+        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
+        const int hid = 16 * (tile % g.HT) + i;
+        return __uint_as_float(split::a_dword(RNVP_W2(net, feat_trans(g.NF, q, v, pc), hid), p));
+    }
+    if (idx >= g.oA1S) {                                   // A1S [tile][NI1][lane][4 dwords]: A1 split bf16 (same k order)
+        const int j = idx - g.oA1S;
+        const int e = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int ni = rest % g.NI1, tile = rest / g.NI1;
+        const int D = 4 * ni + e, kk = D / 3, p = D % 3;
+        const int q = lane >> 4, i = lane & 15;
+        const int net = tile / g.HT, hid = 16 * (tile % g.HT) + i;
+        int col;
+        if (kk < g.NF) col = xcol(feat_cond(g.NF, q, kk, pc));
+        else if (kk < g.KS1) col = ccol(q * g.CQ + (kk - g.NF));
+        else return 0.f;
+        return __uint_as_float(split::a_dword((k.act == RNVP_ACT_TANH ? kTanhScale : 1.0f) * RNVP_W1(net, hid, col), p));
+    }
     if (idx < g.oA1T) {                                    // A2T [tile][otl][lane][4 rho]
         const int j = idx - g.oA2T;
         const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;

@@ -238,16 +238,63 @@ __device__ __forceinline__ f4 gemm1(const f4 (&a1)[FwdDims<NF, CQ>::K4], f4 b1, 
     return acc;
 }
 
+// BX (training kernel, split-GEMM1 form): GEMM1 runs on v_mfma_f32_16x16x32_bf16 with three-term bf16 operands
+// (rnvp_split.h) -- the A fragments come from the oA1S section (NI1 per tile instead of K4), the B operand is `bin`,
+// the layer's inputs split once per layer and row tile (build_bin).
+using split::mfma32;
+template <int NF, int CQ> struct SplitDims {
+    static constexpr int NI1 = split::n_mfma(NF + CQ);     // bf16 MFMAs per GEMM1 tile
+    static constexpr int NI2 = split::n_mfma(NF);          // bf16 MFMAs of g_h = W2^T g_out per tile
+};
+template <int NF, int CQ, bool BX> struct G1Dims {
+    static constexpr int NA = BX ? SplitDims<NF, CQ>::NI1 : FwdDims<NF, CQ>::K4;      // f4 fragments per GEMM1 tile
+};
+template <int NF, int CQ, int PC, int R>
+__device__ __forceinline__ void build_bin(const float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                          f4 (&bin)[R][SplitDims<NF, CQ>::NI1]) {
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+        float v[NF + CQ];
+#pragma unroll
+        for (int kk = 0; kk < NF + CQ; ++kk) v[kk] = in_op<NF, CQ, PC, R>(xr, cr, rt, kk);
+        split::build_b<NF + CQ>(v, bin[rt]);
+    }
+}
+// one GEMM1 step (fragment i of NA) of row tile rt onto acc
+template <int NF, int CQ, int PC, int R, bool BX>
+__device__ __forceinline__ f4 gemm1_step(const f4 (&a1)[G1Dims<NF, CQ, BX>::NA], int i, const float (&xr)[R][2 * NF],
+                                         const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                         const f4 (*bin)[SplitDims<NF, CQ>::NI1], int rt, f4 acc) {
+    if constexpr (BX) {
+        return mfma32(a1[i], bin[rt][i], acc);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * i + e < NF + CQ) acc = mfma16(a1[i][e], in_op<NF, CQ, PC, R>(xr, cr, rt, 4 * i + e), acc);
+        return acc;
+    }
+}
+template <int NF, int CQ, int PC, int R, bool BX>
+__device__ __forceinline__ f4 gemm1_any(const f4 (&a1)[G1Dims<NF, CQ, BX>::NA], f4 b1, const float (&xr)[R][2 * NF],
+                                        const float (&cr)[R][CQ > 0 ? CQ : 1],
+                                        const f4 (*bin)[SplitDims<NF, CQ>::NI1], int rt) {
+    f4 acc = b1;
+#pragma unroll
+    for (int i = 0; i < G1Dims<NF, CQ, BX>::NA; ++i) acc = gemm1_step<NF, CQ, PC, R, BX>(a1, i, xr, cr, bin, rt, acc);
+    return acc;
+}
+
 // Tiles [tile0, tile0 + ntiles) of the packed layer feed out tiles OT0 .. OT0 + OTL - 1.
-template <int NF, int CQ, int R, int PC, int OT0, int ACT>
+template <int NF, int CQ, int R, int PC, int OT0, int ACT, bool BX = false>
 __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo &g, int lane, int tile0,
                                           int ntiles, const float (&xr)[R][2 * NF],
                                           const float (&cr)[R][CQ > 0 ? CQ : 1],
-                                          f4 (&out)[R][FwdDims<NF, CQ>::NT2]) {
+                                          f4 (&out)[R][FwdDims<NF, CQ>::NT2],
+                                          const f4 (*bin)[SplitDims<NF, CQ>::NI1] = nullptr) {
     using D = FwdDims<NF, CQ>;
-    constexpr int K4 = D::K4, OTL = D::OTL;
+    constexpr int K4 = G1Dims<NF, CQ, BX>::NA, OTL = D::OTL;
     const int q = lane >> 4;
-    const float *pA1 = W + g.oA1 + ((size_t)tile0 * K4 * 64 + lane) * 4;
+    const float *pA1 = W + (BX ? g.oA1S : g.oA1) + ((size_t)tile0 * K4 * 64 + lane) * 4;
     const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
     const float *pA2 = W + g.oA2 + ((size_t)tile0 * OTL * 64 + lane) * 4;
     const int last = ntiles - 1;
@@ -268,7 +315,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
         for (int k4 = 0; k4 < K4; ++k4) s0.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
         s0.b1n = *opaque(pB1 + t1 * 16);
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
+        for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1_any<NF, CQ, PC, R, BX>(a1c, b1c, xr, cr, bin, rt);
     }
     auto gemm2 = [&](const St &c, const f4 (&hv)[R]) {
 #pragma unroll
@@ -293,11 +340,18 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
         for (int r0 = 0; r0 < R; r0 += RB) {           // phase A: GEMM1 of tile t+1 || activation of tile t
 #pragma unroll
             for (int u = 0; u < RB; ++u) nx.acc[r0 + u] = c.b1n;
+            if constexpr (BX) {
 #pragma unroll
-            for (int kk = 0; kk < NF + CQ; ++kk)
+                for (int i = 0; i < K4; ++i)
 #pragma unroll
-                for (int u = 0; u < RB; ++u)
-                    nx.acc[r0 + u] = mfma16(c.a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), nx.acc[r0 + u]);
+                    for (int u = 0; u < RB; ++u) nx.acc[r0 + u] = mfma32(c.a1n[i], bin[r0 + u][i], nx.acc[r0 + u]);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NF + CQ; ++kk)
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        nx.acc[r0 + u] = mfma16(c.a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), nx.acc[r0 + u]);
+            }
 #pragma unroll
             for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
@@ -322,15 +376,15 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
 // GEMM1 accumulator register, as before) by 4 outputs (A, pre-packed per lane) for rows 4rg..4rg+3.
 // Partial sums over the lane groups q are combined once per layer by a two-step reduce-scatter.
 // Measured on MI355X: 8 x 4x4x1 take 37 ns against 58 ns for the 4 x 16x16x4 they replace.
-template <int CQ, int R, int PC, int NET, int ACT>
+template <int CQ, int R, int PC, int NET, int ACT, bool BX = false>
 __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const Geo &g, int lane, int tile0,
                                              int ntiles, const float (&xr)[R][4],
-                                             const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4]) {
+                                             const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4],
+                                             const f4 (*bin)[SplitDims<2, CQ>::NI1] = nullptr) {
     constexpr int NF = 2;
-    using D = FwdDims<NF, CQ>;
-    constexpr int K4 = D::K4;
+    constexpr int K4 = G1Dims<NF, CQ, BX>::NA;
     const int q = lane >> 4;
-    const float *pA1 = W + g.oA1 + ((size_t)tile0 * K4 * 64 + lane) * 4;
+    const float *pA1 = W + (BX ? g.oA1S : g.oA1) + ((size_t)tile0 * K4 * 64 + lane) * 4;
     const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
     const float *pA2 = W + g.oA2X + ((size_t)tile0 * 2 * 64 + lane) * 4;
     const int last = ntiles - 1;
@@ -348,7 +402,7 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
         for (int k4 = 0; k4 < K4; ++k4) s0.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
         s0.b1n = *opaque(pB1 + t1 * 16);
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1<NF, CQ, PC, R>(a1c, b1c, xr, cr, rt);
+        for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1_any<NF, CQ, PC, R, BX>(a1c, b1c, xr, cr, bin, rt);
     }
     auto gemm2 = [&](const St &c, const f4 (&hv)[R]) {     // 4x4x1 GEMM2, 2R independent chains
 #pragma unroll
@@ -373,11 +427,18 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
         for (int r0 = 0; r0 < R; r0 += RB) {           // phase A: GEMM1 of tile t+1 || activation of tile t
 #pragma unroll
             for (int u = 0; u < RB; ++u) nx.acc[r0 + u] = c.b1n;
+            if constexpr (BX) {
 #pragma unroll
-            for (int kk = 0; kk < NF + CQ; ++kk)
+                for (int i = 0; i < K4; ++i)
 #pragma unroll
-                for (int u = 0; u < RB; ++u)
-                    nx.acc[r0 + u] = mfma16(c.a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), nx.acc[r0 + u]);
+                    for (int u = 0; u < RB; ++u) nx.acc[r0 + u] = mfma32(c.a1n[i], bin[r0 + u][i], nx.acc[r0 + u]);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NF + CQ; ++kk)
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        nx.acc[r0 + u] = mfma16(c.a1n[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), nx.acc[r0 + u]);
+            }
 #pragma unroll
             for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
@@ -412,13 +473,15 @@ __device__ __forceinline__ void reduce_scatter_x4(const f4 (&part)[4], float (&t
 // MODE 0: forward (x*exp(s)+t, log-det)   realnvp.py:99-100
 // MODE 1: inverse ((x-t)*exp(-s))          realnvp.py:128
 // MODE 2: forward, also writing the layer input of the transformed features and exp(s) to scr
-template <int NF, int CQ, int R, int PC, int MODE, int ACT>
+template <int NF, int CQ, int R, int PC, int MODE, int ACT, bool BX = false>
 __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const Geo &g, int lane,
                                               float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                               float (&ld)[R], float *__restrict__ scr) {
     using D = FwdDims<NF, CQ>;
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4;
+    f4 bin[BX ? R : 1][SplitDims<NF, CQ>::NI1];
+    if constexpr (BX) build_bin<NF, CQ, PC, R>(xr, cr, bin);
     f4 out[R][NT2];
     const f4 bias2 = *reinterpret_cast<const f4 *>(W + g.oB2 + q * 4);      // out tile 0 (all of it when NF == 2)
     if constexpr (NF == 2 && kUseX4) {
@@ -427,8 +490,8 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
-        run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, outx);
-        run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+        run_tiles_x4<CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, outx, bin);
+        run_tiles_x4<CQ, R, PC, 1, ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, outx, bin);
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
             float tv[2], sv[2];
@@ -443,10 +506,10 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
         }
         if (NF >= 4) {      // each net feeds its own out tiles
-            run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, out);
-            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, out, bin);
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, out, bin);
         } else {            // t and s share one out tile: one pipelined pass over all 2*HT tiles
-            run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, 0, 2 * g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, 2 * g.HT, xr, cr, out, bin);
         }
     }
 #pragma unroll
@@ -476,7 +539,7 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ W, const
 // net each (role 0: t, role 1: s).  This wave runs the hidden tiles of its own net, reduces them to its net's
 // output for the features each lane owns, and swaps it with the partner wave through xown / xother in LDS
 // (one __syncthreads per layer; the caller double-buffers the records by layer parity).  MODE as layer_forward.
-template <int NF, int CQ, int R, int PC, int MODE, int ACT>
+template <int NF, int CQ, int R, int PC, int MODE, int ACT, bool BX = false>
 __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
                                                  float *xown, const float *xother, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
@@ -484,6 +547,8 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
     using D = FwdDims<NF, CQ>;
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4;
+    f4 bin[BX ? R : 1][SplitDims<NF, CQ>::NI1];
+    if constexpr (BX) build_bin<NF, CQ, PC, R>(xr, cr, bin);
     float own[R][NF];
     if constexpr (NF == 2 && kUseX4) {
         const f4 bias2 = *reinterpret_cast<const f4 *>(W + g.oB2 + q * 4);
@@ -493,7 +558,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (role == 0) {
-            run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, outx);
+            run_tiles_x4<CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, outx, bin);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -503,7 +568,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
                 own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[1];
             }
         } else {
-            run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT, g.HT, xr, cr, outx);
+            run_tiles_x4<CQ, R, PC, 1, ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, outx, bin);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -522,13 +587,13 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = b;
         }
         if (role == 0) {
-            run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, 0, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, out, bin);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) own[rt][f] = out[rt][f >> 2][f & 3];
         } else {
-            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT, g.HT, xr, cr, out);
+            run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, out, bin);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt)
 #pragma unroll

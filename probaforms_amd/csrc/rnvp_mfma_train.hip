@@ -63,6 +63,28 @@ struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2
 #ifndef RNVP_TRAIN_WAVES
 #define RNVP_TRAIN_WAVES 4
 #endif
+// RNVP_TRAIN_BX: the row-parallel training launches (every batch the tile-split kernel does not take) use the split-GEMM1
+// form k_mfma_train_bx
+#ifndef RNVP_TRAIN_BX
+#define RNVP_TRAIN_BX 0
+#endif
+constexpr bool kTrainBx = RNVP_TRAIN_BX != 0;
+// RNVP_W2C_NO_NS: the compact 4x4x1 form of dW2 (Dims::w2c) also where a wave runs both nets one after the other
+#ifndef RNVP_W2C_NO_NS
+#define RNVP_W2C_NO_NS 1
+#endif
+constexpr bool kW2cNoNs = RNVP_W2C_NO_NS != 0;
+#ifndef RNVP_TRAIN_BXF
+#define RNVP_TRAIN_BXF 1
+#endif
+constexpr bool kTrainBxF = RNVP_TRAIN_BXF != 0;
+// RNVP_TRAIN_BX_NS_FIRST: batches that give at most one workgroup per CU keep the net-split f32-backward kernel (two waves
+// per SIMD) and the one-wave split-GEMM1 form takes only the larger ones
+#ifndef RNVP_TRAIN_BX_NS_FIRST
+#define RNVP_TRAIN_BX_NS_FIRST 1
+#endif
+constexpr bool kTrainBxNsFirst = RNVP_TRAIN_BX_NS_FIRST != 0;
+constexpr bool kTrainSplit = kTrainBx || kTrainBxF;      // the packed block carries the split fragments
 constexpr int kWaves = RNVP_TRAIN_WAVES;    // waves per workgroup
 #ifndef RNVP_MAX_GRID_TRAIN
 #define RNVP_MAX_GRID_TRAIN 512
@@ -96,12 +118,14 @@ template <int NF, int CQ> struct Dims {
     // q are added by a permlane reduce-scatter once per hidden tile, and the tile's dW2 record shrinks from 256 to 128
     // floats (only this net's 16 x 8 entries).  g_out^T is read from a wave-private LDS image [row tile][row][GS]
     // (position 2j + cb holds column 4cb + j, so one ds_read_b64 feeds both column blocks) instead of registers.
-    template <int NS> static constexpr bool w2c() { return NF == 2 && NS == 1 && kUseX4; }
+    // NS == 0 (a wave runs net t, then net s): the same form with one g_out^T image per net (RNVP_W2C_NO_NS).
+    template <int NS> static constexpr bool w2c() { return NF == 2 && (NS == 1 || (NS == 0 && kW2cNoNs)) && kUseX4; }
+    template <int NS> static constexpr int gimg(int R) { return (NS == 0 ? 2 : 1) * R * 16 * GS; }      // floats of the image(s)
+    static constexpr int GS = 10;
     template <int NS> static constexpr int tblk() { return w2c<NS>() ? NTI * 256 + 128 : (NTI + OTL) * 256; }
     template <int NS> static constexpr int slot() { return FT * tblk<NS>() + NT2 * 16; }
-    static constexpr int GS = 10;
     template <int R, int NS> static constexpr int tbn() {
-        return (w2c<NS>() ? R * 16 * GS : NT2 * 16 * kTS) + 16 * SIN + 2 * (R >= 4 ? 2 : R) * 16 * kTS;
+        return (w2c<NS>() ? gimg<NS>(R) : NT2 * 16 * kTS) + 16 * SIN + 2 * (R >= 4 ? 2 : R) * 16 * kTS;
     }
 };
 
@@ -110,7 +134,7 @@ template <int NF, int CQ> struct Dims {
 // (role 0: t, role 1: s).  Each runs its own net's hidden tiles and accumulates its own net's weight
 // gradients; the two exchange only the net outputs (forward) and the input-gradient partial sums (here)
 // through xown / xother in LDS, once per layer.
-template <int NF, int CQ, int R, int PC, int NS, int ACT>
+template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
@@ -135,8 +159,16 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
     float *slot = lds + wave * SLOT;
     float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging); W2C: R x 16 x GS
-    float *bufI = tb + (W2C ? R * 16 * GS : NT2 * 16 * kTS);   // 16 x SIN
+    float *bufI = tb + (W2C ? D::template gimg<NS>(R) : NT2 * 16 * kTS);   // 16 x SIN
     float *bufH = bufI + 16 * SIN;                        // 2R tiles of 16 x kTS: (h, g_pre) per row tile
+    // BX: GEMM1 (recompute) and g_h = W2^T g_out on split-bf16 MFMA (rnvp_split.h).  Their B operands are split once per
+    // layer and row tile: `bin` from the conditioning features and conditions (the layer leaves them unchanged, so the
+    // registers restored below are not needed for it), `gob` from g_out of each net (NS: this wave's net only).
+    constexpr int NI1 = SplitDims<NF, CQ>::NI1, NI2 = SplitDims<NF, CQ>::NI2;
+    constexpr int NA1 = BX ? NI1 : K4, NA2 = BX ? NI2 : OTL;      // f4 fragments per tile of GEMM1 / of W2^T
+    constexpr int NGB = NS ? 1 : 2;
+    f4 bin[BX ? R : 1][NI1], gob[BX ? R : 1][NGB][NI2];
+    if constexpr (BX) build_bin<NF, CQ, PC, R>(xr, cr, bin);
 
     // 1. restore the layer input, form g_out = [g_t | g_s] and the gradient of the pass-through part
     f4 go[R][NT2];
@@ -163,11 +195,32 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
         for (int rt = 1; rt < R; ++rt) gb2[ot] += go[rt][ot];
     }
+    if constexpr (BX) {
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < NGB; ++nb) {
+                float v[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    float vt, vs;
+                    if (NF >= 4) { vt = go[rt][f >> 2][f & 3]; vs = go[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
+                    else { vt = go[rt][0][f & 1]; vs = go[rt][0][2 + (f & 1)]; }
+                    v[f] = NS ? (role ? vs : vt) : (nb ? vs : vt);
+                }
+                split::build_b<NF>(v, gob[rt][nb]);
+            }
+    }
     // 2. row-contraction operands: g_out^T and [in | 1]^T through the wave's LDS tiles
     float goT[R][NT2][4], inT[R][NTI][4];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
-        if constexpr (W2C) {        // this wave's net only: columns 2q, 2q+1 of row r, at positions 2j + cb (Dims)
+        if constexpr (W2C && NS == 0) {      // one image per net
+            float *gp = bufG + (rt * 16 + r) * GS + 4 * (q & 1) + (q >> 1);
+            wave_lds_fence();
+            gp[0] = go[rt][0][0]; gp[2] = go[rt][0][1];
+            gp[R * 16 * GS] = go[rt][0][2]; gp[R * 16 * GS + 2] = go[rt][0][3];
+        } else if constexpr (W2C) {        // this wave's net only: columns 2q, 2q+1 of row r, at positions 2j + cb (Dims)
             const float v0 = role ? go[rt][0][2] : go[rt][0][0], v1 = role ? go[rt][0][3] : go[rt][0][1];
             float *gp = bufG + (rt * 16 + r) * GS + 4 * (q & 1) + (q >> 1);
             wave_lds_fence();
@@ -210,26 +263,26 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     //    fragments of the next tile are in flight for a whole iteration.
     auto net_pass = [&](auto net_c) {
         constexpr int net = decltype(net_c)::value;
-        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
+        const float *pA1 = W + (BX ? g.oA1S : g.oA1) + ((size_t)net * HT * NA1 * 64 + lane) * 4;
         const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
-        const float *pA2T = W + g.oA2T + ((size_t)net * HT * OTL * 64 + lane) * 4;
+        const float *pA2T = W + (BX ? g.oA2TS : g.oA2T) + ((size_t)net * HT * NA2 * 64 + lane) * 4;
         const float *pA1T = W + (X4 ? g.oA1X : g.oA1T) + ((size_t)net * HT * NGI * 64 + lane) * 4;
-        f4 a1[K4], a2t[OTL], a1t[NGI], b1;
+        f4 a1[NA1], a2t[NA2], a1t[NGI], b1;
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)ht_lo * K4 + k4) * 256);
+        for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)ht_lo * NA1 + k4) * 256);
         b1 = *reinterpret_cast<const f4 *>(pB1 + ht_lo * 16);
 #pragma unroll
-        for (int o = 0; o < OTL; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)ht_lo * OTL + o) * 256);
+        for (int o = 0; o < NA2; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)ht_lo * NA2 + o) * 256);
 #pragma unroll
         for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)ht_lo * NGI + m) * 256);
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
-            f4 na1[K4], na2t[OTL], na1t[NGI], nb1;
+            f4 na1[NA1], na2t[NA2], na1t[NGI], nb1;
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
+            for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * NA1 + k4) * 256);
             nb1 = *opaque(pB1 + nx * 16);
 #pragma unroll
-            for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
+            for (int o = 0; o < NA2; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * NA2 + o) * 256);
 #pragma unroll
             for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
             BWD_SCHED_BARRIER();
@@ -248,6 +301,16 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 f4 acc[RH], gh[RH];
 #pragma unroll
                 for (int u = 0; u < RH; ++u) { acc[u] = b1; gh[u] = f4{0.f, 0.f, 0.f, 0.f}; }
+                if constexpr (BX) {
+#pragma unroll
+                    for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                        for (int u = 0; u < RH; ++u) acc[u] = mfma32(a1[i], bin[r0 + u][i], acc[u]);
+#pragma unroll
+                    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+                        for (int u = 0; u < RH; ++u) gh[u] = mfma32(a2t[i], gob[r0 + u][NS ? 0 : net][i], gh[u]);
+                } else {
 #pragma unroll
                 for (int kk = 0; kk < KS1; ++kk)
 #pragma unroll
@@ -267,6 +330,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                         for (int u = 0; u < RH; ++u)
                             gh[u] = mfma16(a2t[0][2 * net + v], go[r0 + u][0][2 * net + v], gh[u]);
+                }
                 }
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p1, t0);
@@ -320,7 +384,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
                         }
                         if constexpr (W2C)
-                            gB[u][ks] = *reinterpret_cast<const float2 *>(bufG + ((r0 + u) * 16 + 4 * ks + q) * GS + 2 * (r & 3));
+                            gB[u][ks] = *reinterpret_cast<const float2 *>(bufG + (NS == 0 ? net * R * 16 * GS : 0) +
+                                                                          ((r0 + u) * 16 + 4 * ks + q) * GS + 2 * (r & 3));
                     }
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p3, t0);
@@ -448,10 +513,10 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.bflush, t0);
             }
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
+            for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = na1[k4];
             b1 = nb1;
 #pragma unroll
-            for (int o = 0; o < OTL; ++o) a2t[o] = na2t[o];
+            for (int o = 0; o < NA2; ++o) a2t[o] = na2t[o];
 #pragma unroll
             for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
         }
@@ -530,12 +595,11 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     STAMP_ADD(stp.btail, t0);
 }
 
-template <int NF, int CQ, int R, int NS, int ACT>
-__global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
-k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+template <int NF, int CQ, int R, int NS, int ACT, bool BX, bool BXF = BX>
+__device__ __forceinline__ void train_body(const float *__restrict__ wp, const Geo &g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
-             float *gpart, float *losspart, float *scratch, int glayer_floats, const float *__restrict__ gz) {
-    // gz != nullptr (a prior other than N(0, I), rnvp_loss_grad_zseed): the backward is seeded with the caller's
+             float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
+    // sd.gz != nullptr (a prior other than N(0, I), rnvp_loss_grad_zseed): the backward is seeded with the caller's
     // d loss / d z rows and the loss partial carries the log-det term only
     using DM = Dims<NF, CQ>;
     constexpr int D = 8 * NF, CD = 4 * CQ;
@@ -578,11 +642,11 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
-                else layer_forward_ns<NF, CQ, R, 0, 2, ACT>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
             } else {
-                if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT>(W, g, lane, xr, cr, ld, scr);
-                else layer_forward<NF, CQ, R, 0, 2, ACT>(W, g, lane, xr, cr, ld, scr);
+                if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
+                else layer_forward<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
             }
         }
         if constexpr (NS) __syncthreads();      // the pair's scratch records (written half by each wave) and the exchange buffers
@@ -594,24 +658,24 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             float l1 = ld[rt];
             l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
             ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-            const float lp = gz ? l1 : l1 + (-0.5f * ss - prior_c);
+            const float lp = sd.gz ? l1 : l1 + (-0.5f * ss - prior_c);
             float v = (valid[rt] && q == 0) ? lp : 0.f;
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
             wave_sum += v;
             // seed of the backward: d(-mean logp)/dz = z / B; padding rows contribute nothing
             const float sc = valid[rt] ? inv_B : 0.f;
-            if (gz) {
+            if (sd.gz) {
                 const int64_t row = base + rt * 16 + r;
 #pragma unroll
                 for (int u = 0; u < 2 * NF; ++u) {
                     const int j = q * 2 * NF + u;
-                    gy[rt][u] = (valid[rt] && j < g.d) ? gz[row * g.d + j] : 0.f;
+                    gy[rt][u] = (valid[rt] && j < g.d) ? sd.gz[row * g.d + j] : 0.f;
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
             }
-            gld[rt] = -sc;
+            gld[rt] = sd.gld ? (valid[rt] ? sd.gld[base + rt * 16 + r] : 0.f) : -sc;       // rnvp_backward: the caller's d loss / d logdet
         }
         STAMP_ADD(stp.fwd, t0);
         for (int l = L - 1; l >= 0 && !(kAblate & 16); --l) {
@@ -621,8 +685,14 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
             float *xb = xbuf + (size_t)(l & 1) * NW * XW;
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ kWaves) * XW : nullptr;
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+        }
+        if (sd.gx && role == 0) {               // rnvp_backward: d loss / d x of the batch rows (gy after the first layer's backward)
+            const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt)
+                if (valid[rt]) store_row<NF>(sd.gx, base + rt * 16 + r, g.d, fullg, q, gy[rt]);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
@@ -636,6 +706,35 @@ k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *_
                    (int)blockIdx.x, wave, tk1 - tk0, stp.ld, stp.fwd, stp.bsetup, stp.p1, stp.p2, stp.p3, stp.p4, stp.p5, stp.fb1, stp.fsum, stp.bflush, stp.btail);
     }
 #endif
+}
+
+template <int NF, int CQ, int R, int NS, int ACT>
+__global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+             const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
+             float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
+    // RNVP_TRAIN_BXF: GEMM1 of the FORWARD phase on split-bf16 MFMA (the backward keeps f32: its split operands do not fit
+    // in 256 registers next to the gradient state)
+    // measured (whole call, 65536 rows): C2 -1.5 %, C3 -2 %, C4 (NF = 8) +2 %: the wide geometry keeps f32
+    train_body<NF, CQ, R, NS, ACT, false, kTrainBxF && NF <= 4>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
+}
+
+// Split-GEMM1 form (BX, rnvp_split.h): GEMM1 of the forward phase, its recompute in the backward and g_h = W2^T g_out run on
+// v_mfma_f32_16x16x32_bf16 with three-term bf16 operands -- the products whose B operand is NOT a fresh activation (the
+// layer's inputs and g_out are split once per layer and row tile); GEMM2, the input gradient and the weight gradients keep
+// the f32 forms, because splitting a fresh tanh output costs the VALU more than the matrix pipe saves
+// (scripts/micro/unit_mix.hip, profiles/r03_micro_overlap.txt).  The split operands need 15-32 more registers per row tile,
+// so this form runs ONE wave per SIMD with the whole 512-entry register file (RNVP_BX_WPE 1): four waves per workgroup,
+// each with both nets of its R row tiles (no net split, no exchange through LDS).
+#ifndef RNVP_BX_WPE
+#define RNVP_BX_WPE 1
+#endif
+template <int NF, int CQ, int R, int ACT>
+__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_BX_WPE, RNVP_BX_WPE)))
+k_mfma_train_bx(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+                const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
+                float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
+    train_body<NF, CQ, R, 0, ACT, true>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
 }
 
 
@@ -654,7 +753,7 @@ template <int NF, int CQ, int R, int ACT>
 __global__ void __launch_bounds__(kTsWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
                 const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
-                float *gpart, float *losspart, float *scratch, int glayer_floats, const float *__restrict__ gz) {
+                float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
     using DM = Dims<NF, CQ>;
     constexpr int D = 8 * NF, CD = 4 * CQ;
     constexpr int XW = R * NF * 64, TBN = DM::template tbn<R, 0>();
@@ -700,23 +799,23 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         float l1 = ld[rt];
         l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
         ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-        const float lp = gz ? l1 : l1 + (-0.5f * ss - prior_c);
+        const float lp = sd.gz ? l1 : l1 + (-0.5f * ss - prior_c);
         float v = (valid[rt] && q == 0) ? lp : 0.f;
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
         wave_sum += v;
         const float sc = valid[rt] ? inv_B : 0.f;
-        if (gz) {
+        if (sd.gz) {
             const int64_t row = row0 + rt * 16 + r;
 #pragma unroll
             for (int u = 0; u < 2 * NF; ++u) {
                 const int j = q * 2 * NF + u;
-                gy[rt][u] = (valid[rt] && j < g.d) ? gz[row * g.d + j] : 0.f;
+                gy[rt][u] = (valid[rt] && j < g.d) ? sd.gz[row * g.d + j] : 0.f;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
         }
-        gld[rt] = -sc;
+        gld[rt] = sd.gld ? (valid[rt] ? sd.gld[row0 + rt * 16 + r] : 0.f) : -sc;
     }
     for (int l = L - 1; l >= 0; --l) {
         const float *W = wp + (size_t)l * g.layer_floats;
@@ -725,6 +824,12 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
         if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
         else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
+    }
+    if (sd.gx && wave == 0) {                   // rnvp_backward: d loss / d x (every wave holds the same sums)
+        const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+            if (valid[rt]) store_row<NF>(sd.gx, row0 + rt * 16 + r, g.d, fullg, q, gy[rt]);
     }
     // the loss: every wave computed the same sum; k_mfma_reduce adds kWaves partials per workgroup
     if (lane == 0 && wave < kWaves) losspart[blockIdx.x * kWaves + wave] = wave == 0 ? wave_sum : 0.f;
@@ -877,7 +982,7 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
 template <int NF, int CQ, int R, int NS, int ACT>
 int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                    float *losspart, float *scratch, int grid, size_t lds_bytes, const float *gz) {
+                    float *losspart, float *scratch, int grid, size_t lds_bytes, Seeds sd) {
     auto kern = k_mfma_train<NF, CQ, R, NS, ACT>;
     static std::atomic<uint64_t> attr_done{0};          // per kernel instance; one bit per device
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
@@ -885,7 +990,7 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
     {
         const KernelEvents ev(RNVP_PROFILE_TRAIN);      // rnvp_profile_*: this launch's own start / stop stamps when enabled
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, ev.start, ev.stop, 0, packed, g,
-                              k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
+                              k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -894,12 +999,12 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
 template <int NF, int CQ, int R, int NS>
 int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                    float *losspart, float *scratch, int grid, size_t lds_bytes, const float *gz) {
+                    float *losspart, float *scratch, int grid, size_t lds_bytes, Seeds sd) {
     if (k.act == RNVP_ACT_TANH)
         return launch_train_act<NF, CQ, R, NS, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
-                                                  grid, lds_bytes, gz);
+                                                  grid, lds_bytes, sd);
     return launch_train_act<NF, CQ, R, NS, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                              lds_bytes, gz);
+                                              lds_bytes, sd);
 }
 
 #ifndef RNVP_NET_SPLIT
@@ -915,7 +1020,7 @@ int launch_train_ns(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 template <int NF, int CQ, int R>
 int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
                     const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
-                    float *scratch, const float *gz, int grid) {
+                    float *scratch, Seeds sd, int grid) {
     using DM = Dims<NF, CQ>;
     const size_t lds_bytes = ((size_t)kTsWaves * DM::template tbn<R, 0>() + 2 * (size_t)kTsWaves * R * NF * 64) * sizeof(float);
     static std::atomic<uint64_t> attr_done[2] = {{0}, {0}};
@@ -926,10 +1031,10 @@ int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
     const KernelEvents ev(RNVP_PROFILE_TRAIN);
     if (k.act == RNVP_ACT_TANH)
         hipExtLaunchKernelGGL((k_mfma_train_ts<NF, CQ, R, 0>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
-                              packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
+                              packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
     else
         hipExtLaunchKernelGGL((k_mfma_train_ts<NF, CQ, R, 1>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
-                              packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, gz);
+                              packed, g, k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }
@@ -937,16 +1042,44 @@ int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 // layout of the partials a launch wrote (the net-split launches of d <= 16 use the compact dW2 records)
 struct PartialLayout { int glayer_floats, w2c; };
 
+template <int NF, int CQ, int R, int ACT>
+int launch_train_bx(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
+                    const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
+                    float *scratch, int grid, size_t lds_bytes, Seeds sd) {
+    auto kern = k_mfma_train_bx<NF, CQ, R, ACT>;
+    static std::atomic<uint64_t> attr_done{0};
+    const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
+    if (arc) return arc;
+    {
+        const KernelEvents ev(RNVP_PROFILE_TRAIN);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt, x,
+                              c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
 template <int NF, int CQ, int R>
 int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                    const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                   float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
+                   float *losspart, float *scratch, int *grid_out, Seeds sd, PartialLayout *lay) {
     using DM = Dims<NF, CQ>;
     const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const int grid = (int)(ngroups < kMaxGridTrain ? ngroups : kMaxGridTrain);
     *grid_out = grid;
-    const size_t per_wave = (size_t)DM::SLOT + DM::template tb<R>();
+    const size_t per_wave = (size_t)DM::template slot<0>() + DM::template tbn<R, 0>();
+    TrainPlan p0 = pl;                                   // partial layout of the launches without net split
+    p0.glayer_floats = 2 * g.HT * DM::template tblk<0>() + DM::NT2 * 16;
+    if (kTrainBx && g.NI1 > 0 && !(RNVP_NET_SPLIT && kTrainBxNsFirst && ngroups <= 256)) {          // split-GEMM1 form (the packed block carries its fragments)
+        lay->w2c = DM::template w2c<0>() ? 1 : 0;
+        lay->glayer_floats = p0.glayer_floats;
+        if (k.act == RNVP_ACT_TANH)
+            return launch_train_bx<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
+                                                 kWaves * per_wave * sizeof(float), sd);
+        return launch_train_bx<NF, CQ, R, 1>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
+                                             kWaves * per_wave * sizeof(float), sd);
+    }
     const size_t per_wave_ns = (size_t)DM::template slot<1>() + DM::template tbn<R, 1>();
     // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
     // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
@@ -957,18 +1090,18 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
         TrainPlan pn = pl;
         pn.glayer_floats = lay->glayer_floats;
         return launch_train_ns<NF, CQ, R, 1>(st, k, g, pn, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
-                                             grid, lds_ns, gz);
+                                             grid, lds_ns, sd);
     }
-    lay->w2c = 0;
-    lay->glayer_floats = pl.glayer_floats;
-    return launch_train_ns<NF, CQ, R, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                         kWaves * per_wave * sizeof(float), gz);
+    lay->w2c = DM::template w2c<0>() ? 1 : 0;
+    lay->glayer_floats = p0.glayer_floats;
+    return launch_train_ns<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
+                                         kWaves * per_wave * sizeof(float), sd);
 }
 
 template <int NF, int CQ>
 int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                  const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
-                 float *losspart, float *scratch, int *grid_out, const float *gz, PartialLayout *lay) {
+                 float *losspart, float *scratch, int *grid_out, Seeds sd, PartialLayout *lay) {
     constexpr int RMAX = TrainRows<NF, CQ>::value;
     if constexpr (RNVP_TILE_SPLIT) {
         // d <= 16: one workgroup per 16 rows up to 4096 rows, per 32 rows up to 8192 (numbers above k_mfma_train_ts); wider
@@ -982,9 +1115,9 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
             lay->glayer_floats = pl.glayer_floats;
             *grid_out = grid;
             if constexpr (NF == 2) {
-                if (R == 2) return launch_train_ts<NF, CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
+                if (R == 2) return launch_train_ts<NF, CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, sd, grid);
             }
-            return launch_train_ts<NF, CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gz, grid);
+            return launch_train_ts<NF, CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, sd, grid);
         }
     }
     const int R = pick_rows(RMAX, n);
@@ -992,7 +1125,7 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
     if constexpr (RMAX >= r) {                                                                                    \
         if (R == r)                                                                                               \
             return launch_train_r<NF, CQ, r>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, \
-                                             grid_out, gz, lay);                                                  \
+                                             grid_out, sd, lay);                                                  \
     }
     RNVP_ROWS(4) RNVP_ROWS(2) RNVP_ROWS(1)
 #undef RNVP_ROWS
@@ -1003,7 +1136,7 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
 
 bool train_supported(const KShape &k) {
     if (!supported(k)) return false;
-    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return false;
     return pl.lds_bytes <= 160 * 1024;
@@ -1011,7 +1144,7 @@ bool train_supported(const KShape &k) {
 
 size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
     (void)max_rows;
-    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return 0;
     size_t b = align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);                    // packed weights
@@ -1025,9 +1158,9 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
 static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
                           const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
                           void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam,
-                          const float *gz = nullptr) {
+                          Seeds sd = Seeds{}) {
     if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
-    const Geo g = make_geo(k.d, k.c, k.nout[0]);
+    const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return RNVP_EUNSUPPORTED;
     char *w = static_cast<char *>(ws);
@@ -1044,10 +1177,10 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     if (rc) return rc;
     int grid = 0;
     PartialLayout lay{pl.glayer_floats, 0};
-    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
-    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
-    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
-    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, gz, &lay);
+    if (g.NF == 2 && g.CQ == 1) rc = launch_train<2, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, sd, &lay);
+    else if (g.NF == 2 && g.CQ == 0) rc = launch_train<2, 0>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, sd, &lay);
+    else if (g.NF == 4 && g.CQ == 2) rc = launch_train<4, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, sd, &lay);
+    else if (g.NF == 8 && g.CQ == 4) rc = launch_train<8, 4>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, sd, &lay);
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
     const size_t P = (size_t)2 * k.npn * k.L;
@@ -1071,9 +1204,9 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes, const float *gz) {
+              void *ws, size_t ws_bytes, Seeds sd) {
     return loss_grad_impl(st, k, params, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, nullptr,
-                          nullptr, nullptr, AdamK{}, gz);
+                          nullptr, nullptr, AdamK{}, sd);
 }
 
 // loss + gradient + Adam with the optimizer fused into the final scatter kernel (one launch and one

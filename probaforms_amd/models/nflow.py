@@ -90,7 +90,9 @@ def row_chunks(n, rows):
 class NormalizingFlow(nn.Module):
     """Layers + prior (nflow.py:71-145).
 
-    log_prob(X, C) -> 0-dim tensor: mean over the batch of [sum_l log_det_l + prior.log_prob(z)].
+    log_prob(X, C) -> 0-dim tensor: mean over the batch of [sum_l log_det_l + prior.log_prob(z)]; differentiable like the
+                      reference's (`(-nf.log_prob(X, C)).backward()` fills p.grad through the HIP backward, rnvp_backward),
+                      unless called under torch.no_grad().
     sample(C)      -> [n, var_size]: prior draw pushed through the layers' inverses, last layer first.
     log_prob_samples(X, C) -> [n] per-row log-density (build-only addition).
     """
@@ -153,10 +155,28 @@ class NormalizingFlow(nn.Module):
             return None
         return torch.as_tensor(t, dtype=torch.float32).to(eng.device).contiguous()
 
+    def _wants_graph(self, X):
+        """as in the reference, log_prob / log_prob_samples carry an autograd graph whenever one can be recorded: grad mode
+        on and a parameter (or X) requiring grad.  Under torch.no_grad() -- or with frozen parameters -- the fused
+        no-graph kernel runs instead (prior folded in, nothing saved for a backward)."""
+        if not torch.is_grad_enabled():
+            return False
+        return (torch.is_tensor(X) and X.requires_grad) or any(p.requires_grad for p in self.parameters())
+
+    def _log_prob_graph(self, X, C):
+        """per-row log-density with a graph: (z, logdet) from the FlowFunction node (forward = the fused stack, backward
+        = rnvp_backward), the prior's log_prob from torch -- any differentiable prior object works (nflow.py:115)"""
+        eng = self.engine()
+        Xd = X.to(eng.device, torch.float32) if torch.is_tensor(X) else self._on_device(X, eng)
+        z, ld = eng.forward_autograd(Xd.contiguous(), self._on_device(C, eng))
+        return ld + self.prior.log_prob(z)
+
     # -- reference API -------------------------------------------------------------------------
     def log_prob(self, X, C):
         if self._layerwise():
             return self._layerwise_forward(X, C).mean()
+        if self._wants_graph(X):
+            return self._log_prob_graph(X, C).mean()
         eng = self.engine()
         X, C = self._on_device(X, eng), self._on_device(C, eng)
         if self._fused_prior():
@@ -168,6 +188,8 @@ class NormalizingFlow(nn.Module):
     def log_prob_samples(self, X, C=None):
         if self._layerwise():
             return self._layerwise_forward(X, C)
+        if self._wants_graph(X):
+            return self._log_prob_graph(X, C)
         eng = self.engine()
         X, C = self._on_device(X, eng), self._on_device(C, eng)
         if self._fused_prior():

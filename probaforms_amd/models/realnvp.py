@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from .._engine import (FlatAdam, PermutationPrefetcher, broadcast_, default_device, dist_info, fit_epochs,
+from .._engine import (FlatAdam, FlowFunction, PermutationPrefetcher, broadcast_, default_device, dist_info, fit_epochs,
                        flatten_parameters, shard_bounds, is_flat, require_hip)
 from .interfaces import GenModel
 from .nflow import InvertibleLayer, NormalizingFlow, StandardNormalPrior
@@ -44,6 +44,19 @@ def gen_network(n_inputs, n_outputs, hidden=(10,), activation='tanh'):
     return net
 
 
+class _LayerView:
+    """what FlowFunction needs of an engine, for ONE layer evaluated on its own (shape with L = 1)"""
+
+    def __init__(self, layer, shape, mask, params, device):
+        self.shape, self.masks, self.params, self.flat = shape, mask, params, params
+        self.param_list = list(layer.parameters())
+        self.P = params.numel()
+        self.device = device
+
+    def workspace(self, op, rows):
+        return RealNVPLayer._ws(self.shape, self.device, op, max(int(rows), 1))
+
+
 class RealNVPLayer(InvertibleLayer):
     """One affine coupling layer (realnvp.py:47-129).
 
@@ -52,8 +65,9 @@ class RealNVPLayer(InvertibleLayer):
       g:  X_new = ((X - T)*exp(-S))*(1-m) + X*m
     `mask` is a {0,1} tensor of length var_size kept as a plain attribute (not in state_dict).
     `f`/`g` run the HIP kernels on this layer alone; inside a NormalizingFlow the whole stack
-    is fused instead.  The outputs carry no autograd graph: training goes through the fused
-    loss/gradient kernel (RealNVP.fit).
+    is fused instead.  `f` is differentiable like the reference's (one autograd node whose backward
+    is the HIP backward, rnvp_backward with L = 1) whenever grad mode is on and a parameter or X
+    requires grad; `g` returns a tensor without a graph (sampling: the reference never differentiates it).
     """
 
     def __init__(self, var_size, cond_size, mask, hidden=(10,), activation='tanh'):
@@ -103,6 +117,13 @@ class RealNVPLayer(InvertibleLayer):
         return dev, X, C, shape, mask, self._layer_params(dev)[:P]
 
     def f(self, X, C=None):
+        wants_graph = torch.is_grad_enabled() and ((torch.is_tensor(X) and X.requires_grad) or
+                                                   any(p.requires_grad for p in self.parameters()))
+        if wants_graph:
+            Xg = X if torch.is_tensor(X) else torch.as_tensor(X, dtype=torch.float32)
+            dev, _, C, shape, mask, params = self._prep(Xg.detach(), C)
+            view = _LayerView(self, shape, mask, params, dev)
+            return FlowFunction.apply(view, Xg.to(dev, torch.float32).contiguous(), C, *view.param_list)
         dev, X, C, shape, mask, params = self._prep(X, C)
         n = X.shape[0]
         X_new = torch.empty_like(X)
@@ -206,10 +227,19 @@ class RealNVP(GenModel):
             from tqdm.auto import tqdm
             bar = tqdm(total=self.n_epochs, unit='epoch')
 
-        def hook(epoch, last_loss):
-            if bar is not None:
-                bar.update(1)
-                bar.set_description("loss: %.4f" % last_loss)
+        def hook(epoch, losses):
+            """progress text of realnvp.py:256-262, from the epoch's loss vector (read back once per epoch, one epoch
+            behind the GPU): verbose == 1 shows the epoch's last batch; verbose >= 2 walks the batches i with
+            i % display_delta == 0 exactly like the reference's inner loop, so the bar ends the epoch on the same text"""
+            if bar is None:
+                return
+            bar.update(1)
+            if self.verbose >= 2:
+                display_delta = max(1, (len(X) // self.batch_size) // self.verbose)
+                for i in range(0, losses.numel(), display_delta):
+                    bar.set_description("loss: %.4f" % float(losses[i]))
+            else:
+                bar.set_description("loss: %.4f" % float(losses[-1]))
 
         fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook, prior=prior, perms=perms)
         if bar is not None:

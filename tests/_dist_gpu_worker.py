@@ -52,6 +52,15 @@ def main():
     cg = [torch.empty_like(cflat) for _ in range(world)]
     dist.all_gather(cg, cflat)
     csame = all(torch.equal(cg[0], g) for g in cg)
+    # the reference's C2 fit at its default batch size (tests/golden/c2_fit.npz), two ranks: 16 rows per rank per step
+    f = np.load(os.path.join(ROOT, "tests", "golden", "c2_fit.npz"))
+    torch.manual_seed(0 if rank == 0 else 77 + rank)
+    m2 = RealNVP(n_layers=8, hidden=(128,), lr=0.001, n_epochs=2)
+    m2.fit(f["X"], f["C"])
+    c2_hist = np.array([float(v) for v in m2.loss_history])
+    c2_flat = m2.nf.engine().flat.detach().cpu().numpy()
+    if rank == 0:
+        np.savez(out + ".c2fit.npz", hist=c2_hist, flat=c2_flat)
     if rank == 0:
         np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs,
                  cvae_flat=cflat.cpu().numpy(), cvae_hist=np.array([float(v) for v in cv.loss_history]), cvae_same=csame)

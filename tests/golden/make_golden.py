@@ -196,6 +196,25 @@ def make_moons_fit():
     print("G7", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def make_c2_fit():
+    """G7 on the C2 architecture at the reference's DEFAULT batch size (realnvp.py:161, 237-254): d=16, c=4, L=8,
+    hidden=(128,), n=256 rows, batch_size=32, 2 epochs = 16 steps.  Pins, end to end against the reference, the kernels
+    that serve small batches of a wide flow (three or more hidden tiles per net)."""
+    rng = np.random.default_rng(42)
+    X = rng.normal(size=(256, 16)); C = rng.normal(size=(256, 4))
+    out = {"X": X, "C": C}
+    torch.manual_seed(0)
+    m = RealNVP(n_layers=8, hidden=(128,), lr=0.001, n_epochs=2)          # batch_size = 32: the default
+    m.fit(X, C)
+    out["loss_history"] = np.array([float(v) for v in m.loss_history], np.float32)
+    out["params_after"] = flat(m.nf)
+    out["sample"] = m.sample(C)
+    with torch.no_grad():
+        out["logp_after"] = per_sample_logp(m.nf, torch.tensor(X, dtype=torch.float32), torch.tensor(C, dtype=torch.float32))[3]
+    np.savez_compressed(os.path.join(HERE, "c2_fit.npz"), **out)
+    print("G7/c2", {k: getattr(v, "shape", None) for k, v in out.items()}, out["loss_history"][:4], out["loss_history"][-2:])
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name in CASES:
@@ -203,3 +222,5 @@ if __name__ == "__main__":
             make_case(name)
     if not only:
         make_loader_indices(); make_prior_samples(); make_moons_fit()
+    if not only or "c2_fit" in only:
+        make_c2_fit()

@@ -96,6 +96,31 @@ def test_seeded_fit_matches_reference(L):
     assert len(m.loss_history) == int(f["L%d_loss_history_len_after_refit" % L])
 
 
+def test_seeded_fit_of_the_c2_flow_at_the_default_batch_size_matches_reference():
+    """tests/golden/c2_fit.npz: the reference's own RealNVP(n_layers=8, hidden=(128,), lr=1e-3, n_epochs=2).fit on 256
+    rows at its default batch_size=32 (realnvp.py:161,237-254) -- 16 steps served by the small-batch (tile-split)
+    training kernel: same init, same shuffles; loss history, trained parameters, per-row log-prob and samples"""
+    from probaforms_amd import _hip
+    from probaforms_amd.models import RealNVP
+    f = np.load(os.path.join(GOLDEN, "c2_fit.npz"))
+    X, C = f["X"], f["C"]
+    torch.manual_seed(0)
+    m = RealNVP(n_layers=8, hidden=(128,), lr=0.001, n_epochs=2)
+    m.fit(X, C)
+    assert _hip.kernel_path(m.nf.engine().shape, m.nf.engine().masks_host, _hip.OP_TRAIN) == _hip.PATH_MFMA
+    hist = np.array([float(v) for v in m.loss_history], np.float32)
+    ref = f["loss_history"]
+    assert hist.shape == ref.shape == (16,)
+    np.testing.assert_allclose(hist[:4], ref[:4], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(hist, ref, rtol=1e-3, atol=1e-3)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.nf.parameters()]).cpu().numpy()
+    assert np.abs(flat - f["params_after"]).max() < 2e-3 and np.abs(flat - f["params_after"]).mean() < 1e-4
+    lp = m.nf.log_prob_samples(X.astype(np.float32), C.astype(np.float32)).detach().cpu().numpy()
+    assert np.abs(lp - f["logp_after"]).mean() < 2e-2                  # 16 Adam steps of drift on |log p| ~ 25
+    xs = m.sample(C)                                                   # the reference's randn(256, 16) stream
+    assert xs.shape == (256, 16) and np.abs(xs - f["sample"]).mean() < 5e-3
+
+
 @pytest.mark.parametrize("name", ["c1_L8", "tm", "tm_nocond", "reg1d", "relu_mh", "relu_sh", "c2"])
 def test_load_reference_weights_and_compare_logprob(name):
     """weights travel through state_dict-shaped tensors; per-row log-prob and samples equal the reference's"""
@@ -108,19 +133,20 @@ def test_load_reference_weights_and_compare_logprob(name):
     for k, v in sd.items():
         new[k] = torch.from_numpy(cs["params"][off:off + v.numel()].copy()).view_as(v); off += v.numel()
     nf.load_state_dict(new)
-    lp = nf.log_prob_samples(cs["X"], cs["C"]).cpu().numpy()
+    lp = nf.log_prob_samples(cs["X"], cs["C"]).detach().cpu().numpy()
     assert np.abs(lp - g["G2_logp"]).mean() < logp_mae_tol(name)
     mean = float(nf.log_prob(torch.from_numpy(cs["X"]), None if cs["C"] is None else torch.from_numpy(cs["C"])))
     assert abs(mean - float(g["G2_mean"])) < logp_mae_tol(name)
     # layer-level API: RealNVPLayer.f / .g on one layer
     y, ld = nf.layers[0].f(torch.from_numpy(cs["X"]), None if cs["C"] is None else torch.from_numpy(cs["C"]))
-    np.testing.assert_allclose(y.cpu().numpy(), g["G2_layer_out"][0], rtol=2e-6, atol=2e-6)
-    np.testing.assert_allclose(ld.cpu().numpy(), g["G2_layer_ld"][0], rtol=2e-6, atol=2e-6)
+    assert y.grad_fn is not None and ld.grad_fn is not None          # a graph node, like the reference's layer.f
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["G2_layer_out"][0], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ld.detach().cpu().numpy(), g["G2_layer_ld"][0], rtol=2e-6, atol=2e-6)
     xg = nf.layers[-1].g(torch.from_numpy(cs["Z"]), None if cs["C"] is None else torch.from_numpy(cs["C"]))
     np.testing.assert_allclose(xg.cpu().numpy(), g["G3_layer_out"][0], rtol=2e-6, atol=2e-6)
     # after a later .to()/.float() style re-allocation the engine re-flattens transparently
     nf.layers[0].nn_t[0].weight.data = nf.layers[0].nn_t[0].weight.data.clone()
-    lp2 = nf.log_prob_samples(cs["X"], cs["C"]).cpu().numpy()
+    lp2 = nf.log_prob_samples(cs["X"], cs["C"]).detach().cpu().numpy()
     assert np.array_equal(lp, lp2)
 
 
@@ -271,7 +297,7 @@ def test_heterogeneous_layer_list_runs_layer_by_layer(oracle32):
     assert nf._layerwise()
     rng = np.random.default_rng(1)
     X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
-    lp = nf.log_prob_samples(X, C).cpu().numpy()
+    lp = nf.log_prob_samples(X, C).detach().cpu().numpy()
     # oracle: one layer at a time with that layer's own shape
     x = X.copy(); ld = np.zeros(n, np.float64)
     for i, (layer, (h, a)) in enumerate(zip(layers, specs)):
@@ -309,9 +335,149 @@ def test_small_calls_latency_keyword():
         m.fit(X, C)
         torch.manual_seed(1)
         xs = m.sample(C[:1000])
-        lp = m.nf.log_prob_samples(torch.from_numpy(X[:1000]).cuda(), torch.from_numpy(C[:1000]).cuda()).cpu().numpy()
+        lp = m.nf.log_prob_samples(torch.from_numpy(X[:1000]).cuda(), torch.from_numpy(C[:1000]).cuda()).detach().cpu().numpy()
         out[mode] = (xs, lp)
     assert np.abs(out[None][0] - out["latency"][0]).max() < 2e-4 and np.abs(out[None][1] - out["latency"][1]).max() < 2e-4
     assert not np.array_equal(out[None][0], out["latency"][0])            # different kernels did run
     with pytest.raises(KeyError):
         RealNVP(small_calls="fast").fit(X[:64], C[:64])
+
+
+# ---- differentiable seam (nflow.py:107-117, realnvp.py:246-250): log_prob / layer.f carry an autograd graph -----------------
+def _flow_from_case(cs):
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    L, d, c = cs["L"], cs["d"], cs["c"]
+    layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, cs["hidden"], cs["act"]) for i in range(L)]
+    nf = NormalizingFlow(layers, StandardNormalPrior(d, "cuda"))
+    sd = nf.state_dict(); off = 0; new = {}
+    for k, v in sd.items():
+        new[k] = torch.from_numpy(cs["params"][off:off + v.numel()].copy()).view_as(v); off += v.numel()
+    nf.load_state_dict(new)
+    return nf
+
+
+@pytest.mark.parametrize("name", ["tm", "c2", "relu_mh", "tm_nocond", "c1_L8"])
+def test_backward_through_log_prob_fills_param_grads_like_the_reference(name):
+    """`loss = -nf.log_prob(X, C); loss.backward()` (realnvp.py:246-250) on the reference's weights: p.grad equals the
+    gradient the reference's autograd produced (G4), through rnvp_backward -- register-chained MFMA (tm, c2), lmm (relu_mh)"""
+    from cases import GRAD_STRIDE
+    cs = load_case(name); g = cs["gold"]
+    nf = _flow_from_case(cs)
+    X = torch.from_numpy(cs["X"]); C = None if cs["C"] is None else torch.from_numpy(cs["C"])
+    loss = -nf.log_prob(X, C)
+    assert loss.requires_grad and loss.grad_fn is not None
+    assert abs(float(loss) - float(g["G4_loss"])) < 2e-5 * max(1.0, abs(float(g["G4_loss"])))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in nf.parameters()]).cpu().numpy()
+    if "G4_grad" in g:
+        ref = g["G4_grad"]
+        assert np.abs(grad - ref).max() < 3e-6 * np.abs(ref).max() + 1e-9
+    else:
+        ref = g["G4_grad_sub"]
+        assert np.abs(grad[::GRAD_STRIDE] - ref).max() < 3e-6 * np.abs(ref).max() + 1e-9
+        assert abs(np.sqrt((grad.astype(np.float64) ** 2).sum()) - float(g["G4_grad_l2"])) < 3e-6 * float(g["G4_grad_l2"])
+    # under no_grad the fused kernel answers, without a graph, with the same value
+    with torch.no_grad():
+        v = nf.log_prob(X, C)
+    assert not v.requires_grad and abs(float(v) + float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+
+
+def test_input_gradient_and_per_row_seeds_vs_torch_autograd(oracle64):
+    """d loss / d x and per-row d loss / d logdet (log_prob_samples with a non-uniform weighting; RealNVPLayer.f alone)
+    against torch autograd over an eager restatement of realnvp.py:91-100 on the same weights"""
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    torch.manual_seed(3)
+    d, c, L, n = 6, 2, 3, 50
+    layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, (12,), "tanh") for i in range(L)]
+    nf = NormalizingFlow(layers, StandardNormalPrior(d, "cuda"))
+    nf.engine()
+    X = torch.randn(n, d, device="cuda", requires_grad=True); C = torch.randn(n, c, device="cuda")
+    w = torch.rand(n, device="cuda") + 0.5
+
+    def eager(x):       # the reference's op sequence, float64 on the same parameters
+        x = x.double(); ld = torch.zeros(n, dtype=torch.float64, device="cuda")
+        for layer in nf.layers:
+            m = layer.mask.to("cuda").double()
+            xc = torch.cat([x * m, C.double()], 1)
+            def net(seq, u):
+                for mod in seq:
+                    u = torch.tanh(u) if isinstance(mod, torch.nn.Tanh) else torch.nn.functional.linear(u, mod.weight.double(), mod.bias.double())
+                return u
+            T, S = net(layer.nn_t, xc), net(layer.nn_s, xc)
+            x = (x * torch.exp(S) + T) * (1 - m) + x * m
+            ld = ld + (S * (1 - m)).sum(-1)
+        return x, ld
+
+    lp = nf.log_prob_samples(X, C)
+    loss = -(w * lp).sum() / n
+    loss.backward()
+    got_x = X.grad.clone(); got_p = [p.grad.clone() for p in nf.parameters()]
+    X.grad = None
+    for p in nf.parameters():
+        p.grad = None
+    z, ld = eager(X)
+    lp64 = ld - 0.5 * ((z * z).sum(-1) + d * np.log(2 * np.pi))
+    (-(w.double() * lp64).sum() / n).backward()
+    assert torch.allclose(lp.double(), lp64, atol=1e-5)
+    gx = X.grad; scale = float(gx.abs().max())
+    assert float((got_x.double() - gx.double()).abs().max()) < 5e-6 * scale
+    for a, p in zip(got_p, nf.parameters()):
+        assert float((a.double() - p.grad.double()).abs().max()) < 5e-6 * max(float(p.grad.abs().max()), 1e-3)
+    # one layer on its own: f is a graph node too
+    for p in nf.parameters():
+        p.grad = None
+    y, ldet = nf.layers[1].f(X.detach(), C)
+    assert y.grad_fn is not None and ldet.grad_fn is not None
+    ((y * y).sum() + (w * ldet).sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in nf.layers[1].parameters())
+    assert all(p.grad is None for p in nf.layers[0].parameters())
+
+
+def test_user_written_adam_loop_reproduces_the_reference_fit():
+    """the reference's own training loop written by a USER over nf.log_prob (realnvp.py:235-254) -- DataLoader shuffle,
+    torch.optim.Adam over nf.parameters(), loss.backward() through rnvp_backward -- reproduces G7's loss history"""
+    from probaforms_amd.models import RealNVP
+    from probaforms_amd._engine import loader_permutation
+    f = np.load(os.path.join(GOLDEN, "moons_fit.npz"))
+    X, C = f["X"], f["C"]
+    torch.manual_seed(0)
+    m = RealNVP(n_layers=8, lr=0.01, n_epochs=2)
+    m._model_init(X, C)                                      # same init draws as fit (realnvp.py:180-207)
+    nf = m.nf
+    opt = torch.optim.Adam(nf.parameters(), lr=0.01)
+    Xd = torch.tensor(X, dtype=torch.float32, device="cuda"); Cd = torch.tensor(C, dtype=torch.float32, device="cuda")
+    hist = []
+    for _epoch in range(2):
+        perm = loader_permutation(len(X)).cuda()
+        for s in range(0, len(X), 32):
+            idx = perm[s:s + 32]
+            loss = -nf.log_prob(Xd[idx], Cd[idx])
+            opt.zero_grad(); loss.backward(); opt.step()
+            hist.append(float(loss))
+    ref = f["L8_loss_history"]
+    assert len(hist) == 64
+    np.testing.assert_allclose(hist[:8], ref[:8], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(hist, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_verbose_progress_text_follows_the_reference(monkeypatch):
+    """verbose >= 2 (realnvp.py:256-259): the description is set from the batches i % max(1, (n // bs) // verbose) == 0"""
+    import tqdm.auto
+    from probaforms_amd.models import RealNVP
+    seen = []
+
+    class Bar:
+        def __init__(self, total=None, unit=None): self.total = total
+        def update(self, k): seen.append(("update", k))
+        def set_description(self, s): seen.append(("desc", s))
+        def close(self): seen.append(("close",))
+
+    monkeypatch.setattr(tqdm.auto, "tqdm", Bar)
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(100, 3)); C = rng.normal(size=(100, 1))
+    m = RealNVP(n_layers=2, n_epochs=2, batch_size=10, verbose=2)
+    m.fit(X, C)
+    descs = [s for kind, *rest in seen if kind == "desc" for s in rest]
+    # 10 batches per epoch, display_delta = (100 // 10) // 2 = 5 -> batches 0 and 5 of each epoch
+    want = ["loss: %.4f" % float(m.loss_history[i]) for i in (0, 5, 10, 15)]
+    assert descs == want and seen[-1] == ("close",)

@@ -59,6 +59,12 @@ def test_two_ranks_on_hip_kernels_match_single_process(tmp_path):
     np.testing.assert_allclose(dp["cvae_hist"], np.array([float(v) for v in cv.loss_history]), rtol=5e-4, atol=5e-4)
     cf = cv._core.flat.detach().cpu().numpy()
     assert np.abs(dp["cvae_flat"] - cf).max() < 2e-3 and np.abs(dp["cvae_flat"] - cf).mean() < 5e-5
+    # the reference's own fit of the C2 flow at batch_size=32 (tests/golden/c2_fit.npz), here on two ranks
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "c2_fit.npz")); got = np.load(out + ".c2fit.npz")
+    assert got["hist"].shape == (16,)
+    np.testing.assert_allclose(got["hist"][:4], ref["loss_history"][:4], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got["hist"], ref["loss_history"], rtol=1e-3, atol=1e-3)
+    assert np.abs(got["flat"][:ref["params_after"].size] - ref["params_after"]).max() < 2e-3
     # sharded sampling: rank shares are consecutive blocks of the replicated draw; 'gather' rebuilds all of it
     s0, s1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
     assert s0["shard"].shape == (31, 5) and s1["shard"].shape == (30, 5)

@@ -729,3 +729,102 @@ def test_small_calls_latency_mode_vs_oracle(d, c, h, act, prec, n, oracle32, ora
     _hip.forward_logprob(pinned, pd, None, xd, cd, None, n, zb, None, None, None, _ws(_hip, pinned, _hip.OP_FORWARD, n))
     _hip.forward_logprob(invb, pd, None, xd, cd, None, n, zc, None, None, None, _ws(_hip, invb, _hip.OP_FORWARD, n))
     assert torch.equal(zb, zc)
+
+
+# ---- out-of-bounds canaries: guard bands around every output buffer ----------------------------------
+_CANARY = 0x7fc0dead          # a quiet-NaN bit pattern no kernel produces
+
+
+class _Guarded:
+    """a float32 output buffer of `numel` elements with 64 poisoned elements on either side (16-byte aligned interior)"""
+
+    def __init__(self, numel):
+        self.full = torch.full((numel + 128,), 0, dtype=torch.int32, device="cuda")
+        self.full.fill_(_CANARY)
+        self.view = self.full[64:64 + numel].view(torch.float32)
+        self.numel = numel
+
+    def check(self, what):
+        lo, hi = self.full[:64], self.full[64 + self.numel:]
+        assert bool((lo == _CANARY).all()) and bool((hi == _CANARY).all()), "write outside %s" % what
+
+
+@pytest.mark.parametrize("L,d,c,hidden,n,family", [
+    (8, 16, 4, (128,), 200, "auto"), (8, 16, 4, (128,), 70001, "auto"), (3, 5, 3, (10,), 33, "auto"), (2, 1, 1, (10,), 17, "auto"),
+    (12, 32, 8, (256,), 1000, "auto"), (4, 64, 16, (128,), 4097, "auto"), (4, 33, 0, (40,), 129, "auto"),
+    (3, 6, 2, (7, 9), 203, "lmm"), (3, 6, 2, (7, 9), 203, "valu"), (3, 80, 20, (24,), 301, "auto")])
+def test_no_kernel_writes_outside_its_output_buffers(L, d, c, hidden, n, family):
+    """z_out, logdet/logp, x_out, grad_out, gx_out and loss_hist sit between poisoned guard bands; every entry point runs
+    (forward, inverse, fused sampling, loss + gradient, backward, one fitted epoch) and the bands must be untouched"""
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(L + d + n)
+    masks = ((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8)
+    alt = 1 if len(hidden) == 1 and d <= 64 and c <= 16 and family == "auto" else 0
+    shape = _hip.RnvpShape.make(L, d, c, hidden, "tanh", alt_masks=alt, family=family)
+    P = _hip.param_count(shape)
+    params = _dev((rng.uniform(-1, 1, P) * 0.2).astype(np.float32)); mk = _dev(masks, torch.uint8)
+    x = _dev(rng.standard_normal((n, d)).astype(np.float32))
+    cc = _dev(rng.standard_normal((n, c)).astype(np.float32)) if c else None
+    z, ld, lp, tot = _Guarded(n * d), _Guarded(n), _Guarded(n), _Guarded(1)
+    _hip.forward_logprob(shape, params, mk, x, cc, None, n, z.view.view(n, d), ld.view, lp.view, tot.view, _ws(_hip, shape, _hip.OP_FORWARD, n))
+    xb = _Guarded(n * d)
+    _hip.inverse(shape, params, mk, z.view.view(n, d), cc, n, xb.view.view(n, d), _ws(_hip, shape, _hip.OP_INVERSE, n))
+    xs = _Guarded(n * d)
+    _hip.sample(shape, params, mk, cc, n, 3, 5, xs.view.view(n, d), _ws(_hip, shape, _hip.OP_INVERSE, n))
+    g, loss = _Guarded(P), _Guarded(1)
+    _hip.loss_grad(shape, params, mk, x, cc, None, n, 1.0 / n, g.view, loss.view, _ws(_hip, shape, _hip.OP_TRAIN, n))
+    g2, gx = _Guarded(P), _Guarded(n * d)
+    gz = torch.randn(n, d, device="cuda"); gld = torch.randn(n, device="cuda")
+    _hip.backward(shape, params, mk, x, cc, None, n, gz, gld, g2.view, gx.view.view(n, d), _ws(_hip, shape, _hip.OP_TRAIN, n))
+    bs = max(1, n // 3)
+    nb = (n + bs - 1) // bs
+    hist, gbuf = _Guarded(nb), _Guarded(P)
+    p2, m1, m2 = _Guarded(P), _Guarded(P), _Guarded(P)
+    p2.view.copy_(params); m1.view.zero_(); m2.view.zero_()
+    perm = torch.randperm(n, device="cuda")
+    _hip.fit_epoch(shape, p2.view, mk, x, cc, perm, n, bs, gbuf.view, hist.view, m1.view, m2.view, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1,
+                   _ws(_hip, shape, _hip.OP_TRAIN, bs))
+    torch.cuda.synchronize()
+    for buf, what in ((z, "z_out"), (ld, "logdet_out"), (lp, "logp_out"), (tot, "logp_sum"), (xb, "x_out (inverse)"),
+                      (xs, "x_out (sample)"), (g, "grad_out"), (loss, "loss_out"), (g2, "grad_out (backward)"),
+                      (gx, "gx_out"), (hist, "loss_hist"), (gbuf, "grad_buf"), (p2, "params"), (m1, "exp_avg"), (m2, "exp_avg_sq")):
+        buf.check(what)
+    for buf in (z, lp, xb, xs, g, g2, gx, hist):
+        assert bool(torch.isfinite(buf.view).all())
+
+
+def test_backward_entry_point_vs_loss_grad_and_oracle(oracle64):
+    """rnvp_backward seeded with the loss's own seeds (gz = z / B, gld = -1 / B) equals rnvp_loss_grad, on every kernel
+    family; gx_out against a central finite difference of the float64 oracle's loss"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    for (L, d, c, hidden, fam, n) in [(8, 16, 4, (128,), "auto", 100), (8, 16, 4, (128,), "auto", 20000), (4, 6, 2, (12, 20), "lmm", 77),
+                                      (4, 6, 2, (12, 20), "valu", 77), (6, 32, 8, (64,), "auto", 300)]:
+        alt = 1 if len(hidden) == 1 else 0
+        shape = _hip.RnvpShape.make(L, d, c, hidden, "tanh", alt_masks=alt, family=fam)
+        rng = np.random.default_rng(d + n)
+        masks = ((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8)
+        P = _hip.param_count(shape)
+        p = (rng.uniform(-1, 1, P) * 0.25).astype(np.float32)
+        X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
+        pd, mk, xd, cd = _dev(p), _dev(masks, torch.uint8), _dev(X), _dev(C)
+        z = torch.empty(n, d, device="cuda")
+        _hip.forward_logprob(shape, pd, mk, xd, cd, None, n, z, None, None, None, _ws(_hip, shape, _hip.OP_FORWARD, n))
+        g1 = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+        _hip.loss_grad(shape, pd, mk, xd, cd, None, n, 1.0 / n, g1, loss, _ws(_hip, shape, _hip.OP_TRAIN, n))
+        g2 = torch.empty(P, device="cuda"); gx = torch.empty(n, d, device="cuda")
+        _hip.backward(shape, pd, mk, xd, cd, None, n, (z / n).contiguous(), torch.full((n,), -1.0 / n, device="cuda"), g2, gx,
+                      _ws(_hip, shape, _hip.OP_TRAIN, n))
+        scale = float(g1.abs().max())
+        assert float((g1 - g2).abs().max()) < 2e-6 * scale, (hidden, fam, n)
+        if n <= 100:      # d loss / d x[r][j] by finite differences of the float64 oracle
+            so = Shape.make(L, d, c, hidden, "tanh")
+            gxh = gx.cpu().numpy()
+            for (r, j) in [(0, 0), (3, d - 1), (n - 1, d // 2)]:
+                e = 1e-4
+                Xp, Xm = X.astype(np.float64).copy(), X.astype(np.float64).copy()
+                Xp[r, j] += e; Xm[r, j] -= e
+                lp_, _ = oracle64.loss_grad(so, p.astype(np.float64), Xp, C.astype(np.float64), masks=masks if not alt else None)
+                lm_, _ = oracle64.loss_grad(so, p.astype(np.float64), Xm, C.astype(np.float64), masks=masks if not alt else None)
+                fd = (float(lp_) - float(lm_)) / (2 * e)
+                assert abs(gxh[r, j] - fd) < 2e-5 * max(1.0, np.abs(gxh).max()) + 1e-7, (hidden, fam, r, j, gxh[r, j], fd)
