@@ -269,7 +269,53 @@ def secondary_configs(Xh, Ch, dev):
         out["c2_batch%d" % bs] = {"workload": "the C2 flow at batch_size=%d%s: %d fused steps in one rnvp_fit_epoch call (tile-split "
                                               "training kernel)" % (bs, " (the reference's default)" if bs == 32 else "", nsteps),
                                   "us_per_step": us, "rows_per_s": bs / (us * 1e-6)}
+    out["c2_precision_ab"] = precision_ab(Xh, Ch, dev)
     out.update(secondary_c3_c4(dev))
+    return out
+
+
+def precision_ab(Xh, Ch, dev):
+    """BASELINE.json configs[1] says "bf16": the C2 flow with rnvp_shape.precision = f32 against bx3 (split-bf16 first Linear
+    in forward / inverse / sampling and in the forward phase of the training kernel; rnvp_split.h) -- kernel times from the
+    library's HIP events and the per-row log-prob MAE of each against the float64 oracle on the same weights.  Plain bf16
+    inputs would miss the 1e-5 parity bar by three orders; the split form keeps float32-level accuracy."""
+    import torch
+    from oracle import Oracle, Shape
+    from probaforms_amd import _engine, _hip
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    X = torch.from_numpy(Xh).to(dev); C = torch.from_numpy(Ch).to(dev)
+    out = {}
+    rows = 4096
+    for prec in ("f32", "bx3"):
+        torch.manual_seed(0)
+        layers = [RealNVPLayer(D, CDIM, (torch.arange(D) + i) % 2, HIDDEN, "tanh") for i in range(LAYERS)]
+        nf = NormalizingFlow(layers, StandardNormalPrior(D, dev, host_rng=False), precision=prec)
+        for p in nf.parameters():
+            p.data = p.data.to(dev)
+        eng = nf.engine()
+        opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+        idx = torch.randperm(N_ROWS, device=dev)[:BATCH].contiguous(); loss = torch.zeros(1, device=dev)
+        xs = torch.empty(N_ROWS, D, device=dev)
+        res = {}
+        _hip.profile_enable(64)
+        for name, kind, fn, reps in (("train_step_65536_rows", _hip.PROFILE_TRAIN, lambda: eng.train_step(opt, X, C, idx, BATCH, 1.0 / BATCH, loss), 20),
+                                     ("log_prob_1M_rows", _hip.PROFILE_FORWARD, lambda: eng.forward(X, C, want_z=False, want_logp=True), 5),
+                                     ("sample_1M_rows", _hip.PROFILE_INVERSE, lambda: eng.sample(N_ROWS, C, 5, row_offset=0, out=xs), 5)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(dev); _hip.profile_read(kind)
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+            nk, kms = _hip.profile_read(kind)
+            res[name + "_kernel_ms"] = kms / max(nk, 1)
+        _hip.profile_enable(0)
+        with torch.no_grad():
+            lp = nf.log_prob_samples(X[:rows], C[:rows]).cpu().numpy()
+        params = eng.params.detach().cpu().numpy()
+        _, lp64, _ = Oracle(64).log_prob(Shape.make(LAYERS, D, CDIM, HIDDEN, "tanh"), params, Xh[:rows], Ch[:rows])
+        res["logprob_mae_vs_oracle_f64"] = float(np.abs(lp - lp64).mean())
+        out[prec] = res
     return out
 
 

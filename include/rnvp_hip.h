@@ -69,8 +69,10 @@ typedef struct rnvp_shape {
                                          1/2 let the library skip the masked-out (dead) columns and
                                          pick the MFMA path; the masks pointer is then not read.   */
     int32_t precision;                /* RNVP_PREC_*: arithmetic of the first Linear of the s/t nets in the forward /
-                                         inverse / sampling kernels of the MFMA path (the reference computes in
-                                         float32 throughout, realnvp.py:226-228; both settings meet its 1e-5 bar) */
+                                         inverse / sampling kernels of the MFMA path and in the FORWARD phase of its
+                                         training kernels (row-parallel launches, d <= 32; the backward is always f32).
+                                         The reference computes in float32 throughout, realnvp.py:226-228; both
+                                         settings meet its 1e-5 bar and the same gradient tolerances */
     int32_t small_calls;              /* RNVP_SMALL_*: how forward / inverse / sampling calls of at most 4096 rows run */
     int32_t family;                   /* RNVP_FAMILY_*: which kernels serve a shape OUTSIDE RNVP_PATH_MFMA (several hidden
                                          layers, user masks, d > 64, cdim > 16).  Per call, not process state: two threads

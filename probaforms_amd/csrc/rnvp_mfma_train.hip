@@ -74,6 +74,11 @@ constexpr bool kTrainBx = RNVP_TRAIN_BX != 0;
 #define RNVP_W2C_NO_NS 1
 #endif
 constexpr bool kW2cNoNs = RNVP_W2C_NO_NS != 0;
+// RNVP_TRAIN_WIDE: k_mfma_train_wide for d in (16, 32] when a batch needs more than 256 four-wave workgroups
+#ifndef RNVP_TRAIN_WIDE
+#define RNVP_TRAIN_WIDE 1
+#endif
+constexpr bool kTrainWide = RNVP_TRAIN_WIDE != 0;
 #ifndef RNVP_TRAIN_BXF
 #define RNVP_TRAIN_BXF 1
 #endif
@@ -134,7 +139,7 @@ template <int NF, int CQ> struct Dims {
 // (role 0: t, role 1: s).  Each runs its own net's hidden tiles and accumulates its own net's weight
 // gradients; the two exchange only the net outputs (forward) and the input-gradient partial sums (here)
 // through xown / xother in LDS, once per layer.
-template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false>
+template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false, int WV = kWaves>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
@@ -468,20 +473,20 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     const int nfl4 = ntile * TBLK / 4;
                     const int fr = tid >> 8, ft = tid & 255;
                     f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)fr * netblock + (size_t)t0 * TBLK);
-                    const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)fr * kWaves * SLOT);
+                    const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)fr * WV * SLOT);
                     for (int i = ft; i < nfl4; i += 256) {
                         f4 old = f4{0.f, 0.f, 0.f, 0.f};
                         if (!first) old = dst[i];           // in flight while the slots are read
                         f4 v = s0[i];
 #pragma unroll
-                        for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];
+                        for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];
                         dst[i] = first ? v : v + old;
                     }
                     if (last_tile && tid < NT2 * 16) {
-                        const int i = kWaves * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
+                        const int i = WV * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
                         float v = lds[i];
 #pragma unroll
-                        for (int w = 1; w < kWaves; ++w) v += lds[w * SLOT + i];
+                        for (int w = 1; w < WV; ++w) v += lds[w * SLOT + i];
                         float *p = gp_layer + 2 * (size_t)netblock + tid;
                         *p = first ? v : *p + v;
                     }
@@ -491,19 +496,19 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     const int nfl4 = ntile * TBLK / 4;
                     f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds);
-                    for (int i = tid; i < nfl4; i += kWaves * 64) {
+                    for (int i = tid; i < nfl4; i += WV * 64) {
                         f4 old = f4{0.f, 0.f, 0.f, 0.f};
                         if (!first) old = dst[i];           // in flight while the slots are read
                         f4 v = s0[i];
 #pragma unroll
-                        for (int w = 1; w < kWaves; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
+                        for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
                         dst[i] = first ? v : v + old;
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
                         const int i = FT * TBLK + tid;
                         float v = lds[i];
 #pragma unroll
-                        for (int w = 1; w < kWaves; ++w) v += lds[w * SLOT + i];
+                        for (int w = 1; w < WV; ++w) v += lds[w * SLOT + i];
                         float *p = gp_layer + 2 * (size_t)netblock + tid;
                         *p = first ? v : *p + v;
                     }
@@ -595,7 +600,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     STAMP_ADD(stp.btail, t0);
 }
 
-template <int NF, int CQ, int R, int NS, int ACT, bool BX, bool BXF = BX>
+// WV: waves of the workgroup that own row tiles (4; 8 in the wide form k_mfma_train_wide, NS == 0 only)
+template <int NF, int CQ, int R, int NS, int ACT, bool BX, bool BXF = BX, int WV = kWaves>
 __device__ __forceinline__ void train_body(const float *__restrict__ wp, const Geo &g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
@@ -603,21 +609,21 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     // d loss / d z rows and the loss partial carries the log-det term only
     using DM = Dims<NF, CQ>;
     constexpr int D = 8 * NF, CD = 4 * CQ;
-    constexpr int NW = kWaves * (1 + NS);                 // waves in the workgroup
+    constexpr int NW = WV * (1 + NS);                 // waves in the workgroup
     constexpr int XW = R * NF * 64;                       // floats one wave exchanges per layer (NS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pw = wave & (kWaves - 1), role = NS ? wave >> 2 : 0;     // row owner index; net of this wave (NS)
+    const int pw = wave & (WV - 1), role = NS ? wave >> 2 : 0;     // row owner index; net of this wave (NS)
     const int q = lane >> 4, r = lane & 15;
     constexpr int SLOTN = DM::template slot<NS>(), TBN = DM::template tbn<R, NS>();
     float *tb = lds + NW * SLOTN + wave * TBN;
     float *xbuf = lds + NW * SLOTN + NW * TBN;                         // NS: 2 x NW x XW, double buffered by layer parity
-    const int64_t rows_per_wg = (int64_t)kWaves * R * 16;
+    const int64_t rows_per_wg = (int64_t)WV * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
     const bool full = (g.d == D) && (g.c == CD) && ((uintptr_t)x & 15) == 0;     // else: guarded scalar row loads
     float *gp = gpart + (size_t)blockIdx.x * glayer_floats * L;
-    float *scr_wave = scratch + ((size_t)blockIdx.x * kWaves + pw) * L * R * 2 * NF * 64;
+    float *scr_wave = scratch + ((size_t)blockIdx.x * WV + pw) * L * R * 2 * NF * 64;
     float wave_sum = 0.f;
     bool first = true;
     Stamps stp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -642,8 +648,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
-                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ kWaves) * XW, xr, cr, ld, scr);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr);
             } else {
                 if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
                 else layer_forward<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
@@ -684,9 +690,9 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *gpl = gp + (size_t)l * glayer_floats;
             float *xb = xbuf + (size_t)(l & 1) * NW * XW;
             float *xo = NS ? xb + wave * XW : nullptr;
-            const float *xp = NS ? xb + (wave ^ kWaves) * XW : nullptr;
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
         }
         if (sd.gx && role == 0) {               // rnvp_backward: d loss / d x of the batch rows (gy after the first layer's backward)
             const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
@@ -697,7 +703,19 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
     }
-    if (lane == 0 && role == 0) losspart[blockIdx.x * kWaves + pw] = wave_sum;
+    if constexpr (WV > kWaves) {        // k_mfma_reduce adds kWaves loss partials per workgroup: fold the owners' sums, fixed order
+        __syncthreads();
+        if (lane == 0) lds[wave] = wave_sum;
+        __syncthreads();
+        if (wave == 0 && lane < kWaves) {
+            float a = lds[lane];
+#pragma unroll
+            for (int w = kWaves; w < WV; w += kWaves) a += lds[lane + w];
+            losspart[blockIdx.x * kWaves + lane] = a;
+        }
+    } else {
+        if (lane == 0 && role == 0) losspart[blockIdx.x * WV + pw] = wave_sum;
+    }
 #ifdef RNVP_STAMP
     {
         unsigned long long tk1; STAMP(tk1);
@@ -708,15 +726,30 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
 #endif
 }
 
-template <int NF, int CQ, int R, int NS, int ACT>
+// BXF (rnvp_shape.precision = RNVP_PREC_BX3, or AUTO where it resolves to BX3): GEMM1 of the FORWARD phase on split-bf16 MFMA
+// (rnvp_split.h); the backward keeps f32 -- its split operands do not fit in 256 registers next to the gradient state, and
+// the one-wave 512-register form that has the room is slower (k_mfma_train_bx below; profiles/r03_train_bx_ab.txt).
+// Measured (whole call, 65536 rows): C2 -1.5 %, C3 -2 %, C4 (NF = 8) +2 %: the wide geometry keeps f32 (train_bxf()).
+template <int NF, int CQ, int R, int NS, int ACT, bool BXF = false>
 __global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
-    // RNVP_TRAIN_BXF: GEMM1 of the FORWARD phase on split-bf16 MFMA (the backward keeps f32: its split operands do not fit
-    // in 256 registers next to the gradient state)
-    // measured (whole call, 65536 rows): C2 -1.5 %, C3 -2 %, C4 (NF = 8) +2 %: the wide geometry keeps f32
-    train_body<NF, CQ, R, NS, ACT, false, kTrainBxF && NF <= 4>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
+    train_body<NF, CQ, R, NS, ACT, false, BXF>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
+}
+
+// Wide form: EIGHT row-owning waves per workgroup (no net split), one workgroup per CU.  Where a 65 536-row batch would
+// otherwise need two 4-wave workgroups per CU (d > 16: 128 rows per workgroup), this halves the number of per-workgroup
+// partial gradients -- the bytes k_mfma_train writes and k_sum_segments reads (C3: 512 x 1.18 MB -> 256 x 1.18 MB) -- at the
+// same two waves per SIMD.  Eight LDS slots are added per flush instead of four.
+constexpr int kWideWaves = 2 * kWaves;
+template <int NF, int CQ, int R, int ACT, bool BXF = false>
+__global__ void __launch_bounds__(kWideWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+k_mfma_train_wide(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
+                  const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
+                  float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
+    train_body<NF, CQ, R, 0, ACT, false, BXF, kWideWaves>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+                                                          glayer_floats, sd);
 }
 
 // Split-GEMM1 form (BX, rnvp_split.h): GEMM1 of the forward phase, its recompute in the backward and g_h = W2^T g_out run on
@@ -979,11 +1012,20 @@ bool plan_for(const Geo &g, int L, TrainPlan *p) {
     return false;
 }
 
-template <int NF, int CQ, int R, int NS, int ACT>
+// forward GEMM1 of the training kernels on split-bf16 MFMA: the caller asked for it (precision bx3, or auto on a shape
+// where auto means bx3) and the geometry gains from it
+static bool train_bxf(const KShape &k, const Geo &g) { return kTrainBxF && k.prec == RNVP_PREC_BX3 && g.NF <= 4 && g.NI1 > 0; }
+
+template <int NF, int CQ, int R, int NS, int ACT, bool BXF = false>
 int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                     const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
                     float *losspart, float *scratch, int grid, size_t lds_bytes, Seeds sd) {
-    auto kern = k_mfma_train<NF, CQ, R, NS, ACT>;
+    if constexpr (!BXF && NF <= 4) {
+        if (train_bxf(k, g))
+            return launch_train_act<NF, CQ, R, NS, ACT, true>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart,
+                                                              scratch, grid, lds_bytes, sd);
+    }
+    auto kern = k_mfma_train<NF, CQ, R, NS, ACT, BXF>;
     static std::atomic<uint64_t> attr_done{0};          // per kernel instance; one bit per device
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
     if (arc) return arc;
@@ -991,6 +1033,28 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
         const KernelEvents ev(RNVP_PROFILE_TRAIN);      // rnvp_profile_*: this launch's own start / stop stamps when enabled
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, ev.start, ev.stop, 0, packed, g,
                               k.L, k.alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+template <int NF, int CQ, int R, int ACT, bool BXF = false>
+int launch_train_wide(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
+                      const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
+                      float *scratch, int grid, size_t lds_bytes, Seeds sd) {
+    if constexpr (!BXF && NF <= 4) {
+        if (train_bxf(k, g))
+            return launch_train_wide<NF, CQ, R, ACT, true>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+                                                           grid, lds_bytes, sd);
+    }
+    auto kern = k_mfma_train_wide<NF, CQ, R, ACT, BXF>;
+    static std::atomic<uint64_t> attr_done{0};
+    const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
+    if (arc) return arc;
+    {
+        const KernelEvents ev(RNVP_PROFILE_TRAIN);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWideWaves * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt,
+                              x, c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -1094,6 +1158,20 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     }
     lay->w2c = DM::template w2c<0>() ? 1 : 0;
     lay->glayer_floats = p0.glayer_floats;
+    if constexpr (kTrainWide && NF == 4) {       // d in (16, 32]: two 4-wave workgroups per CU become one 8-wave workgroup
+        const size_t lds_wide = kWideWaves * per_wave * sizeof(float);
+        if (ngroups > 256 && lds_wide <= 160 * 1024) {
+            const int64_t rows_wide = (int64_t)kWideWaves * R * 16;
+            const int64_t gw = (n + rows_wide - 1) / rows_wide;
+            const int gridw = (int)(gw < kMaxGridTrain / 2 ? gw : kMaxGridTrain / 2);
+            *grid_out = gridw;
+            if (k.act == RNVP_ACT_TANH)
+                return launch_train_wide<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+                                                       gridw, lds_wide, sd);
+            return launch_train_wide<NF, CQ, R, 1>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, gridw,
+                                                   lds_wide, sd);
+        }
+    }
     return launch_train_ns<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
                                          kWaves * per_wave * sizeof(float), sd);
 }

@@ -292,8 +292,12 @@ template <int V, int R, int WAVES> void run(const unsigned *w, float *d, unsigne
     unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
     const double units_per_wave = (double)tiles * reps * R, units_timed = (double)tiles * (reps - 1) * R;
     const double ghz = (double)h[0] / ((double)h[1] * 10.0);          // s_memrealtime ticks at 100 MHz
-    printf("  %-58s R=%d waves/SIMD=%d: %7.1f ns/unit/wave, %6.0f cycles per unit per SIMD, clock %.2f GHz (wall %.3f ms)\n", name, R,
-           WAVES / 4, best * 1e6 / units_per_wave, (double)h[0] / units_timed / (WAVES / 4), ghz, best);
+    // SIMD time per unit from the WALL time of the launch (every SIMD works through waves/SIMD x units_per_wave units); the
+    // cycle counter of one wave under-reads it (the older wave of a SIMD wins the arbitration and finishes early)
+    const double ns_simd = best * 1e6 / units_per_wave / (WAVES / 4);
+    (void)units_timed;
+    printf("  %-58s R=%d waves/SIMD=%d: %6.1f ns per unit per SIMD = %5.0f cycles at the measured %.2f GHz (wall %.3f ms)\n", name, R,
+           WAVES / 4, ns_simd, ns_simd * ghz, ghz, best);
 }
 
 int main() {
@@ -319,7 +323,7 @@ int main() {
     run<1, 4, 4>(w, d, clk, "bwd all bx3");
     run<5, 4, 4>(w, d, clk, "fwd all bx3");
     run<1, 8, 4>(w, d, clk, "bwd all bx3");
-    printf("-- occupancy sweep (same units; NOTE ns/unit/wave / (waves/SIMD) = SIMD time per unit)\n");
+    printf("-- occupancy sweep (same units)\n");
     run<3, 2, 8>(w, d, clk, "fwd f32");
     run<3, 2, 16>(w, d, clk, "fwd f32");
     run<3, 1, 16>(w, d, clk, "fwd f32");

@@ -56,7 +56,7 @@ def test_attributes_and_state_dict_after_fit():
     m.fit(X, C)                                     # warm start: same optimizer, history keeps growing
     assert len(m.loss_history) == 4 and m.opt.step_count == 4
     lp = m.nf.log_prob(torch.tensor(X, dtype=torch.float32), torch.tensor(C, dtype=torch.float32))
-    assert lp.dim() == 0 and np.isfinite(float(lp))
+    assert lp.dim() == 0 and np.isfinite(lp.item())
 
 
 def test_sample_argument_types():
@@ -344,7 +344,7 @@ def test_small_calls_latency_keyword():
 
 
 # ---- differentiable seam (nflow.py:107-117, realnvp.py:246-250): log_prob / layer.f carry an autograd graph -----------------
-def _flow_from_case(cs):
+def _nf_from_case(cs):
     from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
     L, d, c = cs["L"], cs["d"], cs["c"]
     layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, cs["hidden"], cs["act"]) for i in range(L)]
@@ -362,7 +362,7 @@ def test_backward_through_log_prob_fills_param_grads_like_the_reference(name):
     gradient the reference's autograd produced (G4), through rnvp_backward -- register-chained MFMA (tm, c2), lmm (relu_mh)"""
     from cases import GRAD_STRIDE
     cs = load_case(name); g = cs["gold"]
-    nf = _flow_from_case(cs)
+    nf = _nf_from_case(cs)
     X = torch.from_numpy(cs["X"]); C = None if cs["C"] is None else torch.from_numpy(cs["C"])
     loss = -nf.log_prob(X, C)
     assert loss.requires_grad and loss.grad_fn is not None

@@ -805,7 +805,7 @@ def test_backward_entry_point_vs_loss_grad_and_oracle(oracle64):
         rng = np.random.default_rng(d + n)
         masks = ((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8)
         P = _hip.param_count(shape)
-        p = (rng.uniform(-1, 1, P) * 0.25).astype(np.float32)
+        p = (rng.uniform(-1, 1, P) * min(0.2, 1.0 / np.sqrt(max(hidden) + d + c))).astype(np.float32)
         X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
         pd, mk, xd, cd = _dev(p), _dev(masks, torch.uint8), _dev(X), _dev(C)
         z = torch.empty(n, d, device="cuda")
@@ -816,7 +816,7 @@ def test_backward_entry_point_vs_loss_grad_and_oracle(oracle64):
         _hip.backward(shape, pd, mk, xd, cd, None, n, (z / n).contiguous(), torch.full((n,), -1.0 / n, device="cuda"), g2, gx,
                       _ws(_hip, shape, _hip.OP_TRAIN, n))
         scale = float(g1.abs().max())
-        assert float((g1 - g2).abs().max()) < 2e-6 * scale, (hidden, fam, n)
+        assert float((g1 - g2).abs().max()) < 5e-6 * scale, (hidden, fam, n)       # the seeds differ by one rounding (z * inv_B in-kernel)
         if n <= 100:      # d loss / d x[r][j] by finite differences of the float64 oracle
             so = Shape.make(L, d, c, hidden, "tanh")
             gxh = gx.cpu().numpy()
@@ -828,3 +828,29 @@ def test_backward_entry_point_vs_loss_grad_and_oracle(oracle64):
                 lm_, _ = oracle64.loss_grad(so, p.astype(np.float64), Xm, C.astype(np.float64), masks=masks if not alt else None)
                 fd = (float(lp_) - float(lm_)) / (2 * e)
                 assert abs(gxh[r, j] - fd) < 2e-5 * max(1.0, np.abs(gxh).max()) + 1e-7, (hidden, fam, r, j, gxh[r, j], fd)
+
+
+@pytest.mark.parametrize("L,d,c,h,n", [(8, 16, 4, 128, 20000), (4, 32, 8, 64, 9000), (3, 12, 3, 40, 16500)])
+def test_training_forward_on_split_bf16_keeps_the_gradient_tolerance(L, d, c, h, n, oracle64):
+    """rnvp_shape.precision = bx3 also moves GEMM1 of the training kernel's forward phase to split-bf16 MFMA (row-parallel
+    launches: more than 8192 rows): loss and gradient against the float64 oracle at the tolerance of the f32 kernel"""
+    from oracle import Shape
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(d + n)
+    s = Shape.make(L, d, c, (h,), "tanh")
+    X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
+    res = {}
+    for prec in ("f32", "bx3"):
+        shape = _hip.RnvpShape.make(L, d, c, (h,), "tanh", alt_masks=1, precision=prec)
+        P = _hip.param_count(shape)
+        if prec == "f32":
+            params = (rng.uniform(-1, 1, size=P) * min(0.5, 1.5 / np.sqrt(h + d + c))).astype(np.float32)
+        grad = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+        _hip.loss_grad(shape, _dev(params), None, _dev(X), _dev(C), None, n, 1.0 / n, grad, loss, _ws(_hip, shape, _hip.OP_TRAIN, n))
+        res[prec] = (float(loss), grad.cpu().numpy())
+    lo, go = oracle64.loss_grad(s, params.astype(np.float64), X.astype(np.float64), C.astype(np.float64))
+    go = np.asarray(go, np.float64)
+    for prec, (l, g) in res.items():
+        assert abs(l - float(lo)) < 1e-5 * max(1.0, abs(float(lo))), prec
+        assert np.abs(g - go).max() < 5e-6 * np.abs(go).max() + 1e-9, prec
+    assert not np.array_equal(res["f32"][1], res["bx3"][1])          # two different kernels did run
