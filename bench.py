@@ -229,9 +229,9 @@ def secondary_configs(Xh, Ch, dev):
     core = m._core
     eps = torch.randn(BATCH, 2, device=dev); idx = torch.randperm(N_ROWS, device=dev)[:BATCH].contiguous()
     g = core.grads(); ws = core.workspace(BATCH)
-    def cvae_step(t):
-        _hip.cvae_loss_grad(core.shape, core.sync(), X, C, idx, eps, BATCH, 1.0 / BATCH, 0.001, g[:core.P], g[core.P:core.P + 1], ws)
-        _hip.adam_step(core.sync(), g[:core.P], m.opt.exp_avg[:core.P], m.opt.exp_avg_sq[:core.P], core.P, 1e-3, 0.9, 0.999, 1e-8, 0.0, t)
+    def cvae_step(t):        # what CVAE.fit issues per batch on one GPU: loss + gradient + Adam, one library call
+        _hip.cvae_train_step(core.shape, core.sync(), X, C, idx, eps, BATCH, 1.0 / BATCH, 0.001, g[:core.P], g[core.P:core.P + 1],
+                             m.opt.exp_avg[:core.P], m.opt.exp_avg_sq[:core.P], 1e-3, 0.9, 0.999, 1e-8, 0.0, t, ws)
     for t in range(3):
         cvae_step(t + 1)
     torch.cuda.synchronize(dev)

@@ -47,6 +47,17 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params,
                    int64_t n_rows, float inv_B, float kl_weight,
                    float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes);
 
+/* cvae_loss_grad followed by rnvp_adam_step (rnvp_hip.h) on the same stream: the three lines `loss = compute_loss(...)`,
+ * `loss.backward()`, `opt.step()` of the training loop (cvae.py:243-246).  On the MFMA path the optimizer is fused into the
+ * kernel that scatters the gradient into parameter order (one launch fewer; identical arithmetic).  grad_buf [P] is scratch
+ * owned by the caller; `step` is the 1-based Adam step. */
+int cvae_train_step(void *stream, const cvae_shape *shape, float *params,
+                    const float *x, const float *c, const int64_t *row_index, const float *eps,
+                    int64_t n_rows, float inv_B, float kl_weight,
+                    float *grad_buf, float *loss_out, float *exp_avg, float *exp_avg_sq,
+                    double lr, double beta1, double beta2, double adam_eps, double weight_decay, int64_t step,
+                    void *workspace, size_t workspace_bytes);
+
 /* x_out [n,d] = Decoder([z || c])                                       cvae.py:108-113, 284-290
  * workspace (nullable; cvae_workspace_bytes) lets shapes on RNVP_PATH_MFMA run the MFMA kernels (the packed
  * weights live there); NULL runs the generic kernels. */

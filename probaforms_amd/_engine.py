@@ -538,10 +538,34 @@ def dp_communicator(device):
         return None
     key = (world, rank, torch.device(device).index)
     if key not in _DP_COMM:
-        box = [_hip.dp_unique_id() if rank == 0 else None]
+        # Whether the communicator exists must be the SAME answer on every rank (it selects which collectives the fit
+        # issues): each step is followed by an agreement over torch.distributed, and one rank's failure sends all of them
+        # to the per-batch loop (with a warning -- slower, not wrong).
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        uid, comm, err = None, None, None
+        try:
+            uid = _hip.dp_unique_id() if rank == 0 else None
+        except Exception as e:          # librccl missing / not loadable
+            err = e
+        box = [uid]
         dist.broadcast_object_list(box, src=0)
-        with torch.cuda.device(device):
-            _DP_COMM[key] = _hip.dp_init(box[0], rank, world)
+        if agree(box[0] is not None):
+            try:
+                with torch.cuda.device(device):
+                    comm = _hip.dp_init(box[0], rank, world)
+            except Exception as e:
+                err = e
+            if not agree(comm is not None):
+                _hip.dp_destroy(comm)
+                comm = None
+        if comm is None:
+            import warnings
+            warnings.warn("probaforms_amd: no RCCL communicator for the in-library data-parallel loop (%r); "
+                          "falling back to the per-batch loop over torch.distributed" % (err,))
+        _DP_COMM[key] = comm
     return _DP_COMM[key]
 
 

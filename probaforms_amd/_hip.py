@@ -136,6 +136,8 @@ _SIGNATURES = {
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
     "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
     "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
+    "cvae_train_step": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _VP,
+                                  _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
     "rnvp_profile_enable": (C.c_int, [C.c_int]),
@@ -370,6 +372,18 @@ def cvae_loss_grad(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight
           _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"), _ptr(eps, torch.float32, "eps"),
           int(n_rows), float(inv_B), float(kl_weight), _ptr(grad_out, torch.float32, "grad_out"),
           _ptr(loss_out, torch.float32, "loss_out"), wp, wn))
+
+
+def cvae_train_step(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_buf, loss_out, exp_avg, exp_avg_sq,
+                    lr, beta1, beta2, adam_eps, weight_decay, step, ws):
+    """cvae_loss_grad + Adam, fused on the MFMA path (one launch fewer)"""
+    wp, wn = _ws(ws)
+    _call("cvae_train_step", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(x, torch.float32, "x"),
+          _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"), _ptr(eps, torch.float32, "eps"),
+          int(n_rows), float(inv_B), float(kl_weight), _ptr(grad_buf, torch.float32, "grad_buf"),
+          _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
+          _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(adam_eps),
+          float(weight_decay), int(step), wp, wn))
 
 
 def cvae_decode(shape, params, z, c, n_rows, x_out, ws=None):

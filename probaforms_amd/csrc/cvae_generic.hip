@@ -249,6 +249,29 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, c
     return generic_reduce_partials(st, grad_out ? gpart : nullptr, losspart, G, P, inv_B, grad_out, loss_out);
 }
 
+int cvae_train_step(void *stream, const cvae_shape *shape, float *params, const float *x, const float *c,
+                    const int64_t *row_index, const float *eps, int64_t n_rows, float inv_B, float kl_weight,
+                    float *grad_buf, float *loss_out, float *exp_avg, float *exp_avg_sq,
+                    double lr, double beta1, double beta2, double adam_eps, double weight_decay, int64_t step,
+                    void *workspace, size_t workspace_bytes) {
+    CvaeK k;
+    int rc = make_cvae(shape, &k);
+    if (rc) return rc;
+    if (!grad_buf || !exp_avg || !exp_avg_sq || step < 1) return RNVP_EINVAL;
+    if (n_rows > 0 && use_mfma(shape)) {
+        if (!params || !x || (k.c > 0 && !c) || !eps) return RNVP_EINVAL;
+        if (!workspace || workspace_bytes < cvae_workspace_bytes(shape, n_rows)) return RNVP_EWORKSPACE;
+        return cvae_mfma::train_step(static_cast<hipStream_t>(stream), shape, params, x, c, row_index, eps, n_rows, inv_B,
+                                     kl_weight, grad_buf, loss_out, exp_avg, exp_avg_sq,
+                                     make_adam(lr, beta1, beta2, adam_eps, weight_decay, step), workspace, workspace_bytes);
+    }
+    rc = cvae_loss_grad(stream, shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_buf, loss_out, workspace,
+                        workspace_bytes);
+    if (rc) return rc;
+    return rnvp_adam_step(stream, params, grad_buf, exp_avg, exp_avg_sq, (int64_t)cvae_param_count(shape), lr, beta1, beta2,
+                          adam_eps, weight_decay, step);
+}
+
 int cvae_decode(void *stream, const cvae_shape *shape, const float *params, const float *z, const float *c,
                 int64_t n_rows, float *x_out, void *workspace, size_t workspace_bytes) {
     CvaeK k;

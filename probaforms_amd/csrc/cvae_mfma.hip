@@ -526,7 +526,7 @@ __device__ __forceinline__ int dloc(int hid, int col) { const int i = hid & 15; 
 
 __global__ void __launch_bounds__(256)
 k_unpack(CG g, const float *__restrict__ seg, int S, const float *__restrict__ losspart, int nloss, float inv_B,
-         float *__restrict__ grad, float *loss) {
+         float *__restrict__ grad, float *loss, float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.P) {
         if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
@@ -570,6 +570,7 @@ k_unpack(CG g, const float *__restrict__ seg, int S, const float *__restrict__ l
     float a = 0.f;
     for (int b = 0; b < S; ++b) a += seg[(size_t)b * g.gfloats + loc];
     grad[p] = a;
+    if (adam_p) adam_one(adam_p[p], a, adam_m[p], adam_v[p], adam);       // fused optimizer (cvae_train_step)
 }
 
 size_t lds_bytes() { return ((size_t)kWaves * (kFT * 3 * 256 + 32) + (size_t)kWaves * 7 * 16 * kTS) * sizeof(float); }
@@ -587,9 +588,9 @@ size_t workspace_bytes(const cvae_shape *s) {
            align_up((size_t)kSeg * g.gfloats * 4, 256) + align_up((size_t)kMaxGrid * kWaves * 4, 256);
 }
 
-int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const float *x, const float *c,
-              const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
-              float *loss_out, void *ws, size_t ws_bytes) {
+static int loss_grad_impl(hipStream_t st, const cvae_shape *s, const float *params, const float *x, const float *c,
+                          const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
+                          float *loss_out, void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
     if (!ws || ws_bytes < workspace_bytes(s)) return RNVP_EWORKSPACE;
     const CG g = make_cg(s);
     char *w = static_cast<char *>(ws);
@@ -624,9 +625,25 @@ int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const fl
         }
     }
     hipLaunchKernelGGL(k_unpack, dim3(g.P / 256 + 2), dim3(256), 0, st, g, seg, S, losspart, grid * kWaves, inv_B, grad_out,
-                       loss_out);
+                       loss_out, adam_p, adam_m, adam_v, adam);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
+}
+
+int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const float *x, const float *c,
+              const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
+              float *loss_out, void *ws, size_t ws_bytes) {
+    return loss_grad_impl(st, s, params, x, c, row_index, eps, n, inv_B, klw, grad_out, loss_out, ws, ws_bytes, nullptr, nullptr,
+                          nullptr, AdamK{});
+}
+
+// loss + gradient + Adam with the optimizer fused into the final scatter kernel (one launch fewer than cvae_loss_grad +
+// rnvp_adam_step; the same arithmetic, bit for bit)
+int train_step(hipStream_t st, const cvae_shape *s, float *params, const float *x, const float *c, const int64_t *row_index,
+               const float *eps, int64_t n, float inv_B, float klw, float *grad_buf, float *loss_out, float *exp_avg,
+               float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes) {
+    return loss_grad_impl(st, s, params, x, c, row_index, eps, n, inv_B, klw, grad_buf, loss_out, ws, ws_bytes, params, exp_avg,
+                          exp_avg_sq, adam);
 }
 
 // encoder (mu, log_sigma) or decoder (x_rec) alone on the MFMA blocks; the packed weights go to the caller's workspace

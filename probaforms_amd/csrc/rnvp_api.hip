@@ -126,9 +126,11 @@ size_t rnvp_workspace_bytes(const rnvp_shape *shape, int op, int64_t max_rows) {
     KShape k;
     if (make_kshape(shape, &k) != RNVP_OK) return 0;
     const bool use_mfma = (op == RNVP_OP_TRAIN) ? mfma::train_supported(k) : mfma::supported(k);
-    const size_t b = use_mfma ? mfma::workspace_bytes(k, op, max_rows)
-                              : (lmm::use_lmm(k, op) ? lmm::workspace_bytes(k, op, max_rows < 1 ? 1 : max_rows)
-                                                     : generic_workspace_bytes(k, op, max_rows));
+    const size_t other = lmm::use_lmm(k, op) ? lmm::workspace_bytes(k, op, max_rows < 1 ? 1 : max_rows)
+                                             : generic_workspace_bytes(k, op, max_rows);
+    size_t b = use_mfma ? mfma::workspace_bytes(k, op, max_rows) : other;
+    // rnvp_backward of more rows than the tile-split MFMA kernel takes runs on the any-shape kernels: one size serves both
+    if (use_mfma && op == RNVP_OP_TRAIN && !mfma::backward_rows_ok(k, max_rows) && other > b) b = other;
     return b + 256;
 }
 
@@ -246,7 +248,8 @@ static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *par
         return RNVP_OK;
     }
     if (bad_ptrs(k, params, masks, x, c)) return RNVP_EINVAL;
-    if (mfma::train_supported(k))
+    const bool seeded = sd.gld || sd.gx;        // rnvp_backward: only the tile-split MFMA kernel takes those (small calls)
+    if (mfma::train_supported(k) && (!seeded || mfma::backward_rows_ok(k, n_rows)))
         return mfma::loss_grad(st, k, params, x, c, row_index, n_rows, inv_B, grad_out, loss_out, workspace,
                                workspace_bytes, sd);
     if (!masks) return RNVP_EINVAL;

@@ -138,6 +138,12 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 
 AdamK make_adam(double lr, double beta1, double beta2, double eps, double wd, int64_t step);
 
+namespace cvae_mfma {
+int train_step(hipStream_t st, const ::cvae_shape *s, float *params, const float *x, const float *c,
+               const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_buf,
+               float *loss_out, float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes);
+}  // namespace cvae_mfma
+
 // ---- optimizer: rnvp_adam.hip -----------------------------------------------------------
 int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int64_t n,
               double lr, double beta1, double beta2, double eps, double wd, int64_t step,

@@ -93,6 +93,7 @@ __host__ __device__ inline int feat_trans(int NF, int q, int f, int pc) { return
 
 bool supported(const KShape &k);            // forward / inverse
 bool train_supported(const KShape &k);      // fused forward + backward
+bool backward_rows_ok(const KShape &k, int64_t n);      // rnvp_backward (per-row seeds, d loss / d x) of n rows runs here
 size_t train_workspace_bytes(const KShape &k, int64_t max_rows);
 int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed);
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows);

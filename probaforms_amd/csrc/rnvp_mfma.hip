@@ -289,12 +289,17 @@ k_mfma_flow_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float 
         load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[0], cr[0]);
     }
     ld[0] = 0.f;
+    constexpr bool PRE = NF <= 4;   // a layer's opening fragments, requested one layer ahead (rnvp_mfma_layer.h)
+    TilePre<NF, CQ> pre;
+    if (PRE && tile_hi > tile_lo)
+        load_tile_pre<NF, CQ>(wp + (size_t)(INVERSE ? L - 1 : 0) * g.layer_floats, g, lane, (wave >> 2) * g.HT + tile_lo, tile_hi - tile_lo, pre);
     for (int lp = 0; lp < L; ++lp) {
         const int l = INVERSE ? L - 1 - lp : lp;
         const float *W = wp + (size_t)l * g.layer_floats;
+        const float *Wn = lp + 1 < L ? wp + (size_t)(INVERSE ? l - 1 : l + 1) * g.layer_floats : nullptr;
         float *rb = lds + (size_t)(lp & 1) * kTsWaves * XW;
-        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, INVERSE ? 1 : 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, nullptr);
-        else layer_forward_ts<NF, CQ, R, 0, INVERSE ? 1 : 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, nullptr);
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, INVERSE ? 1 : 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, nullptr, Wn, pre, PRE);
+        else layer_forward_ts<NF, CQ, R, 0, INVERSE ? 1 : 0, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, nullptr, Wn, pre, PRE);
     }
     if (wave != 0) {
         if (!INVERSE && part && lane == 0 && wave < kWaves) part[blockIdx.x * kWaves + wave] = 0.f;

@@ -284,13 +284,41 @@ __device__ __forceinline__ f4 gemm1_any(const f4 (&a1)[G1Dims<NF, CQ, BX>::NA], 
     return acc;
 }
 
+// The fragments a tile loop starts with (the prologue of run_tiles / run_tiles_x4, f32 forms): the tile-split kernels load
+// them for the NEXT layer before the current layer's LDS rendezvous, so that a layer does not open with a dependent
+// round trip to memory (those launches are latency chains; the packed block was written by another kernel moments ago and
+// the first touch of a line comes from beyond this XCD's L2).
+template <int NF, int CQ> struct TilePre {
+    static constexpr int K4 = FwdDims<NF, CQ>::K4, NA2 = (NF == 2 && kUseX4) ? 2 : FwdDims<NF, CQ>::OTL;
+    f4 a1c[K4], b1c, a2c[NA2], a1n[K4], b1n;
+};
+template <int NF, int CQ>
+__device__ __forceinline__ void load_tile_pre(const float *__restrict__ W, const Geo &g, int lane, int tile0, int ntiles,
+                                              TilePre<NF, CQ> &p) {
+    constexpr int K4 = TilePre<NF, CQ>::K4, NA2 = TilePre<NF, CQ>::NA2;
+    const int q = lane >> 4;
+    const float *pA1 = W + g.oA1 + ((size_t)tile0 * K4 * 64 + lane) * 4;
+    const float *pB1 = W + g.oB1 + ((size_t)tile0 * 4 + q) * 4;
+    const float *pA2 = W + ((NF == 2 && kUseX4) ? g.oA2X : g.oA2) + ((size_t)tile0 * NA2 * 64 + lane) * 4;
+    const int t1 = ntiles > 1 ? 1 : 0;
+#pragma unroll
+    for (int k4 = 0; k4 < K4; ++k4) p.a1c[k4] = *opaque(pA1 + k4 * 256);
+    p.b1c = *opaque(pB1);
+#pragma unroll
+    for (int o = 0; o < NA2; ++o) p.a2c[o] = *opaque(pA2 + o * 256);
+#pragma unroll
+    for (int k4 = 0; k4 < K4; ++k4) p.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
+    p.b1n = *opaque(pB1 + t1 * 16);
+}
+
 // Tiles [tile0, tile0 + ntiles) of the packed layer feed out tiles OT0 .. OT0 + OTL - 1.
 template <int NF, int CQ, int R, int PC, int OT0, int ACT, bool BX = false>
 __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo &g, int lane, int tile0,
                                           int ntiles, const float (&xr)[R][2 * NF],
                                           const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           f4 (&out)[R][FwdDims<NF, CQ>::NT2],
-                                          const f4 (*bin)[SplitDims<NF, CQ>::NI1] = nullptr) {
+                                          const f4 (*bin)[SplitDims<NF, CQ>::NI1] = nullptr,
+                                          const TilePre<NF, CQ> *pre = nullptr) {
     using D = FwdDims<NF, CQ>;
     constexpr int K4 = G1Dims<NF, CQ, BX>::NA, OTL = D::OTL;
     const int q = lane >> 4;
@@ -305,6 +333,18 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
     St s0, s1;
     {   // prologue: GEMM1 of the first tile; fragments of the second
         f4 a1c[K4], b1c;
+        bool have = false;
+        if constexpr (!BX && (NF >= 4 || !kUseX4)) {
+            if (pre) {          // loaded ahead by the caller (TilePre)
+                have = true;
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) { a1c[k4] = pre->a1c[k4]; s0.a1n[k4] = pre->a1n[k4]; }
+                b1c = pre->b1c; s0.b1n = pre->b1n;
+#pragma unroll
+                for (int o = 0; o < OTL; ++o) s0.a2c[o] = pre->a2c[o];
+            }
+        }
+        if (!have) {
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) a1c[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
         b1c = *reinterpret_cast<const f4 *>(pB1);
@@ -314,6 +354,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) s0.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
         s0.b1n = *opaque(pB1 + t1 * 16);
+        }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1_any<NF, CQ, PC, R, BX>(a1c, b1c, xr, cr, bin, rt);
     }
@@ -380,7 +421,8 @@ template <int CQ, int R, int PC, int NET, int ACT, bool BX = false>
 __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const Geo &g, int lane, int tile0,
                                              int ntiles, const float (&xr)[R][4],
                                              const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4],
-                                             const f4 (*bin)[SplitDims<2, CQ>::NI1] = nullptr) {
+                                             const f4 (*bin)[SplitDims<2, CQ>::NI1] = nullptr,
+                                             const TilePre<2, CQ> *pre = nullptr) {
     constexpr int NF = 2;
     constexpr int K4 = G1Dims<NF, CQ, BX>::NA;
     const int q = lane >> 4;
@@ -392,6 +434,17 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
     St s0, s1;
     {
         f4 a1c[K4], b1c;
+        bool have = false;
+        if constexpr (!BX) {
+            if (pre) {          // loaded ahead by the caller (TilePre)
+                have = true;
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) { a1c[k4] = pre->a1c[k4]; s0.a1n[k4] = pre->a1n[k4]; }
+                b1c = pre->b1c; s0.b1n = pre->b1n;
+                s0.a2c[0] = pre->a2c[0]; s0.a2c[1] = pre->a2c[1];
+            }
+        }
+        if (!have) {
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) a1c[k4] = *reinterpret_cast<const f4 *>(pA1 + k4 * 256);
         b1c = *reinterpret_cast<const f4 *>(pB1);
@@ -401,6 +454,7 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) s0.a1n[k4] = *opaque(pA1 + ((size_t)t1 * K4 + k4) * 256);
         s0.b1n = *opaque(pB1 + t1 * 16);
+        }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) s0.acc[rt] = gemm1_any<NF, CQ, PC, R, BX>(a1c, b1c, xr, cr, bin, rt);
     }
@@ -638,10 +692,26 @@ template <int NF, int CQ, int R, int PC, int MODE, int ACT>
 __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, const Geo &g, int lane, int wave, int tile0,
                                                  int nt, float *red, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
-                                                 float *__restrict__ scr) {
+                                                 float *__restrict__ scr, const float *__restrict__ Wnext,
+                                                 TilePre<NF, CQ> &pre, bool use_pre) {
+    // pre: this layer's opening fragments, loaded by the caller / the previous layer; Wnext (nullable): the layer that
+    // follows in this pass -- its opening fragments are requested here, before the rendezvous
     using D = FwdDims<NF, CQ>;
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4, net = wave >> 2;
+    // bias of the second Linear: the lane's slot of the t tile(s) and of the s tile(s), as layer_forward reads it (requested
+    // now, needed after the rendezvous)
+    float b2t[NF], b2s[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (NF >= 4) {
+            b2t[f] = W[g.oB2 + ((f >> 2) * 4 + q) * 4 + (f & 3)];
+            b2s[f] = W[g.oB2 + ((OTL + (f >> 2)) * 4 + q) * 4 + (f & 3)];
+        } else {
+            b2t[f] = W[g.oB2 + q * 4 + (f & 1)];
+            b2s[f] = W[g.oB2 + q * 4 + 2 + (f & 1)];
+        }
+    }
     float own[R][NF];           // this wave's share of its net's output for the features each lane owns (no bias)
     if constexpr (NF == 2 && kUseX4) {
         f4 outx[R][4];
@@ -650,8 +720,9 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (nt > 0) {
-            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx);
-            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx);
+            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr);
+            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr);
+            if (use_pre && Wnext) load_tile_pre<NF, CQ>(Wnext, g, lane, net * g.HT + tile0, nt, pre);
         }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
@@ -669,8 +740,9 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = f4{0.f, 0.f, 0.f, 0.f};
         if (nt > 0) {
-            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out);
-            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out);
+            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr);
+            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr);
+            if (use_pre && Wnext) load_tile_pre<NF, CQ>(Wnext, g, lane, net * g.HT + tile0, nt, pre);
         }
 #pragma unroll
         for (int rt = 0; rt < R; ++rt)
@@ -688,15 +760,7 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
     for (int rt = 0; rt < R; ++rt) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            // bias of the second Linear: the lane's slot of the t tile(s) and of the s tile(s), as layer_forward reads it
-            float tv, sv;
-            if (NF >= 4) {
-                tv = W[g.oB2 + ((f >> 2) * 4 + q) * 4 + (f & 3)];
-                sv = W[g.oB2 + ((OTL + (f >> 2)) * 4 + q) * 4 + (f & 3)];
-            } else {
-                tv = W[g.oB2 + q * 4 + (f & 1)];
-                sv = W[g.oB2 + q * 4 + 2 + (f & 1)];
-            }
+            float tv = b2t[f], sv = b2s[f];
 #pragma unroll
             for (int w = 0; w < kTsSlices; ++w) {
                 tv += red[(w * R * NF + rt * NF + f) * 64 + lane];

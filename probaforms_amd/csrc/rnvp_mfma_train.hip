@@ -139,13 +139,53 @@ template <int NF, int CQ> struct Dims {
 // (role 0: t, role 1: s).  Each runs its own net's hidden tiles and accumulates its own net's weight
 // gradients; the two exchange only the net outputs (forward) and the input-gradient partial sums (here)
 // through xown / xother in LDS, once per layer.
+// What the backward of a layer opens with (tile-split kernel only): the saved layer input / exp(s) records and the first
+// hidden tile's fragments, requested by the PREVIOUS call (the layer above) before its rendezvous -- the same latency
+// argument as TilePre (rnvp_mfma_layer.h).
+template <int NF, int CQ, int R> struct BwdPre {
+    static constexpr int K4 = Dims<NF, CQ>::K4, OTL = Dims<NF, CQ>::OTL, NGI = (NF == 2 && kUseX4) ? 2 : Dims<NF, CQ>::MTI;
+    float sx[R][NF], se[R][NF];
+    f4 a1[K4], b1, a2t[OTL], a1t[NGI];
+};
+template <int NF, int CQ, int R>
+__device__ __forceinline__ void load_bwd_pre(const float *__restrict__ W, const Geo &g, int lane, const float *__restrict__ scr,
+                                             int net, int ht_lo, BwdPre<NF, CQ, R> &p) {
+    using P = BwdPre<NF, CQ, R>;
+    constexpr int K4 = P::K4, OTL = P::OTL, NGI = P::NGI;
+    constexpr bool X4 = (NF == 2) && kUseX4;
+    const int q = lane >> 4, HT = g.HT;
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            p.sx[rt][f] = scr[((rt * 2 * NF) + f) * 64 + lane];
+            p.se[rt][f] = scr[((rt * 2 * NF) + NF + f) * 64 + lane];
+        }
+    const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
+    const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
+    const float *pA2T = W + g.oA2T + ((size_t)net * HT * OTL * 64 + lane) * 4;
+    const float *pA1T = W + (X4 ? g.oA1X : g.oA1T) + ((size_t)net * HT * NGI * 64 + lane) * 4;
+#pragma unroll
+    for (int k4 = 0; k4 < K4; ++k4) p.a1[k4] = *opaque(pA1 + ((size_t)ht_lo * K4 + k4) * 256);
+    p.b1 = *opaque(pB1 + ht_lo * 16);
+#pragma unroll
+    for (int o = 0; o < OTL; ++o) p.a2t[o] = *opaque(pA2T + ((size_t)ht_lo * OTL + o) * 256);
+#pragma unroll
+    for (int m = 0; m < NGI; ++m) p.a1t[m] = *opaque(pA1T + ((size_t)ht_lo * NGI + m) * 256);
+}
+
 template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false, int WV = kWaves>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
                                           const float *__restrict__ scr, float *lds, float *tb,
                                           float *gp_layer, bool first, Stamps &stp, float *xown,
-                                          const float *xother, int tile_lo = 0, int tile_hi = -1) {
+                                          const float *xother, int tile_lo, int tile_hi,
+                                          BwdPre<NF, CQ, R> &pre_ref, bool use_pre, const float *__restrict__ Wprev = nullptr,
+                                          const float *__restrict__ scr_prev = nullptr) {
+    BwdPre<NF, CQ, R> *const pre = &pre_ref;       // (a reference + flag, not a nullable pointer: the record must stay in registers)
+    // pre (tile split only): this layer's opening loads, made by the caller / the layer above; Wprev, scr_prev (nullable):
+    // the layer below, whose opening loads are requested here before the input-gradient rendezvous
     // NS == 2 (tile split, k_mfma_train_ts): every wave of the workgroup holds the same row tiles; this wave owns net
     // wave >> 2 and the hidden tiles [tile_lo, tile_hi) of it, writes their weight gradients straight to gp_layer (no
     // other wave has them) and adds its input-gradient share to those of all kTsWaves waves (xother = the record base).
@@ -181,8 +221,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     for (int rt = 0; rt < R; ++rt) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const float sx = scr[((rt * 2 * NF) + f) * 64 + lane];
-            const float se = scr[((rt * 2 * NF) + NF + f) * 64 + lane];
+            const float sx = (TS && use_pre) ? pre->sx[rt][f] : scr[((rt * 2 * NF) + f) * 64 + lane];
+            const float se = (TS && use_pre) ? pre->se[rt][f] : scr[((rt * 2 * NF) + NF + f) * 64 + lane];
             const int e = 2 * f + 1 - PC;
             const float gyv = gy[rt][e];
             const float gt = gyv;                                  // (1-m) * gy
@@ -273,6 +313,20 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         const float *pA2T = W + (BX ? g.oA2TS : g.oA2T) + ((size_t)net * HT * NA2 * 64 + lane) * 4;
         const float *pA1T = W + (X4 ? g.oA1X : g.oA1T) + ((size_t)net * HT * NGI * 64 + lane) * 4;
         f4 a1[NA1], a2t[NA2], a1t[NGI], b1;
+        bool have = false;
+        if constexpr (TS && !BX) {
+            if (use_pre) {          // loaded ahead (BwdPre)
+                have = true;
+#pragma unroll
+                for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = pre->a1[k4];
+                b1 = pre->b1;
+#pragma unroll
+                for (int o = 0; o < NA2; ++o) a2t[o] = pre->a2t[o];
+#pragma unroll
+                for (int m = 0; m < NGI; ++m) a1t[m] = pre->a1t[m];
+            }
+        }
+        if (!have) {
 #pragma unroll
         for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)ht_lo * NA1 + k4) * 256);
         b1 = *reinterpret_cast<const f4 *>(pB1 + ht_lo * 16);
@@ -280,6 +334,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         for (int o = 0; o < NA2; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)ht_lo * NA2 + o) * 256);
 #pragma unroll
         for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)ht_lo * NGI + m) * 256);
+        }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
             f4 na1[NA1], na2t[NA2], na1t[NGI], nb1;
@@ -531,6 +586,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             if (role == 0) net_pass(std::integral_constant<int, 0>{});
             else net_pass(std::integral_constant<int, 1>{});
         }
+        // the layer below: request what its backward opens with, now, ahead of the rendezvous at the end of this one
+        if (use_pre && Wprev) load_bwd_pre<NF, CQ, R>(Wprev, g, lane, scr_prev, role, ht_lo, *pre);
         if (wave == 0) {         // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
 #pragma unroll
             for (int ot = 0; ot < NT2; ++ot)
@@ -681,7 +738,7 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
 #pragma unroll
                 for (int u = 0; u < 2 * NF; ++u) gy[rt][u] = xr[rt][u] * sc;
             }
-            gld[rt] = sd.gld ? (valid[rt] ? sd.gld[base + rt * 16 + r] : 0.f) : -sc;       // rnvp_backward: the caller's d loss / d logdet
+            gld[rt] = -sc;                      // (per-row seeds, rnvp_backward: the tile-split kernel below; see backward_rows_ok)
         }
         STAMP_ADD(stp.fwd, t0);
         for (int l = L - 1; l >= 0 && !(kAblate & 16); --l) {
@@ -691,14 +748,9 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *xb = xbuf + (size_t)(l & 1) * NW * XW;
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp);
-        }
-        if (sd.gx && role == 0) {               // rnvp_backward: d loss / d x of the batch rows (gy after the first layer's backward)
-            const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt)
-                if (valid[rt]) store_row<NF>(sd.gx, base + rt * 16 + r, g.d, fullg, q, gy[rt]);
+            BwdPre<NF, CQ, R> nopre;            // (tile-split kernel only)
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
@@ -815,12 +867,17 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         load_row<NF, CQ>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
         ld[rt] = 0.f;
     }
+    // a layer's opening loads are requested one layer ahead (TilePre / BwdPre); d > 32 has no registers for that (spills)
+    constexpr bool PRE = NF <= 4;
+    TilePre<NF, CQ> pre;
+    if (PRE && tile_hi > tile_lo) load_tile_pre<NF, CQ>(wp, g, lane, (wave >> 2) * g.HT + tile_lo, tile_hi - tile_lo, pre);
     for (int l = 0; l < L; ++l) {
         const float *W = wp + (size_t)l * g.layer_floats;
+        const float *Wn = l + 1 < L ? W + g.layer_floats : nullptr;
         float *scr = scratch + (size_t)l * R * 2 * NF * 64;
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
-        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
-        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr);
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE);
+        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE);
     }
     __syncthreads();        // wave 0's scratch records; the rendezvous buffers change hands
     float wave_sum = 0.f;
@@ -850,13 +907,20 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         }
         gld[rt] = sd.gld ? (valid[rt] ? sd.gld[row0 + rt * 16 + r] : 0.f) : -sc;
     }
+    BwdPre<NF, CQ, R> bpre;          // a layer's opening loads, requested one layer ahead
+    const bool have_tiles = PRE && tile_hi > tile_lo;
+    if (have_tiles)
+        load_bwd_pre<NF, CQ, R>(wp + (size_t)(L - 1) * g.layer_floats, g, lane, scratch + (size_t)(L - 1) * R * 2 * NF * 64, wave >> 2,
+                                tile_lo, bpre);
     for (int l = L - 1; l >= 0; --l) {
         const float *W = wp + (size_t)l * g.layer_floats;
         const float *scr = scratch + (size_t)l * R * 2 * NF * 64;
         float *gpl = gpart + (size_t)l * glayer_floats;
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
-        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
-        else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi);
+        const float *Wp = l > 0 ? W - g.layer_floats : nullptr;
+        const float *sp = l > 0 ? scr - (size_t)R * 2 * NF * 64 : nullptr;
+        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp);
+        else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp);
     }
     if (sd.gx && wave == 0) {                   // rnvp_backward: d loss / d x (every wave holds the same sums)
         const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
@@ -1176,6 +1240,12 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
                                          kWaves * per_wave * sizeof(float), sd);
 }
 
+// rows the tile-split kernel takes for a geometry (launch_train below)
+static int64_t ts_max_rows(const Geo &g) {
+    if (!RNVP_TILE_SPLIT || g.HT < 3) return 0;
+    return g.NF == 2 ? RNVP_TS_MAX_ROWS : RNVP_TS_MAX_ROWS / 2;
+}
+
 template <int NF, int CQ>
 int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                  const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
@@ -1212,6 +1282,15 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
 
 }  // namespace
 
+// rnvp_backward (per-row d loss / d logdet, d loss / d x out) is served by the tile-split kernel only: the row-parallel
+// kernels have no register to spare for the extra output (measured: +64 B of scratch per lane in the C2 kernel).  Larger
+// calls go to the any-shape MFMA kernels (rnvp_lmm.hip), which take every shape.
+bool backward_rows_ok(const KShape &k, int64_t n) {
+    if (!train_supported(k)) return false;
+    const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
+    return n <= ts_max_rows(g);
+}
+
 bool train_supported(const KShape &k) {
     if (!supported(k)) return false;
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
@@ -1239,6 +1318,7 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
                           Seeds sd = Seeds{}) {
     if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
+    if ((sd.gld || sd.gx) && n > ts_max_rows(g)) return RNVP_EUNSUPPORTED;       // see backward_rows_ok
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return RNVP_EUNSUPPORTED;
     char *w = static_cast<char *>(ws);

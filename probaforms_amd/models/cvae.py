@@ -319,10 +319,16 @@ class CVAE(GenModel):
                     eps = eps_all[s:e] if host_noise else _rank0(self._device_eps(B))
                     g = core.grads()
                     lo, hi = (s, e) if world == 1 else shard_bounds(s, e, rank, world)
+                    if world == 1:          # loss + gradient + Adam in one call (the optimizer fused into the last kernel)
+                        self.opt.step_count += 1
+                        _hip.cvae_train_step(core.shape, core.sync(), Xd, Cd, perm[lo:hi], eps[lo - s:hi - s], hi - lo, 1.0 / B,
+                                             self.KL_weight, g[:core.P], g[core.P:core.P + 1], self.opt.exp_avg[:core.P],
+                                             self.opt.exp_avg_sq[:core.P], lr, b1, b2, eps_adam, wd, self.opt.step_count,
+                                             core.workspace(B))
+                        continue
                     _hip.cvae_loss_grad(core.shape, core.sync(), Xd, Cd, perm[lo:hi], eps[lo - s:hi - s], hi - lo,
                                         1.0 / B, self.KL_weight, g[:core.P], g[core.P:core.P + 1], core.workspace(B))
-                    if world > 1:
-                        all_reduce_sum(g[:core.P + 1])
+                    all_reduce_sum(g[:core.P + 1])
                     self.opt.step_count += 1
                     _hip.adam_step(core.sync(), g[:core.P], self.opt.exp_avg[:core.P], self.opt.exp_avg_sq[:core.P],
                                    core.P, lr, b1, b2, eps_adam, wd, self.opt.step_count)

@@ -130,6 +130,13 @@ def test_loss_grad_and_adam(name, path):
         assert abs(float(loss) - g["adam_loss"][step]) < 5e-5 * max(1.0, abs(float(loss)))
         _hip.adam_step(p, grad, m, v, P, 0.01, 0.9, 0.999, 1e-8, 0.0, step + 1)
         assert np.abs(p.cpu().numpy() - g["adam_p"][step]).mean() < 2e-6
+    # the fused step (cvae_train_step: optimizer inside the scatter kernel on the MFMA path) walks the same trajectory, bit for bit
+    p2 = _dev(g["init_params"]).clone(); m2 = torch.zeros(P, device="cuda"); v2 = torch.zeros(P, device="cuda")
+    g2 = torch.empty(P, device="cuda"); l2 = torch.empty(1, device="cuda")
+    for step in range(3):
+        _hip.cvae_train_step(shape, p2, x, cc, None, _dev(g["adam_eps"][step]), n, 1.0 / n, klw, g2, l2, m2, v2,
+                             0.01, 0.9, 0.999, 1e-8, 0.0, step + 1, ws)
+    assert torch.equal(p2, p) and torch.equal(m2, m) and torch.equal(v2, v)
 
 
 @pytest.mark.parametrize("name", ["default", "nocond", "relu_mh"])
