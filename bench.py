@@ -56,7 +56,8 @@ BATCH = 65_536
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # split-bf16 GEMM1 (precision 'bx3'): six bf16 products per f32 product on the dense bf16 MFMA peak (16x the f32 one)
 BX3_EFFECTIVE_TFLOPS = 16.0 * F32_MFMA_PEAK_TFLOPS / 6.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")             # the C2 step (this command, default workload)
+TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r03_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
 
 
 def mixed_bound_seconds_per_row(d, c, hidden, L, passes=1):
@@ -113,13 +114,13 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, traffic_file=None):
     """HBM bytes per launch of a kernel from the committed PMC profile of this same command
     (scripts/gpu_traffic.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled per
     MI355X_MICROARCH.md).  bench.py cannot collect counters itself; the file's number is reported only while
     it was taken with exactly these kernel sources (csrc_hash) and names this kernel, else None."""
     try:
-        d = json.load(open(TRAFFIC_FILE))
+        d = json.load(open(traffic_file or TRAFFIC_FILE))
     except (OSError, ValueError):
         return None
     if d.get("csrc_hash") != csrc_hash():
@@ -562,13 +563,17 @@ def main():
         mixed = mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS)
         if do_fit:
             roof = {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": train_tf / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(kname),
+                    "frac": train_tf / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": pmc_traffic("k_mfma_train<2, 1, 4") if args.workload == "c2" else
+                               (pmc_traffic("k_mfma_train_wide<4, 2", TRAFFIC_FILE_C3C4) if args.workload == "c3" else None),
                     "kernel": "%s (fused forward+backward): %d launches in the timed region, %.3f ms avg (15 of every 16 "
                               "on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch"
                               % (kname, n_train, train_ms / n_train, 3 * f1, N_ROWS)}
         else:           # sampling only (C4): the inverse kernel is the dominant one
             roof = {"bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(flow_kernel),
+                    "frac": inv_tf / F32_MFMA_PEAK_TFLOPS,
+                    # the committed PMC profile has this kernel at 1M rows per launch; scaled to this launch's rows
+                    "traffic": (lambda t: None if t is None else t * N_ROWS / 1048576.0)(pmc_traffic("k_flow_bx3<8, 4, 2, true", TRAFFIC_FILE_C3C4)),
                     "frac_mixed_bound": mixed * N_ROWS * args.steps / (inv_ms * 1e-3) if flow_bx3 else None,
                     "kernel": "%s inverse with the prior drawn in-kernel: %d launches of %d rows in the timed region, %.3f ms avg, "
                               "%d useful flop/row; `frac` prices it against the f32 MFMA peak, `frac_mixed_bound` against the "

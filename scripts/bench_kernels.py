@@ -23,7 +23,7 @@ def main():
     for name in which:
         L, d, c, h = CONFIGS[name]
         n = int(os.environ.get("N", 1 << 20))
-        shape = _hip.RnvpShape.make(L, d, c, (h,), os.environ.get("ACT", "tanh"), alt_masks=1,
+        shape = _hip.RnvpShape.make(L, d, c, (h,), os.environ.get("ACT", "tanh"), alt_masks=1, precision=os.environ.get("PREC") or None,
                                     small_calls=_hip.SMALL_CALLS[os.environ.get("SMALL", "invariant")])
         P = _hip.param_count(shape)
         g = torch.Generator(device="cuda").manual_seed(0)
