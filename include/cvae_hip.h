@@ -28,15 +28,18 @@ typedef struct cvae_shape {
     int32_t n_hidden;     /* len(hidden)                                              */
     int32_t hidden[8];
     int32_t act;          /* 0 tanh, 1 relu                             cvae.py:26-32   */
-    int32_t family;       /* 0: the MFMA kernels where the shape allows; 1: the generic kernels (per call;
-                             test / measurement aid: both are checked against the oracle)                */
+    int32_t family;       /* RNVP_FAMILY_* (rnvp_hip.h), per call.  0 AUTO: the register-chained MFMA kernels where the
+                             shape allows, else the any-shape MFMA kernels (RNVP_PATH_LMM) while a 16-row tile's LDS
+                             image fits, else one thread per row; 1 VALU: always one thread per row; 2 LMM: the
+                             any-shape MFMA kernels also where AUTO would pick the register-chained ones (test /
+                             measurement aid: every path is checked against the oracle)                          */
 } cvae_shape;
 
 size_t cvae_param_count(const cvae_shape *shape);
 size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows);
 
-/* RNVP_PATH_MFMA (d <= 16, c <= 4, lat <= 4, one tanh hidden layer, shape->family == 0) or RNVP_PATH_GENERIC: which
- * kernels cvae_loss_grad runs for this shape. */
+/* RNVP_PATH_MFMA (d <= 16, c <= 4, lat <= 4, one tanh hidden layer, shape->family == 0), RNVP_PATH_LMM (any depth, width,
+ * activation, d, c, lat whose tile image fits the 160 KB of LDS) or RNVP_PATH_GENERIC: which kernels cvae_loss_grad runs. */
 int cvae_kernel_path(const cvae_shape *shape);
 
 /* loss = KL_weight * (1/B) sum_b KL_b + (1/(B d)) sum_{b,j} (x - x_rec)^2 with 1/B = inv_B, and its

@@ -93,7 +93,8 @@ class CvaeShape(C.Structure):
         for i, h in enumerate(hidden):
             s.hidden[i] = h
         s.act = 0 if activation == "tanh" else 1       # cvae.py:26-32
-        s.family = {"auto": 0, "generic": 1}[family]   # per call: pin the generic kernels (test / measurement aid)
+        # per call (test / measurement aid): "generic" pins one thread per row, "lmm" the any-shape MFMA kernels
+        s.family = {"auto": 0, "generic": 1, "lmm": 2}[family]
         return s
 
 
@@ -362,7 +363,7 @@ def cvae_workspace_bytes(shape, max_rows):
 
 
 def cvae_kernel_path(shape):
-    """PATH_MFMA / PATH_GENERIC: the kernels cvae_loss_grad runs for this shape"""
+    """PATH_MFMA / PATH_LMM / PATH_GENERIC: the kernels cvae_loss_grad runs for this shape"""
     return int(lib().cvae_kernel_path(C.byref(shape)))
 
 

@@ -6,18 +6,13 @@
 #include "../../include/cvae_hip.h"
 #include "rnvp_common.h"
 #include "rnvp_generic_net.h"
+#include "rnvp_lmm.h"
 
 namespace rnvp {
 namespace {
 
 constexpr int kMaxGrid = 512, kMaxGridTrain = 256;
 constexpr size_t kLdsHard = 160 * 1024 - 1024;
-
-struct CvaeK {
-    KShape enc, dec;      // enc: (d+c) -> hidden.. -> 2*lat ; dec: (lat+c) -> hidden.. -> d
-    int d, c, lat;
-    int pe;               // floats of the encoder block (decoder parameters start here)
-};
 
 int make_mlp(int nin, const int32_t *hidden, int nh, int nout, int act, int dgrad, KShape *k) {
     std::memset(k, 0, sizeof(*k));
@@ -40,6 +35,7 @@ int make_mlp(int nin, const int32_t *hidden, int nh, int nout, int act, int dgra
 
 int make_cvae(const cvae_shape *s, CvaeK *k) {
     if (!s || s->d < 1 || s->c < 0 || s->lat < 1 || s->n_hidden < 1 || s->n_hidden > 8) return RNVP_EINVAL;
+    if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM) return RNVP_EINVAL;
     k->d = s->d; k->c = s->c; k->lat = s->lat;
     int rc = make_mlp(s->d + s->c, s->hidden, s->n_hidden, 2 * s->lat, s->act, 0, &k->enc);
     if (rc) return rc;
@@ -188,13 +184,18 @@ size_t cvae_param_count(const cvae_shape *shape) {
     return (size_t)k.enc.npn + k.dec.npn;
 }
 
-// shape->family == 1 pins the generic kernels for this call (cvae_hip.h)
-static bool use_mfma(const cvae_shape *shape) { return shape->family == 0 && cvae_mfma::supported(shape); }
+// shape->family (cvae_hip.h): 0 = the register-chained MFMA kernels where the shape allows, else the any-shape MFMA kernels
+// (rnvp_lmm.hip) while a tile's LDS image fits, else one thread per row; 1 pins the latter, 2 the any-shape MFMA kernels
+static bool use_mfma(const cvae_shape *shape) { return shape->family == RNVP_FAMILY_AUTO && cvae_mfma::supported(shape); }
+static bool use_lmm(const cvae_shape *shape, const CvaeK &k, int op) {
+    return shape->family != RNVP_FAMILY_VALU && !use_mfma(shape) && lmm::cvae_fits(k, op);
+}
 
 int cvae_kernel_path(const cvae_shape *shape) {
     CvaeK k;
     if (make_cvae(shape, &k) != RNVP_OK) return RNVP_EINVAL;
-    return use_mfma(shape) ? RNVP_PATH_MFMA : RNVP_PATH_GENERIC;
+    if (use_mfma(shape)) return RNVP_PATH_MFMA;
+    return use_lmm(shape, k, RNVP_OP_TRAIN) ? RNVP_PATH_LMM : RNVP_PATH_GENERIC;
 }
 
 static size_t generic_cvae_workspace(const CvaeK &k) {
@@ -203,11 +204,11 @@ static size_t generic_cvae_workspace(const CvaeK &k) {
 }
 
 size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows) {
-    (void)max_rows;
     CvaeK k;
     if (make_cvae(shape, &k) != RNVP_OK) return 0;
-    size_t b = generic_cvae_workspace(k);                       // either path may run (shape->family)
+    size_t b = generic_cvae_workspace(k);                       // any path may run (shape->family)
     if (cvae_mfma::supported(shape)) { const size_t m = cvae_mfma::workspace_bytes(shape) + 256; if (m > b) b = m; }
+    if (lmm::cvae_fits(k, RNVP_OP_TRAIN)) { const size_t m = lmm::cvae_workspace_bytes(k, max_rows) + 256; if (m > b) b = m; }
     return b;
 }
 
@@ -230,6 +231,9 @@ int cvae_loss_grad(void *stream, const cvae_shape *shape, const float *params, c
     if (use_mfma(shape))
         return cvae_mfma::loss_grad(st, shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out,
                                     workspace, workspace_bytes);
+    if (use_lmm(shape, k, RNVP_OP_TRAIN))
+        return lmm::cvae_loss_grad(st, k, params, x, c, row_index, eps, n_rows, inv_B, kl_weight, grad_out, loss_out, workspace,
+                                   workspace_bytes);
     int TB; size_t lds;
     if (!pick_tb(train_floats_per_row(k), n_rows, &TB, &lds)) return RNVP_EUNSUPPORTED;
     rc = allow(k_cvae_train, g_attr_train);
@@ -283,6 +287,9 @@ int cvae_decode(void *stream, const cvae_shape *shape, const float *params, cons
     if (workspace && use_mfma(shape))
         return cvae_mfma::forward(static_cast<hipStream_t>(stream), shape, params, false, z, c, n_rows, x_out, nullptr,
                                   workspace, workspace_bytes);
+    if (workspace && use_lmm(shape, k, RNVP_OP_INVERSE))
+        return lmm::cvae_forward(static_cast<hipStream_t>(stream), k, params, false, z, c, n_rows, x_out, nullptr, workspace,
+                                 workspace_bytes);
     int TB; size_t lds;
     const size_t fpr = (size_t)(k.lat + k.c) + 2 * k.dec.hmax + k.d;
     if (!pick_tb(fpr, n_rows, &TB, &lds)) return RNVP_EUNSUPPORTED;
@@ -306,6 +313,9 @@ int cvae_encode(void *stream, const cvae_shape *shape, const float *params, cons
     if (workspace && use_mfma(shape))
         return cvae_mfma::forward(static_cast<hipStream_t>(stream), shape, params, true, x, c, n_rows, mu_out, log_sigma_out,
                                   workspace, workspace_bytes);
+    if (workspace && use_lmm(shape, k, RNVP_OP_FORWARD))
+        return lmm::cvae_forward(static_cast<hipStream_t>(stream), k, params, true, x, c, n_rows, mu_out, log_sigma_out, workspace,
+                                 workspace_bytes);
     int TB; size_t lds;
     const size_t fpr = (size_t)(k.d + k.c) + 2 * k.enc.hmax + 2 * k.lat;
     if (!pick_tb(fpr, n_rows, &TB, &lds)) return RNVP_EUNSUPPORTED;

@@ -41,7 +41,13 @@ using mfma::kTanhScale;
 using mfma::kSeg;
 using mfma::k_sum_segments;
 
-constexpr int kWaves = 4, kR = 4, kMaxGrid = 512, kFT = 8;
+#ifndef CVAE_R
+#define CVAE_R 4
+#endif
+#ifndef CVAE_FT
+#define CVAE_FT 8
+#endif
+constexpr int kWaves = 4, kR = CVAE_R, kMaxGrid = 512, kFT = CVAE_FT;
 
 struct CG {                      // geometry + offsets (floats)
     int d, c, lat, h, HT;

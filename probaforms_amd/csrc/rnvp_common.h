@@ -96,6 +96,14 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
 int generic_reduce_partials(hipStream_t st, const float *gpart, const float *losspart, int G, size_t P,
                             float loss_scale, float *grad_out, float *loss_out);
 
+// Kernel-side view of cvae_shape: the two MLPs (/root/reference/probaforms/models/cvae.py:35-84) as KShapes with L = 1;
+// KShape::d counts the leading inputs that need an input gradient (encoder 0, decoder the latent), KShape::c the rest.
+struct CvaeK {
+    KShape enc, dec;      // enc: (d+c) -> hidden.. -> 2*lat ; dec: (lat+c) -> hidden.. -> d
+    int d, c, lat;
+    int pe;               // floats of the encoder block (decoder parameters start here)
+};
+
 // ---- CVAE step on MFMA: cvae_mfma.hip (d <= 16, c <= 4, latent <= 4, one tanh hidden layer) ----
 namespace cvae_mfma {
 bool supported(const ::cvae_shape *s);

@@ -8,6 +8,7 @@ namespace lmm {
 
 struct LGeo {
     int nlin;                              // Linears per net: n_hidden + 1
+    int nnets;                             // nets that share this geometry: 2 L (t, s per coupling layer); 1 for a CVAE encoder / decoder
     int nin[kMaxLin], nout[kMaxLin];
     int MT[kMaxLin], KS[kMaxLin];          // forward: out tiles (16), k-steps (4) over the inputs
     int MTt[kMaxLin], KSt[kMaxLin];        // transposed (input gradient): in tiles, k-steps over the outputs
@@ -31,6 +32,15 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
               Seeds sd);
+
+// ---- CVAE (encoder / decoder MLPs of any depth and width) on the same building blocks ---------------------------------
+// op: RNVP_OP_TRAIN (cvae_loss_grad), RNVP_OP_FORWARD (cvae_encode), RNVP_OP_INVERSE (cvae_decode)
+bool cvae_fits(const CvaeK &k, int op);
+size_t cvae_workspace_bytes(const CvaeK &k, int64_t max_rows);
+int cvae_loss_grad(hipStream_t st, const CvaeK &k, const float *params, const float *x, const float *c, const int64_t *row_index,
+                   const float *eps, int64_t n, float inv_B, float klw, float *grad_out, float *loss_out, void *ws, size_t ws_bytes);
+int cvae_forward(hipStream_t st, const CvaeK &k, const float *params, bool encode, const float *in, const float *c, int64_t n,
+                 float *out0, float *out1, void *ws, size_t ws_bytes);
 
 }  // namespace lmm
 }  // namespace rnvp

@@ -57,7 +57,7 @@ __device__ __forceinline__ void block_decode(int o, int MT, int KSp, int *m, int
 
 __global__ void __launch_bounds__(256)
 k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__restrict__ masks, float *__restrict__ packed) {
-    const int64_t total = (int64_t)s.L * 2 * g.net_floats;
+    const int64_t total = (int64_t)g.nnets * g.net_floats;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int ln = (int)(t / g.net_floats), o = (int)(t - (int64_t)ln * g.net_floats);
         const int l = ln >> 1;
@@ -70,14 +70,14 @@ k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__
             if (o >= g.offF[k] && o < g.offF[k] + g.MT[k] * g.KS[k] * 64) {
                 block_decode(o - g.offF[k], g.MT[k], g.KS[k], &m, &ks, &lane);
                 const int row = 16 * m + (lane & 15), col = 4 * ks + (lane >> 4);
-                if (row < nout && col < nin) v = W[row * nin + col] * ((k == 0 && col < s.d) ? (float)masks[l * s.d + col] : 1.f);
+                if (row < nout && col < nin) v = W[row * nin + col] * ((masks && k == 0 && col < s.d) ? (float)masks[l * s.d + col] : 1.f);
                 break;
             }
             if (o >= g.offT[k] && o < g.offT[k] + g.MTt[k] * g.KSt[k] * 64) {
                 block_decode(o - g.offT[k], g.MTt[k], g.KSt[k], &m, &ks, &lane);
                 const int out = 4 * ks + (lane >> 4), in = 16 * m + (lane & 15);
                 const int nin_eff = k == 0 ? s.d : nin;
-                if (out < nout && in < nin_eff) v = W[out * nin + in] * (k == 0 ? (float)masks[l * s.d + in] : 1.f);
+                if (out < nout && in < nin_eff) v = W[out * nin + in] * ((masks && k == 0) ? (float)masks[l * s.d + in] : 1.f);
                 break;
             }
         }
@@ -303,6 +303,44 @@ __device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot,
     }
 }
 
+// one net, backward, for the tile: on entry GA holds d loss / d (net output) and ACT the net's hidden activations
+// (net_fwd<true>).  Last Linear to first: activation derivative, dump of the weight-gradient operands (pre-activation
+// gradient + the Linear's input with a ones column) into dn, input gradient through the W^T fragments; Linear 0's goes,
+// for the first s.d inputs only, ADDED into gin (the conditioning columns get no gradient).  Ends on a barrier.
+__device__ __forceinline__ void net_bwd(const float *__restrict__ pkn, const KShape &s, const LGeo &g, const float *in0, float *ACT,
+                                        float *GA, float *GB, float *gin, float *__restrict__ dn, int lane, int wave) {
+    const int q = lane >> 4, r = lane & 15, nh = s.nh;
+    float *gcur = GA, *gprev = GB;
+    int aoff = g.hs;                                       // running feature offset of Linear k's own activation block
+    for (int k = nh; k >= 0; --k) {
+        const int nin = g.nin[k], nout = g.nout[k];
+        if (k < nh) {
+            aoff -= nout;
+            const float *ak = ACT + aoff * RS;
+            for (int f0 = q + 16 * wave; f0 < nout; f0 += 16 * kW) {          // four features per pass: overlapped LDS reads
+                float a[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + 4 * u < nout ? f0 + 4 * u : f0;
+                    a[u] = ak[f * RS + r]; gv[u] = gcur[f * RS + r];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (f0 + 4 * u < nout)
+                        gcur[(f0 + 4 * u) * RS + r] = (s.act == RNVP_ACT_TANH) ? gv[u] * (1.f - a[u] * a[u]) : (a[u] > 0.f ? gv[u] : 0.f);
+            }
+            __syncthreads();
+        }
+        const float *inp = (k == 0) ? in0 : ACT + (aoff - nin) * RS;
+        dump_tile(gcur, nout, 16 * g.MT[k], -1, dn + g.offP[k], lane, wave);
+        dump_tile(inp, nin, 16 * g.PT[k], nin, dn + g.offA[k], lane, wave);
+        if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, s.d, gcur, gin, nullptr, -1, lane, wave);
+        else linear<false>(pkn + g.offT[k], g.MTt[k], g.KSt[k], nout, nin, gcur, gprev, nullptr, -1, lane, wave);
+        __syncthreads();
+        float *tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+}
+
 // ---- loss + input-gradient chain; dumps the operands of the weight gradients -------------------------------------------
 __global__ void __launch_bounds__(64 * kW)
 k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__restrict__ params,
@@ -310,7 +348,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             const int64_t *__restrict__ row_index, int64_t n, float inv_B, Seeds sd,
             float *__restrict__ dump, float *__restrict__ xsave, float *losspart, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c, nh = s.nh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
     const int jq = q + 4 * wave, jstep = 4 * kW;           // this lane's features in the elementwise passes
     const float *__restrict__ gz = sd.gz;
     float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
@@ -377,36 +415,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
                     GA[j * RS + r] = v;
                 }
                 __syncthreads();
-                float *gcur = GA, *gprev = GB;
-                int aoff = g.hs;                                       // running feature offset of Linear k's own activation block
-                for (int k = nh; k >= 0; --k) {
-                    const int nin = g.nin[k], nout = g.nout[k];
-                    if (k < nh) {
-                        aoff -= nout;
-                        const float *ak = ACT + aoff * RS;
-                        for (int f0 = q + 16 * wave; f0 < nout; f0 += 16 * kW) {          // four features per pass: overlapped LDS reads
-                            float a[4], gv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int f = f0 + 4 * u < nout ? f0 + 4 * u : f0;
-                                a[u] = ak[f * RS + r]; gv[u] = gcur[f * RS + r];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (f0 + 4 * u < nout)
-                                    gcur[(f0 + 4 * u) * RS + r] = (s.act == RNVP_ACT_TANH) ? gv[u] * (1.f - a[u] * a[u]) : (a[u] > 0.f ? gv[u] : 0.f);
-                        }
-                        __syncthreads();
-                    }
-                    const float *inp = (k == 0) ? XC : ACT + (aoff - nin) * RS;
-                    dump_tile(gcur, nout, 16 * g.MT[k], -1, dn + g.offP[k], lane, wave);
-                    dump_tile(inp, nin, 16 * g.PT[k], nin, dn + g.offA[k], lane, wave);
-                    // input gradient: for Linear 0 only the x part, added into GIN (the mask is folded into the fragments)
-                    if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, d, gcur, GIN, nullptr, -1, lane, wave);
-                    else linear<false>(pkn + g.offT[k], g.MTt[k], g.KSt[k], nout, nin, gcur, gprev, nullptr, -1, lane, wave);
-                    __syncthreads();
-                    float *tmp = gcur; gcur = gprev; gprev = tmp;
-                }
+                net_bwd(pkn, s, g, XC, ACT, GA, GB, GIN, dn, lane, wave);
             }
             for (int j = jq; j < d; j += jstep) {
                 const float gy = GY[j * RS + r];
@@ -418,6 +427,121 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             for (int j = jq; j < d; j += jstep) sd.gx[row * d + j] = GY[j * RS + r];
     }
     if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;      // chunks run in order on one stream
+}
+
+// ---- CVAE: encoder -> reparameterize -> decoder -> KL + MSE -> backward, one 16-row tile per workgroup -----------------
+// (/root/reference/probaforms/models/cvae.py:186-199 compute_loss; the hand-derived backward of cvae_generic.hip.)
+// The encoder and the decoder are single nets (LGeo::nnets = 1) with their own geometry; the tile's LDS image is
+//   EIN [x | c]  EACT [sum hidden]  EO [mu | log_sigma]  DIN [z | c]  DACT [sum hidden]  XR [d]  EPS [lat]  GZ [lat]
+//   GA, GB [widest layer]  (+ slack, + reduction scratch)
+// and the weight gradients go through the same dump -> k_lmm_wgrad -> k_lmm_reduce pipeline, once per net.
+struct CvaeL {
+    KShape enc, dec;
+    LGeo ge, gd;
+    int d, c, lat, pe, wm;
+    size_t lds_train, lds_enc, lds_dec;
+};
+
+__global__ void __launch_bounds__(64 * kW)
+k_lmm_cvae_train(CvaeL s, const float *__restrict__ packed_e, const float *__restrict__ packed_d, const float *__restrict__ params,
+                 const float *__restrict__ x, const float *__restrict__ c, const int64_t *__restrict__ row_index,
+                 const float *__restrict__ eps, int64_t n, float inv_B, float klw, float *__restrict__ dump_e,
+                 float *__restrict__ dump_d, float *losspart, int first_chunk, int do_grad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15;
+    const int d = s.d, cd = s.c, lat = s.lat;
+    const int jq = q + 4 * wave, jstep = 4 * kW;
+    float *EIN = lds, *EACT = EIN + (d + cd) * RS, *EO = EACT + s.enc.hs * RS, *DIN = EO + 2 * lat * RS;
+    float *DACT = DIN + (lat + cd) * RS, *XR = DACT + s.dec.hs * RS, *EPS = XR + d * RS, *GZ = EPS + lat * RS;
+    float *GA = GZ + lat * RS, *GB = GA + s.wm * RS;
+    float *RED = lds + s.lds_train / sizeof(float) - 2 * kW * 16;
+    for (int e = tid; e < (int)(s.lds_train / sizeof(float)); e += 64 * kW) lds[e] = 0.f;     // see linear_mb: stale rows must be finite
+    __syncthreads();
+    const int64_t ntiles = (n + 15) / 16;
+    const float inv_d = 1.f / (float)d;
+    float wave_sum = 0.f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * 16, row = base + r;
+        const bool valid = row < n;
+        load_tile(x, row_index, base, n, d, EIN, tid);                                            // cat(X, C), cvae.py:58
+        if (cd) { load_tile(c, row_index, base, n, cd, EIN + d * RS, tid); load_tile(c, row_index, base, n, cd, DIN + lat * RS, tid); }
+        load_tile(eps, nullptr, base, n, lat, EPS, tid);                                          // eps is already in batch order
+        __syncthreads();
+        net_fwd<true>(packed_e, params, s.enc, s.ge, EIN, EACT, nullptr, EO, lane, wave);         // mu | log_sigma
+        for (int j = jq; j < lat; j += jstep)                                                     // sample_z, cvae.py:188
+            DIN[j * RS + r] = fmaf(expf(0.5f * EO[(lat + j) * RS + r]), EPS[j * RS + r], EO[j * RS + r]);
+        __syncthreads();
+        net_fwd<true>(packed_d, params + s.pe, s.dec, s.gd, DIN, DACT, nullptr, XR, lane, wave);
+        {
+            float kl = 0.f, se = 0.f;
+            for (int j = jq; j < lat; j += jstep) {
+                const float mu = EO[j * RS + r], ls = EO[(lat + j) * RS + r];
+                kl += 1.f + ls - mu * mu - expf(ls);                                              // cvae.py:191
+            }
+            for (int j = jq; j < d; j += jstep) { const float df = EIN[j * RS + r] - XR[j * RS + r]; se = fmaf(df, df, se); }
+            float lrow = klw * (-0.5f * kl) + se * inv_d;
+            lrow += __shfl_xor(lrow, 16); lrow += __shfl_xor(lrow, 32);
+            lrow = wg_row_sum(lrow, RED, lane, wave);
+            if (wave == 0) {
+                float v = (valid && q == 0) ? lrow : 0.f;
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                wave_sum -= v;                                    // k_lmm_reduce reports -(sum of partials) * inv_B
+            }
+        }
+        if (do_grad) {
+            const float sc = valid ? inv_B : 0.f;
+            for (int j = jq; j < lat; j += jstep) GZ[j * RS + r] = 0.f;
+            for (int j = jq; j < d; j += jstep)                                                   // d MSE / d x_rec
+                GA[j * RS + r] = (2.f * sc * inv_d) * (XR[j * RS + r] - EIN[j * RS + r]);
+            __syncthreads();
+            net_bwd(packed_d, s.dec, s.gd, DIN, DACT, GA, GB, GZ, dump_d + (size_t)tile * s.gd.dump_floats, lane, wave);
+            for (int j = jq; j < lat; j += jstep) {
+                const float mu = EO[j * RS + r], ls = EO[(lat + j) * RS + r], gv = GZ[j * RS + r];
+                GA[j * RS + r] = fmaf(klw * sc, mu, gv);                                          // d / d mu
+                GA[(lat + j) * RS + r] = gv * EPS[j * RS + r] * 0.5f * expf(0.5f * ls)            // d / d log_sigma
+                                         + klw * sc * (-0.5f) * (1.f - expf(ls));
+            }
+            __syncthreads();
+            net_bwd(packed_e, s.enc, s.ge, EIN, EACT, GA, GB, GZ, dump_e + (size_t)tile * s.ge.dump_floats, lane, wave);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;
+}
+
+// encoder (mu, log_sigma) or decoder (x_rec) alone: cvae.py:58-62 / 81-84
+template <bool ENCODE>
+__global__ void __launch_bounds__(64 * kW)
+k_lmm_cvae_mlp(CvaeL s, const float *__restrict__ packed, const float *__restrict__ params, const float *__restrict__ a,
+               const float *__restrict__ c, int64_t n, float *__restrict__ out0, float *__restrict__ out1) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const KShape &m = ENCODE ? s.enc : s.dec;
+    const LGeo &g = ENCODE ? s.ge : s.gd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = ENCODE ? s.d : s.lat, cd = s.c, no = ENCODE ? 2 * s.lat : s.d;
+    const size_t bytes = ENCODE ? s.lds_enc : s.lds_dec;
+    float *IN = lds, *H0 = IN + (na + cd) * RS, *H1 = H0 + m.hmax * RS, *O = H1 + m.hmax * RS;
+    for (int e = tid; e < (int)(bytes / sizeof(float)); e += 64 * kW) lds[e] = 0.f;
+    __syncthreads();
+    const float *pn = ENCODE ? params : params + s.pe;
+    const int64_t ntiles = (n + 15) / 16;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * 16;
+        load_tile(a, nullptr, base, n, na, IN, tid);
+        if (cd) load_tile(c, nullptr, base, n, cd, IN + na * RS, tid);
+        __syncthreads();
+        net_fwd<false>(packed, pn, m, g, IN, H0, H1, O, lane, wave);
+        for (int e = tid; e < 16 * no; e += 64 * kW) {
+            const int rr = e / no, j = e - rr * no;
+            if (base + rr < n) {
+                const float v = O[j * RS + rr];
+                if (!ENCODE) out0[(base + rr) * no + j] = v;
+                else if (j < s.lat) out0[(base + rr) * s.lat + j] = v;
+                else out1[(base + rr) * s.lat + (j - s.lat)] = v;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ---- weight gradients: dW[k] tile (m, p) = sum over rows gP[row][16m + i] * act[row][16p + j] ---------------------------
@@ -435,7 +559,7 @@ k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, fl
     const int pb2 = (g.PT[k] + 1) >> 1;
     const int m0 = 2 * (quad / pb2), p0 = 2 * (quad % pb2);
     const bool m1 = m0 + 1 < g.MT[k], p1 = p0 + 1 < g.PT[k];
-    const size_t tstride = (size_t)s.L * 2 * g.dump_floats;
+    const size_t tstride = (size_t)g.nnets * g.dump_floats;
     const float *pa = dump + (size_t)ln * g.dump_floats + g.offP[k] + m0 * 256 + i * 16 + 4 * q;
     const float *pb = dump + (size_t)ln * g.dump_floats + g.offA[k] + p0 * 256 + i * 16 + 4 * q;
     f4 acc[2][2];
@@ -457,7 +581,7 @@ k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, fl
             acc[1][1] = mfma16(a1[ks], b1[ks], acc[1][1]);
         }
     }
-    float *dst = gpart + ((size_t)blockIdx.y * s.L * 2 + ln) * g.gnet_floats + g.offG[k] + lane * 4;
+    float *dst = gpart + ((size_t)blockIdx.y * g.nnets + ln) * g.gnet_floats + g.offG[k] + lane * 4;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -472,7 +596,7 @@ k_lmm_wgrad(KShape s, LGeo g, const float *__restrict__ dump, int64_t ntiles, fl
 __global__ void __launch_bounds__(256)
 k_lmm_reduce(KShape s, LGeo g, const float *__restrict__ gpart, int S, const uint8_t *__restrict__ masks,
              const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss) {
-    const size_t P = (size_t)2 * s.npn * s.L;
+    const size_t P = (size_t)g.nnets * s.npn;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) {
         if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
@@ -493,12 +617,12 @@ k_lmm_reduce(KShape s, LGeo g, const float *__restrict__ gpart, int S, const uin
     float scale = 1.f;
     if (idx < s.boff[k]) {
         o = (idx - s.woff[k]) / nin; in = (idx - s.woff[k]) - o * nin;
-        if (k == 0 && in < s.d) scale = (float)masks[l * s.d + in];          // W'[:, j] = W[:, j] * mask_j
+        if (masks && k == 0 && in < s.d) scale = (float)masks[l * s.d + in];          // W'[:, j] = W[:, j] * mask_j
     } else { o = idx - s.boff[k]; in = nin; }                                // bias: the ones column
     const int m = o >> 4, pt = in >> 4;
     const int loc = g.offG[k] + (m * g.PT[k] + pt) * 256 + ((((o & 15) >> 2) * 16) + (in & 15)) * 4 + (o & 3);
     const float *src = gpart + (size_t)ln * g.gnet_floats + loc;
-    const size_t stride = (size_t)s.L * 2 * g.gnet_floats;
+    const size_t stride = (size_t)g.nnets * g.gnet_floats;
     float a = 0.f;
     for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];
     grad[p] = a * scale;
@@ -514,6 +638,7 @@ LGeo make_lgeo(const KShape &k) {
     LGeo g;
     std::memset(&g, 0, sizeof(g));
     g.nlin = k.nh + 1;
+    g.nnets = 2 * k.L;
     int oW = 0, oG = 0, oD = 0, pairs = 0, quads = 0;
     for (int i = 0; i < g.nlin; ++i) {
         g.nin[i] = k.nin[i]; g.nout[i] = k.nout[i];
@@ -658,6 +783,154 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_
     const size_t P = (size_t)2 * k.npn * k.L;
     hipLaunchKernelGGL(k_lmm_reduce, dim3((unsigned)(P / 256 + 2)), dim3(256), 0, st, k, g, gpart, S, masks, losspart, G, inv_B,
                        grad_out, loss_out);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+// ---- CVAE host side ------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t kCvaeLdsMax = 159 * 1024;          // one workgroup per CU at worst: still far ahead of one thread per row
+
+LGeo single_net_geo(const KShape &k) { LGeo g = make_lgeo(k); g.nnets = 1; return g; }
+
+CvaeL make_cvae_l(const CvaeK &k) {
+    CvaeL s;
+    std::memset(&s, 0, sizeof(s));
+    s.enc = k.enc; s.dec = k.dec; s.d = k.d; s.c = k.c; s.lat = k.lat; s.pe = k.pe;
+    s.ge = single_net_geo(k.enc); s.gd = single_net_geo(k.dec);
+    int wm = k.enc.hmax > k.dec.hmax ? k.enc.hmax : k.dec.hmax;
+    if (2 * k.lat > wm) wm = 2 * k.lat;
+    if (k.d > wm) wm = k.d;
+    s.wm = wm;
+    const size_t rows_train = (size_t)(k.d + k.c) + k.enc.hs + 2 * k.lat + (k.lat + k.c) + k.dec.hs + k.d + 2 * k.lat + 2 * wm + 16;
+    s.lds_train = (rows_train * RS + 2 * kW * 16) * sizeof(float);
+    s.lds_enc = ((size_t)(k.d + k.c + 2 * k.enc.hmax + 2 * k.lat + 16) * RS) * sizeof(float);
+    s.lds_dec = ((size_t)(k.lat + k.c + 2 * k.dec.hmax + k.d + 16) * RS) * sizeof(float);
+    return s;
+}
+
+int64_t cvae_chunk_rows(const CvaeL &s) {
+    const double per_row = (double)(s.ge.dump_floats + s.gd.dump_floats) * sizeof(float) / 16.0;
+    int64_t r = (int64_t)((1u << 30) / per_row) / 16 * 16;
+    if (r < 4096) r = 4096;
+    if (r > 65536) r = 65536;
+    return r;
+}
+
+int pack_net(hipStream_t st, const KShape &k, const LGeo &g, const float *params, float *packed) {
+    int blocks = (g.net_floats + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_lmm_pack, dim3(blocks), dim3(256), 0, st, k, g, params, (const uint8_t *)nullptr, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+std::atomic<uint64_t> g_attr_cvae_train{0}, g_attr_cvae_enc{0}, g_attr_cvae_dec{0};
+
+}  // namespace
+
+bool cvae_fits(const CvaeK &k, int op) {
+    const CvaeL s = make_cvae_l(k);
+    const size_t need = op == RNVP_OP_TRAIN ? s.lds_train : (op == RNVP_OP_FORWARD ? s.lds_enc : s.lds_dec);
+    return need <= kCvaeLdsMax;
+}
+
+size_t cvae_workspace_bytes(const CvaeK &k, int64_t max_rows) {
+    const CvaeL s = make_cvae_l(k);
+    if (max_rows < 1) max_rows = 1;
+    const int64_t cr = cvae_chunk_rows(s);
+    const int64_t ntiles = ((max_rows < cr ? max_rows : cr) + 15) / 16;
+    size_t b = align_up((size_t)s.ge.net_floats * sizeof(float), 256) + align_up((size_t)s.gd.net_floats * sizeof(float), 256);
+    b += align_up((size_t)kMaxGrid * sizeof(float), 256);
+    b += align_up((size_t)ntiles * s.ge.dump_floats * sizeof(float), 256) + align_up((size_t)ntiles * s.gd.dump_floats * sizeof(float), 256);
+    b += align_up((size_t)kSplits * s.ge.gnet_floats * sizeof(float), 256) + align_up((size_t)kSplits * s.gd.gnet_floats * sizeof(float), 256);
+    return b;
+}
+
+int cvae_loss_grad(hipStream_t st, const CvaeK &k, const float *params, const float *x, const float *c, const int64_t *row_index,
+                   const float *eps, int64_t n, float inv_B, float klw, float *grad_out, float *loss_out, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < cvae_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
+    const CvaeL s = make_cvae_l(k);
+    const int64_t cr = cvae_chunk_rows(s);
+    const int64_t ctiles = ((n < cr ? n : cr) + 15) / 16;
+    char *w = static_cast<char *>(ws);
+    float *packed_e = reinterpret_cast<float *>(w); w += align_up((size_t)s.ge.net_floats * sizeof(float), 256);
+    float *packed_d = reinterpret_cast<float *>(w); w += align_up((size_t)s.gd.net_floats * sizeof(float), 256);
+    float *losspart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * sizeof(float), 256);
+    float *dump_e = reinterpret_cast<float *>(w); w += align_up((size_t)ctiles * s.ge.dump_floats * sizeof(float), 256);
+    float *dump_d = reinterpret_cast<float *>(w); w += align_up((size_t)ctiles * s.gd.dump_floats * sizeof(float), 256);
+    float *gpart_e = reinterpret_cast<float *>(w); w += align_up((size_t)kSplits * s.ge.gnet_floats * sizeof(float), 256);
+    float *gpart_d = reinterpret_cast<float *>(w);
+    int rc = pack_net(st, s.enc, s.ge, params, packed_e);
+    if (rc) return rc;
+    rc = pack_net(st, s.dec, s.gd, params + s.pe, packed_d);
+    if (rc) return rc;
+    rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_cvae_train), 160 * 1024, g_attr_cvae_train);
+    if (rc) return rc;
+    const int G = grid_for(ctiles);
+    const int S = (int)(ctiles < kSplits ? ctiles : kSplits);
+    for (int64_t r0 = 0; r0 < n; r0 += cr) {
+        const int64_t rows = n - r0 < cr ? n - r0 : cr;
+        const int64_t ntiles = (rows + 15) / 16;
+        const bool first = r0 == 0;
+        const float *xc = row_index ? x : x + r0 * k.d;
+        const float *cc = (row_index || !c) ? c : c + r0 * k.c;
+        {
+            KernelTimer timer(st, RNVP_PROFILE_TRAIN);
+            hipLaunchKernelGGL(k_lmm_cvae_train, dim3(G), dim3(64 * kW), s.lds_train, st, s, packed_e, packed_d, params, xc, cc,
+                               row_index ? row_index + r0 : nullptr, eps + r0 * k.lat, rows, inv_B, klw, dump_e, dump_d, losspart,
+                               first ? 1 : 0, grad_out ? 1 : 0);
+        }
+        RNVP_HIP_TRY(hipGetLastError());
+        if (grad_out) {
+            hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)s.ge.quads_per_net, (unsigned)S), dim3(64), 0, st, s.enc, s.ge, dump_e, ntiles,
+                               gpart_e, first ? 0 : 1);
+            hipLaunchKernelGGL(k_lmm_wgrad, dim3((unsigned)s.gd.quads_per_net, (unsigned)S), dim3(64), 0, st, s.dec, s.gd, dump_d, ntiles,
+                               gpart_d, first ? 0 : 1);
+            RNVP_HIP_TRY(hipGetLastError());
+        }
+    }
+    if (!grad_out) {                                   // loss only: the same summation as with gradients (bit-identical loss)
+        if (!loss_out) return RNVP_OK;
+        LGeo none = s.ge;
+        none.nnets = 0;
+        hipLaunchKernelGGL(k_lmm_reduce, dim3(1), dim3(256), 0, st, s.enc, none, gpart_e, 0, (const uint8_t *)nullptr, losspart, G, inv_B,
+                           (float *)nullptr, loss_out);
+        RNVP_HIP_TRY(hipGetLastError());
+        return RNVP_OK;
+    }
+    hipLaunchKernelGGL(k_lmm_reduce, dim3((unsigned)(s.enc.npn / 256 + 2)), dim3(256), 0, st, s.enc, s.ge, gpart_e, S,
+                       (const uint8_t *)nullptr, losspart, G, inv_B, grad_out, loss_out);
+    hipLaunchKernelGGL(k_lmm_reduce, dim3((unsigned)(s.dec.npn / 256 + 2)), dim3(256), 0, st, s.dec, s.gd, gpart_d, S,
+                       (const uint8_t *)nullptr, losspart, G, inv_B, grad_out + s.pe, (float *)nullptr);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+int cvae_forward(hipStream_t st, const CvaeK &k, const float *params, bool encode, const float *in, const float *c, int64_t n,
+                 float *out0, float *out1, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < cvae_workspace_bytes(k, 1)) return RNVP_EWORKSPACE;
+    const CvaeL s = make_cvae_l(k);
+    char *w = static_cast<char *>(ws);
+    float *packed_e = reinterpret_cast<float *>(w); w += align_up((size_t)s.ge.net_floats * sizeof(float), 256);
+    float *packed_d = reinterpret_cast<float *>(w);
+    const int G = grid_for((n + 15) / 16);
+    if (encode) {
+        int rc = pack_net(st, s.enc, s.ge, params, packed_e);
+        if (rc) return rc;
+        rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_cvae_mlp<true>), 160 * 1024, g_attr_cvae_enc);
+        if (rc) return rc;
+        KernelTimer timer(st, RNVP_PROFILE_FORWARD);
+        hipLaunchKernelGGL(k_lmm_cvae_mlp<true>, dim3(G), dim3(64 * kW), s.lds_enc, st, s, packed_e, params, in, c, n, out0, out1);
+    } else {
+        int rc = pack_net(st, s.dec, s.gd, params + s.pe, packed_d);
+        if (rc) return rc;
+        rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_cvae_mlp<false>), 160 * 1024, g_attr_cvae_dec);
+        if (rc) return rc;
+        KernelTimer timer(st, RNVP_PROFILE_INVERSE);
+        hipLaunchKernelGGL(k_lmm_cvae_mlp<false>, dim3(G), dim3(64 * kW), s.lds_dec, st, s, packed_d, params, in, c, n, out0, out1);
+    }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }

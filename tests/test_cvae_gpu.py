@@ -43,22 +43,94 @@ def test_encode_decode(name, with_ws):
     np.testing.assert_allclose(x.cpu().numpy(), g["decoded"], rtol=2e-6, atol=2e-6)
 
 
-@pytest.fixture(params=["auto", "generic"])
+@pytest.fixture(params=["auto", "generic", "lmm"])
 def path(request):
-    """run the step on the kernels the library picks (MFMA where supported) and pinned to the generic ones
-    (cvae_shape.family, per call)"""
+    """run the step on the kernels the library picks (register-chained MFMA where supported, else any-shape MFMA) and
+    pinned to one thread per row / to the any-shape MFMA kernels (cvae_shape.family, per call)"""
     return request.param
 
 
 def test_kernel_path_selection():
     from probaforms_amd import _hip
     for name, (d, c, lat, hidden, act, _) in CASES.items():
-        want = _hip.PATH_GENERIC if name == "relu_mh" else _hip.PATH_MFMA
+        want = _hip.PATH_LMM if name == "relu_mh" else _hip.PATH_MFMA
         assert _hip.cvae_kernel_path(_hip.CvaeShape.make(d, c, lat, hidden, act)) == want
-    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(17, 4, 2, (128,), "tanh")) == _hip.PATH_GENERIC
-    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 5, 2, (128,), "tanh")) == _hip.PATH_GENERIC
-    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 5, (128,), "tanh")) == _hip.PATH_GENERIC
+        assert _hip.cvae_kernel_path(_hip.CvaeShape.make(d, c, lat, hidden, act, family="lmm")) == _hip.PATH_LMM
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(17, 4, 2, (128,), "tanh")) == _hip.PATH_LMM
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 5, 2, (128,), "tanh")) == _hip.PATH_LMM
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 5, (128,), "tanh")) == _hip.PATH_LMM
     assert _hip.cvae_kernel_path(_hip.CvaeShape.make(16, 4, 2, (128,), "tanh", family="generic")) == _hip.PATH_GENERIC
+    # a tile whose LDS image does not fit one CU stays on one thread per row (or is refused there)
+    assert _hip.cvae_kernel_path(_hip.CvaeShape.make(10, 5, 10, (700, 700), "relu")) == _hip.PATH_GENERIC
+
+
+LMM_SHAPES = [(5, 3, 2, (10,), "tanh"), (4, 2, 3, (7, 9), "relu"), (10, 5, 10, (128, 128), "relu"), (33, 0, 17, (64, 20, 40), "tanh"),
+              (1, 0, 1, (1,), "tanh"), (70, 20, 6, (100,), "tanh"), (10, 5, 10, (256, 256), "relu")]
+
+
+@pytest.mark.parametrize("d,c,lat,hidden,act", LMM_SHAPES)
+@pytest.mark.parametrize("n", [1, 63, 1000])
+def test_lmm_step_shapes_vs_oracle(d, c, lat, hidden, act, n):
+    """the any-shape MFMA kernels (rnvp_lmm.hip) on the shapes the register-chained ones do not take -- several hidden
+    layers, relu, wide layers, d > 16, latent > 4 -- and on ragged row tiles: loss, gradient, encoder, decoder ==
+    float64 oracle; loss-only call == the loss of the gradient call; run-to-run bit-identical"""
+    from oracle import CvaeOracle, CvaeShape
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(d * 1000 + sum(hidden) + n)
+    shape = _hip.CvaeShape.make(d, c, lat, hidden, act, family="lmm")
+    assert _hip.cvae_kernel_path(shape) == _hip.PATH_LMM
+    P = _hip.cvae_param_count(shape)
+    p = (rng.standard_normal(P) * 0.2).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    C = rng.standard_normal((n, c)).astype(np.float32) if c else None
+    eps = rng.standard_normal((n, lat)).astype(np.float32)
+    o = CvaeOracle(64); so = CvaeShape.make(d, c, lat, hidden, act)
+    lo, go = o.loss_grad(so, p, X, C, eps, 0.3)
+    ws = torch.empty(_hip.cvae_workspace_bytes(shape, n), dtype=torch.uint8, device="cuda")
+    grad = torch.full((P,), float("nan"), device="cuda"); loss = torch.empty(1, device="cuda")
+    _hip.cvae_loss_grad(shape, _dev(p), _dev(X), _dev(C), None, _dev(eps), n, 1.0 / n, 0.3, grad, loss, ws)
+    assert abs(float(loss) - lo) < 5e-6 * max(1.0, abs(lo))
+    assert np.abs(grad.cpu().numpy() - go).max() < 5e-6 * np.abs(go).max()
+    g2 = torch.empty_like(grad); l2 = torch.empty(1, device="cuda")
+    _hip.cvae_loss_grad(shape, _dev(p), _dev(X), _dev(C), None, _dev(eps), n, 1.0 / n, 0.3, g2, l2, ws)
+    assert torch.equal(grad, g2) and float(l2) == float(loss)
+    l3 = torch.empty(1, device="cuda")
+    _hip.cvae_loss_grad(shape, _dev(p), _dev(X), _dev(C), None, _dev(eps), n, 1.0 / n, 0.3, None, l3, ws)
+    assert float(l3) == float(loss)
+    mu = torch.empty(n, lat, device="cuda"); ls = torch.empty_like(mu); xr = torch.empty(n, d, device="cuda")
+    _hip.cvae_encode(shape, _dev(p), _dev(X), _dev(C), n, mu, ls, ws)
+    _hip.cvae_decode(shape, _dev(p), _dev(eps), _dev(C), n, xr, ws)
+    mu_o, ls_o = o.encode(so, p, X, C); x_o = o.decode(so, p, eps, C)
+    for got, want in ((mu, mu_o), (ls, ls_o), (xr, x_o)):
+        assert np.abs(got.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+
+
+def test_lmm_step_row_chunks_and_gather():
+    """a batch larger than one row chunk of the weight-gradient operands (65536 rows), gathered through row_index, ==
+    the sum of two half-batch calls (which each fit one chunk) and == the one-thread-per-row kernels"""
+    from probaforms_amd import _hip
+    d, c, lat, hidden, act, n = 4, 2, 3, (7, 9), "relu", 70001
+    rng = np.random.default_rng(5)
+    sl = _hip.CvaeShape.make(d, c, lat, hidden, act, family="lmm"); sv = _hip.CvaeShape.make(d, c, lat, hidden, act, family="generic")
+    P = _hip.cvae_param_count(sl)
+    p = _dev((rng.standard_normal(P) * 0.3).astype(np.float32))
+    X = _dev(rng.standard_normal((n, d)).astype(np.float32)); C = _dev(rng.standard_normal((n, c)).astype(np.float32))
+    eps = _dev(rng.standard_normal((n, lat)).astype(np.float32))
+    idx = torch.from_numpy(rng.permutation(n).astype(np.int64)).cuda()
+    ws = torch.empty(_hip.cvae_workspace_bytes(sl, n), dtype=torch.uint8, device="cuda")
+    out = {}
+    for name, shape in (("lmm", sl), ("valu", sv)):
+        g = torch.empty(P + 1, device="cuda")
+        _hip.cvae_loss_grad(shape, p, X, C, idx, eps, n, 1.0 / n, 0.5, g[:P], g[P:], ws)
+        out[name] = g.cpu().numpy().astype(np.float64)
+    h = 40000
+    a = torch.empty(P + 1, device="cuda"); b = torch.empty(P + 1, device="cuda")
+    _hip.cvae_loss_grad(sl, p, X, C, idx[:h].contiguous(), eps[:h].contiguous(), h, 1.0 / n, 0.5, a[:P], a[P:], ws)
+    _hip.cvae_loss_grad(sl, p, X, C, idx[h:].contiguous(), eps[h:].contiguous(), n - h, 1.0 / n, 0.5, b[:P], b[P:], ws)
+    halves = (a + b).cpu().numpy().astype(np.float64)
+    scale = np.abs(out["valu"][:P]).max()
+    assert np.abs(out["lmm"][:P] - halves[:P]).max() < 2e-5 * scale and abs(out["lmm"][P] - halves[P]) < 2e-5 * abs(halves[P])
+    assert np.abs(out["lmm"][:P] - out["valu"][:P]).max() < 2e-5 * scale and abs(out["lmm"][P] - out["valu"][P]) < 2e-5 * abs(halves[P])
 
 
 @pytest.mark.parametrize("d,c,lat,h", [(1, 0, 1, 1), (13, 1, 3, 37), (16, 2, 4, 200), (7, 4, 1, 16), (2, 2, 2, 300),
