@@ -49,6 +49,15 @@ using mfma::k_sum_segments;
 #endif
 constexpr int kWaves = 4, kR = CVAE_R, kMaxGrid = 512, kFT = CVAE_FT;
 
+// CVAE_STAMP: diagnostic build that accumulates cycle-counter deltas per phase and printf()s them for two workgroups
+#ifdef CVAE_STAMP
+#define CSTAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CSTAMP_ADD(acc, t0) do { unsigned long long t1__; CSTAMP(t1__); acc += t1__ - t0; t0 = t1__; } while (0)
+#else
+#define CSTAMP(var) do { } while (0)
+#define CSTAMP_ADD(acc, t0) do { } while (0)
+#endif
+
 struct CG {                      // geometry + offsets (floats)
     int d, c, lat, h, HT;
     // flat (oracle-order) parameter offsets
@@ -181,8 +190,12 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
     bool first = true;
     const f4 bh = *reinterpret_cast<const f4 *>(wp + g.oBH + q * 4);
     const f4 b2d = *reinterpret_cast<const f4 *>(wp + g.oB2D + q * 4);
+    unsigned long long tk0 = 0, t0 = 0, s_ld = 0, s_ef = 0, s_df = 0, s_loss = 0, s_db = 0, s_dfl = 0, s_mid = 0, s_eb = 0, s_efl = 0;
+    (void)tk0; (void)t0; (void)s_ld; (void)s_ef; (void)s_df; (void)s_loss; (void)s_db; (void)s_dfl; (void)s_mid; (void)s_eb; (void)s_efl;
+    CSTAMP(tk0);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t base = grp * rows_per_wg + (int64_t)wave * R * 16;
+        CSTAMP(t0);
         float xr[R][4], cr[R][1], er[R], mu[R], ls[R], el[R], z[R];
         bool valid[R];
 #pragma unroll
@@ -193,16 +206,21 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
             mfma::load_row<2, 1>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
             er[rt] = (valid[rt] && q < g.lat) ? eps[row * g.lat + q] : 0.f;
         }
+        CSTAMP_ADD(s_ld, t0);
         // ---- encoder forward ---------------------------------------------------------------------
         {
             f4 outE[R][2];
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) { outE[rt][0] = f4{0.f, 0.f, 0.f, 0.f}; outE[rt][1] = f4{0.f, 0.f, 0.f, 0.f}; }
             const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2 = wp + g.oA2E + lane * 4;
+            // the fragments of hidden tile t + 1 are requested before tile t is multiplied (one wave per SIMD: nothing
+            // else would cover the L2 round trip)
+            f4 a10 = *opaque(pA1), a11 = *opaque(pA1 + 256), b1 = *opaque(pB1), a20 = *opaque(pA2), a21 = *opaque(pA2 + 256);
             for (int t = 0; t < HT; ++t) {
-                const f4 a10 = *opaque(pA1 + (size_t)(2 * t) * 256), a11 = *opaque(pA1 + (size_t)(2 * t + 1) * 256);
-                const f4 b1 = *opaque(pB1 + t * 16);
-                const f4 a20 = *opaque(pA2 + (size_t)(2 * t) * 256), a21 = *opaque(pA2 + (size_t)(2 * t + 1) * 256);
+                const int nx = t + 1 < HT ? t + 1 : t;
+                const f4 na10 = *opaque(pA1 + (size_t)(2 * nx) * 256), na11 = *opaque(pA1 + (size_t)(2 * nx + 1) * 256);
+                const f4 nb1 = *opaque(pB1 + nx * 16);
+                const f4 na20 = *opaque(pA2 + (size_t)(2 * nx) * 256), na21 = *opaque(pA2 + (size_t)(2 * nx + 1) * 256);
                 f4 hv[R];
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) {
@@ -219,6 +237,7 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                         outE[rt][0] = mfma4(a20[rho], hv[rt][rho], outE[rt][0]);
                         outE[rt][1] = mfma4(a21[rho], hv[rt][rho], outE[rt][1]);
                     }
+                a10 = na10; a11 = na11; b1 = nb1; a20 = na20; a21 = na21;
             }
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
@@ -228,14 +247,17 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                 z[rt] = fmaf(el[rt], er[rt], mu[rt]);                                      // cvae.py:188
             }
         }
+        CSTAMP_ADD(s_ef, t0);
         // ---- decoder forward -----------------------------------------------------------------------
         f4 xrec[R];
         {
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) xrec[rt] = b2d;
             const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4, *pA2 = wp + g.oA2D + lane * 4;
+            f4 a1 = *opaque(pA1), b1 = *opaque(pB1), a2 = *opaque(pA2);
             for (int t = 0; t < HT; ++t) {
-                const f4 a1 = *opaque(pA1 + (size_t)t * 256), b1 = *opaque(pB1 + t * 16), a2 = *opaque(pA2 + (size_t)t * 256);
+                const int nx = t + 1 < HT ? t + 1 : t;
+                const f4 na1 = *opaque(pA1 + (size_t)nx * 256), nb1 = *opaque(pB1 + nx * 16), na2 = *opaque(pA2 + (size_t)nx * 256);
                 f4 hv[R];
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) {
@@ -247,8 +269,10 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                 for (int rho = 0; rho < 4; ++rho)
 #pragma unroll
                     for (int rt = 0; rt < R; ++rt) xrec[rt] = mfma16(a2[rho], hv[rt][rho], xrec[rt]);
+                a1 = na1; b1 = nb1; a2 = na2;
             }
         }
+        CSTAMP_ADD(s_df, t0);
         // ---- loss: KL_weight * KL + MSE (cvae.py:190-193) ----------------------------------------
         f4 gx[R];
 #pragma unroll
@@ -267,6 +291,7 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
             wave_sum += row16_sum(v);
         }
         if (!do_grad) continue;                                                              // uniform
+        CSTAMP_ADD(s_loss, t0);
 
         // ---- decoder backward ------------------------------------------------------------------------
         float goT[R][4], inT[R][4];
@@ -284,9 +309,11 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
         {
             const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4;
             const float *pA2T = wp + g.oA2DT + lane * 4, *pA1X = wp + g.oA1DX + lane * 4;
+            f4 a1 = *opaque(pA1), b1 = *opaque(pB1), a2t = *opaque(pA2T), a1x = *opaque(pA1X);
             for (int t = 0; t < HT; ++t) {
-                const f4 a1 = *opaque(pA1 + (size_t)t * 256), b1 = *opaque(pB1 + t * 16);
-                const f4 a2t = *opaque(pA2T + (size_t)t * 256), a1x = *opaque(pA1X + (size_t)t * 256);
+                const int nx = t + 1 < HT ? t + 1 : t;
+                const f4 na1 = *opaque(pA1 + (size_t)nx * 256), nb1 = *opaque(pB1 + nx * 16);
+                const f4 na2t = *opaque(pA2T + (size_t)nx * 256), na1x = *opaque(pA1X + (size_t)nx * 256);
                 f4 gW1 = f4{0.f, 0.f, 0.f, 0.f}, gW2 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r0 = 0; r0 < R; r0 += RH) {
@@ -329,9 +356,10 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const float v = row16_sum(gb2[e]); if (r == 0) slot[kFT * 3 * 256 + q * 4 + e] = v; }
                     }
+                    CSTAMP_ADD(s_db, t0);
                     __syncthreads();
-                    const int t0 = (t / kFT) * kFT, nfl4 = (t + 1 - t0) * 2 * 256 / 4;
-                    f4 *dst = reinterpret_cast<f4 *>(gp + g.gDec + (size_t)t0 * 2 * 256);
+                    const int tf = (t / kFT) * kFT, nfl4 = (t + 1 - tf) * 2 * 256 / 4;
+                    f4 *dst = reinterpret_cast<f4 *>(gp + g.gDec + (size_t)tf * 2 * 256);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds);
                     for (int i = tid; i < nfl4; i += kWaves * 64) {
                         f4 v = s0[i];
@@ -346,9 +374,12 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                         gp[g.gB2D + tid] = first ? v : gp[g.gB2D + tid] + v;
                     }
                     __syncthreads();
+                    CSTAMP_ADD(s_dfl, t0);
                 }
+                a1 = na1; b1 = nb1; a2t = na2t; a1x = na1x;
             }
         }
+        CSTAMP_ADD(s_db, t0);
         // ---- gradient wrt mu / log_sigma ------------------------------------------------------------
         float gmu[R], gls[R];
         f4 gbh = f4{0.f, 0.f, 0.f, 0.f};
@@ -365,12 +396,15 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
             transpose16(bufI, f4{xr[rt][0], xr[rt][1], xr[rt][2], xr[rt][3]}, lane, inTe[rt][0]);   // x features
             transpose16(bufI + 16 * kTS, f4{cr[rt][0], q == 0 ? 1.f : 0.f, 0.f, 0.f}, lane, inTe[rt][1]);   // [c | 1]
         }
+        CSTAMP_ADD(s_mid, t0);
         // ---- encoder backward ------------------------------------------------------------------------
         {
             const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2T = wp + g.oA2ET + lane * 4;
+            f4 a10 = *opaque(pA1), a11 = *opaque(pA1 + 256), b1 = *opaque(pB1), a2t = *opaque(pA2T);
             for (int t = 0; t < HT; ++t) {
-                const f4 a10 = *opaque(pA1 + (size_t)(2 * t) * 256), a11 = *opaque(pA1 + (size_t)(2 * t + 1) * 256);
-                const f4 b1 = *opaque(pB1 + t * 16), a2t = *opaque(pA2T + (size_t)t * 256);
+                const int nx = t + 1 < HT ? t + 1 : t;
+                const f4 na10 = *opaque(pA1 + (size_t)(2 * nx) * 256), na11 = *opaque(pA1 + (size_t)(2 * nx + 1) * 256);
+                const f4 nb1 = *opaque(pB1 + nx * 16), na2t = *opaque(pA2T + (size_t)nx * 256);
                 f4 gW1a = f4{0.f, 0.f, 0.f, 0.f}, gW1b = f4{0.f, 0.f, 0.f, 0.f}, gW2 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r0 = 0; r0 < R; r0 += RH) {
@@ -411,9 +445,10 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
 #pragma unroll
                         for (int e = 0; e < 2; ++e) { const float v = row16_sum(gbh[e]); if (r == 0) slot[kFT * 3 * 256 + 16 + q * 4 + e] = v; }
                     }
+                    CSTAMP_ADD(s_eb, t0);
                     __syncthreads();
-                    const int t0 = (t / kFT) * kFT, nfl4 = (t + 1 - t0) * 3 * 256 / 4;
-                    f4 *dst = reinterpret_cast<f4 *>(gp + g.gEnc + (size_t)t0 * 3 * 256);
+                    const int tf = (t / kFT) * kFT, nfl4 = (t + 1 - tf) * 3 * 256 / 4;
+                    f4 *dst = reinterpret_cast<f4 *>(gp + g.gEnc + (size_t)tf * 3 * 256);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds);
                     for (int i = tid; i < nfl4; i += kWaves * 64) {
                         f4 v = s0[i];
@@ -428,12 +463,23 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                         gp[g.gBH + tid] = first ? v : gp[g.gBH + tid] + v;
                     }
                     __syncthreads();
+                    CSTAMP_ADD(s_efl, t0);
                 }
+                a10 = na10; a11 = na11; b1 = nb1; a2t = na2t;
             }
         }
+        CSTAMP_ADD(s_eb, t0);
         first = false;
     }
     if (lane == 0) losspart[blockIdx.x * kWaves + wave] = wave_sum;
+#ifdef CVAE_STAMP
+    {
+        unsigned long long tk1; CSTAMP(tk1);
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+            printf("CSTAMP wg %d wave %d total %llu load %llu encfwd %llu decfwd %llu loss %llu decbwd %llu decflush %llu mid %llu encbwd %llu encflush %llu\n",
+                   (int)blockIdx.x, wave, tk1 - tk0, s_ld, s_ef, s_df, s_loss, s_db, s_dfl, s_mid, s_eb, s_efl);
+    }
+#endif
 }
 
 // ---- encoder / decoder alone (cvae_encode, cvae_decode): the forward blocks of the step, no LDS -------------
@@ -470,10 +516,14 @@ k_cvae_mfma_mlp(CG g, const float *__restrict__ wp, const float *__restrict__ in
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) { outE[rt][0] = f4{0.f, 0.f, 0.f, 0.f}; outE[rt][1] = f4{0.f, 0.f, 0.f, 0.f}; }
             const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2 = wp + g.oA2E + lane * 4;
+            // the fragments of hidden tile t + 1 are requested before tile t is multiplied (one wave per SIMD: nothing
+            // else would cover the L2 round trip)
+            f4 a10 = *opaque(pA1), a11 = *opaque(pA1 + 256), b1 = *opaque(pB1), a20 = *opaque(pA2), a21 = *opaque(pA2 + 256);
             for (int t = 0; t < HT; ++t) {
-                const f4 a10 = *opaque(pA1 + (size_t)(2 * t) * 256), a11 = *opaque(pA1 + (size_t)(2 * t + 1) * 256);
-                const f4 b1 = *opaque(pB1 + t * 16);
-                const f4 a20 = *opaque(pA2 + (size_t)(2 * t) * 256), a21 = *opaque(pA2 + (size_t)(2 * t + 1) * 256);
+                const int nx = t + 1 < HT ? t + 1 : t;
+                const f4 na10 = *opaque(pA1 + (size_t)(2 * nx) * 256), na11 = *opaque(pA1 + (size_t)(2 * nx + 1) * 256);
+                const f4 nb1 = *opaque(pB1 + nx * 16);
+                const f4 na20 = *opaque(pA2 + (size_t)(2 * nx) * 256), na21 = *opaque(pA2 + (size_t)(2 * nx + 1) * 256);
                 f4 hv[R];
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) {
@@ -490,6 +540,7 @@ k_cvae_mfma_mlp(CG g, const float *__restrict__ wp, const float *__restrict__ in
                         outE[rt][0] = mfma4(a20[rho], hv[rt][rho], outE[rt][0]);
                         outE[rt][1] = mfma4(a21[rho], hv[rt][rho], outE[rt][1]);
                     }
+                a10 = na10; a11 = na11; b1 = nb1; a20 = na20; a21 = na21;
             }
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
@@ -503,8 +554,10 @@ k_cvae_mfma_mlp(CG g, const float *__restrict__ wp, const float *__restrict__ in
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) xrec[rt] = b2d;
             const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4, *pA2 = wp + g.oA2D + lane * 4;
+            f4 a1 = *opaque(pA1), b1 = *opaque(pB1), a2 = *opaque(pA2);
             for (int t = 0; t < HT; ++t) {
-                const f4 a1 = *opaque(pA1 + (size_t)t * 256), b1 = *opaque(pB1 + t * 16), a2 = *opaque(pA2 + (size_t)t * 256);
+                const int nx = t + 1 < HT ? t + 1 : t;
+                const f4 na1 = *opaque(pA1 + (size_t)nx * 256), nb1 = *opaque(pB1 + nx * 16), na2 = *opaque(pA2 + (size_t)nx * 256);
                 f4 hv[R];
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) {
@@ -516,6 +569,7 @@ k_cvae_mfma_mlp(CG g, const float *__restrict__ wp, const float *__restrict__ in
                 for (int rho = 0; rho < 4; ++rho)
 #pragma unroll
                     for (int rt = 0; rt < R; ++rt) xrec[rt] = mfma16(a2[rho], hv[rt][rho], xrec[rt]);
+                a1 = na1; b1 = nb1; a2 = na2;
             }
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
