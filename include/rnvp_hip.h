@@ -264,6 +264,18 @@ int rnvp_fit_epoch(void *stream, const rnvp_shape *shape,
                    int64_t first_step, void *workspace, size_t workspace_bytes);
 
 /*
+ * 1 when rnvp_fit_epoch runs this shape at this batch size as ONE persistent launch per epoch ("resident" fit,
+ * rnvp_resident.hip): one hidden layer of at most 16 units (at most 32 while d + cdim <= 15), d <= 16, d + cdim <= 31, at
+ * most 16 layers, batch_size <= 128, and the model with its per-wave gradient stages inside one CU's 160 KB of LDS -- the
+ * reference's default network (hidden=(10,), 8 layers, batch_size=32: realnvp.py:161-176).  Parameters stay in LDS for
+ * the whole epoch, a step is a register-to-register MFMA chain per 16-row wave, Adam runs in place: 21 us per step
+ * instead of 41 for the defaults.  The result agrees with the batch-by-batch loop to rounding (another summation order)
+ * and reproduces itself bit for bit.  0: the loop of rnvp_train_step described above.  family == RNVP_FAMILY_VALU pins
+ * the loop (test / measurement aid).
+ */
+int rnvp_fit_epoch_resident(const rnvp_shape *shape, int64_t batch_size);
+
+/*
  * Data-parallel fit (the reference has no counterpart: its loop, realnvp.py:235-254, is single-process).
  * One process per GPU; every rank walks the SAME permutation and takes a contiguous share of each global batch.
  *

@@ -114,6 +114,7 @@ _SIGNATURES = {
     "rnvp_param_count": (_SZ, [_SP]),
     "rnvp_workspace_bytes": (_SZ, [_SP, C.c_int, _I64]),
     "rnvp_kernel_path": (C.c_int, [_SP, _VP, C.c_int]),
+    "rnvp_fit_epoch_resident": (C.c_int, [_SP, _I64]),
     "rnvp_forward_logprob": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_inverse": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "rnvp_prior_normal": (C.c_int, [_VP, _U64, _I64, _I64, C.c_int32, _VP]),
@@ -306,6 +307,11 @@ def train_step(shape, params, masks, x, c, row_index, n_rows, inv_B, grad_buf, l
         _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
         _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(eps),
         float(weight_decay), int(step), wp, wn))
+
+
+def fit_epoch_resident(shape, batch_size):
+    """True when rnvp_fit_epoch runs this shape / batch size as one persistent launch per epoch (rnvp_resident.hip)"""
+    return bool(lib().rnvp_fit_epoch_resident(C.byref(shape), int(batch_size)))
 
 
 def fit_epoch(shape, params, masks, x, c, perm, n, batch_size, grad_buf, loss_hist, exp_avg, exp_avg_sq,

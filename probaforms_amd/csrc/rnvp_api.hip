@@ -6,6 +6,7 @@
 
 #include "rnvp_common.h"
 #include "rnvp_lmm.h"
+#include "rnvp_resident.h"
 #include "rnvp_mfma.h"
 
 using namespace rnvp;
@@ -296,12 +297,28 @@ int rnvp_train_step(void *stream, const rnvp_shape *shape, float *params, const 
                           beta1, beta2, eps, weight_decay, step);
 }
 
+int rnvp_fit_epoch_resident(const rnvp_shape *shape, int64_t batch_size) {
+    KShape ks;
+    if (make_kshape(shape, &ks) != RNVP_OK) return 0;
+    return resident::fits(ks, batch_size) ? 1 : 0;
+}
+
 int rnvp_fit_epoch(void *stream, const rnvp_shape *shape, float *params, const uint8_t *masks,
                    const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
                    float *grad_buf, float *loss_hist, float *exp_avg, float *exp_avg_sq,
                    double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t first_step, void *workspace, size_t workspace_bytes) {
     if (n < 0 || batch_size < 1 || !perm || !loss_hist || first_step < 1) return RNVP_EINVAL;
+    {   // a model that fits one CU's LDS at a batch of at most 256 rows: the whole epoch in one persistent launch
+        KShape ks;
+        const int rc = make_kshape(shape, &ks);
+        if (rc) return rc;
+        if (n > 0 && resident::fits(ks, batch_size)) {
+            if (bad_ptrs(ks, params, masks, x, c) || !masks || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
+            return resident::fit_epoch(static_cast<hipStream_t>(stream), ks, params, masks, x, c, perm, n, batch_size, loss_hist,
+                                       exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step);
+        }
+    }
     int64_t k = 0;
     for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
         const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;

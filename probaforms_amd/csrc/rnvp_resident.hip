@@ -1,0 +1,924 @@
+// rnvp_resident.hip -- "resident" fit: one epoch of a SMALL flow at a SMALL batch size in ONE persistent workgroup (gfx950).
+//
+// The reference's defaults -- hidden=(10,), 8 layers, batch_size=32 (/root/reference/probaforms/models/realnvp.py:161-176),
+// its docstring network hidden=(10, 20, 15) (realnvp.py:22-38) -- are flows of a few thousand parameters stepped on a few
+// dozen rows: a step is a chain of ~50 tiny dependent GEMMs, and the three launches of the general path (weight re-pack,
+// loss + gradient, reduce + Adam) cost more than the arithmetic (41 us per step for d = 2, h = 10; 245 us for
+// hidden=(10,20,15)).  A CU's 160 KB of LDS holds such a model whole, so the batch loop of RealNVP.fit
+// (realnvp.py:237-254) runs here as ONE launch per epoch:
+//   * the flat parameters (reference order) live in LDS for the whole epoch, and so do Adam's moments when they fit;
+//   * wave w owns rows 16w .. 16w+15 of every batch; its activations are a wave-private LDS image [feature][17], so the
+//     forward / backward chain of a step needs no workgroup barrier at all (a wave's DS operations execute in order);
+//   * every Linear is v_mfma_f32_16x16x4_f32 computed transposed (features on M, rows on N) as in rnvp_lmm.hip, the A
+//     operand read straight from the LDS-resident W (forward: W[out][in], input gradient: W[out][in]^T), the weight
+//     gradient dW = gP^T . in as a third MFMA contraction over the tile's 16 rows, written to the wave's stage;
+//   * one barrier, then all threads add the stages in wave order (deterministic), apply Adam in place in LDS and write
+//     the batch loss; one more barrier and the next batch starts.  Parameters and moments go back to HBM once per epoch.
+// Same arithmetic per element as the other kernel families (tanh through exp2 / rcp, torch.optim.Adam as separately
+// rounded operations); the summation ORDER over rows and hidden units differs, so results agree with them to rounding,
+// not bit for bit -- run to run this path is bit-reproducible.
+#include "rnvp_common.h"
+#include "rnvp_generic_net.h"
+#include "rnvp_resident.h"
+
+#include <cmath>
+
+namespace rnvp {
+namespace resident {
+namespace {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+constexpr int RS = 17;                 // row stride of an LDS image [feature][RS]: 16 rows + 1
+constexpr int kMaxWaves = 16;
+constexpr size_t kLdsMax = 160 * 1024;
+#ifndef RNVP_RESIDENT_GENERIC
+#define RNVP_RESIDENT_GENERIC 0      // the LDS-image form for several hidden layers: correct, but no faster than the step loop yet
+#endif
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// LDS traffic between lanes of ONE wave: only the compiler has to be kept from reordering the accesses
+__device__ __forceinline__ void wfence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct RPlan {
+    int W;                 // waves of the workgroup = 16-row tiles of a full batch
+    int P;                 // parameters
+    int mv_lds;            // Adam's moments are LDS-resident too
+    int oPAR, oM, oV, oSTG, oIMG, oRED, oMSK;      // float offsets
+    int img_floats;        // one wave's image
+    int iX, iIN, iACT, iT, iS, iGY, iGIN, iGA, iGB, iXS;      // feature-row offsets inside an image
+    int total_floats;
+};
+
+// out^T[nout x 16] = act(W in^T + b) for the wave's tile; W [nout][nin], b [nout] are LDS-resident; act < 0: none
+__device__ __forceinline__ void lin_fwd(const float *Wk, const float *bk, int nin, int nout, const float *in, float *out,
+                                        int act, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const int MT = (nout + 15) >> 4, KS = (nin + 3) >> 2;
+    for (int m = 0; m < MT; ++m) {
+        f4 acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int o = 16 * m + 4 * q + e; acc[e] = o < nout ? bk[o] : 0.f; }
+        const int row = 16 * m + i;
+        const bool rok = row < nout;
+        const float *wrow = Wk + (rok ? row : 0) * nin;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int col = 4 * ks + q;
+            const float a = (rok && col < nin) ? wrow[col] : 0.f;
+            acc = mfma16(a, in[col * RS + i], acc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = 16 * m + 4 * q + e;
+            if (o < nout) out[o * RS + i] = act >= 0 ? act_fwd(acc[e], act) : acc[e];
+        }
+    }
+}
+
+// input gradient gprev^T[nin_eff x 16] = W^T gcur^T (first nin_eff inputs only)
+__device__ __forceinline__ void lin_bwd_in(const float *Wk, int nin, int nout, int nin_eff, const float *gcur, float *gprev, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const int MT = (nin_eff + 15) >> 4, KS = (nout + 3) >> 2;
+    for (int m = 0; m < MT; ++m) {
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        const int in = 16 * m + i;
+        const bool iok = in < nin_eff;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int out = 4 * ks + q;
+            const float a = (iok && out < nout) ? Wk[out * nin + in] : 0.f;
+            acc = mfma16(a, gcur[out * RS + i], acc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ii = 16 * m + 4 * q + e;
+            if (ii < nin_eff) gprev[ii * RS + i] = acc[e];
+        }
+    }
+}
+
+// weight gradient of the tile: dW[o][j] = sum_rows gP[o][row] in[j][row], db[o] = sum_rows gP[o][row] (the ones column),
+// written (not added) into the wave's stage in the reference's flat order
+__device__ __forceinline__ void lin_wgrad(const float *gP, const float *inp, int nin, int nout, float *stgW, float *stgB, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const int MT = (nout + 15) >> 4, PT = (nin + 1 + 15) >> 4;
+    for (int m = 0; m < MT; ++m) {
+        const int o_a = 16 * m + i;
+        float a[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[ks] = o_a < nout ? gP[o_a * RS + 4 * ks + q] : 0.f;
+        for (int p = 0; p < PT; ++p) {
+            const int j = 16 * p + i;
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float b = j < nin ? inp[j * RS + 4 * ks + q] : (j == nin ? 1.f : 0.f);
+                acc = mfma16(a[ks], b, acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = 16 * m + 4 * q + e;
+                if (o < nout) {
+                    if (j < nin) stgW[o * nin + j] = acc[e];
+                    else if (j == nin) stgB[o] = acc[e];
+                }
+            }
+        }
+    }
+}
+
+// one s or t net forward on the wave's tile; hidden activations at running offsets in hbuf (kept for the backward)
+__device__ __forceinline__ void net_fwd(const float *pn, const KShape &s, const float *in0, float *hbuf, float *out, int lane) {
+    const float *cur = in0;
+    float *dst = hbuf;
+    for (int k = 0; k <= s.nh; ++k) {
+        const bool last = k == s.nh;
+        float *ob = last ? out : dst;
+        wfence();
+        lin_fwd(pn + s.woff[k], pn + s.boff[k], s.nin[k], s.nout[k], cur, ob, last ? -1 : s.act, lane);
+        cur = ob;
+        if (!last) dst += s.nout[k] * RS;
+    }
+    wfence();
+}
+
+// one net backward: GA holds d loss / d (net output); per Linear (last to first) activation derivative, weight gradient
+// into the stage, input gradient; Linear 0's input gradient (x columns only) lands in gx0 (not masked, not accumulated)
+__device__ __forceinline__ void net_bwd(const float *pn, float *stg, const KShape &s, const float *in0, const float *ACT, float *GA,
+                                        float *GB, float *gx0, int lane) {
+    const int q = lane >> 4, r = lane & 15;
+    float *gcur = GA, *gprev = GB;
+    int aoff = s.hs;
+    for (int k = s.nh; k >= 0; --k) {
+        const int nin = s.nin[k], nout = s.nout[k];
+        if (k < s.nh) {
+            aoff -= nout;
+            const float *ak = ACT + aoff * RS;
+            for (int f = q; f < nout; f += 4) {
+                const float a = ak[f * RS + r], gv = gcur[f * RS + r];
+                gcur[f * RS + r] = (s.act == RNVP_ACT_TANH) ? gv * (1.f - a * a) : (a > 0.f ? gv : 0.f);
+            }
+        }
+        wfence();
+        const float *inp = (k == 0) ? in0 : ACT + (aoff - nin) * RS;
+        lin_wgrad(gcur, inp, nin, nout, stg + s.woff[k], stg + s.boff[k], lane);
+        if (k == 0) lin_bwd_in(pn + s.woff[0], nin, nout, s.d, gcur, gx0, lane);
+        else lin_bwd_in(pn + s.woff[k], nin, nout, nin, gcur, gprev, lane);
+        wfence();
+        float *tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+}
+
+__global__ void __launch_bounds__(64 * kMaxWaves)
+k_fit_resident(KShape s, RPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
+               const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch, float *__restrict__ loss_hist,
+               float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1, double beta2, double eps,
+               double wd, double b1t, double b2t) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15;
+    const int d = s.d, cd = s.c, L = s.L, P = pl.P;
+    float *PAR = lds + pl.oPAR, *MM = lds + pl.oM, *VV = lds + pl.oV, *STG = lds + pl.oSTG + (size_t)wave * P;
+    float *IMG = lds + pl.oIMG + (size_t)wave * pl.img_floats, *RED = lds + pl.oRED;
+    const float *MSK = lds + pl.oMSK;                  // masks as 0 / 1 floats
+    float *X = IMG + pl.iX * RS, *IN = IMG + pl.iIN * RS, *ACT = IMG + pl.iACT * RS, *T = IMG + pl.iT * RS, *S = IMG + pl.iS * RS;
+    float *GY = IMG + pl.iGY * RS, *GIN = IMG + pl.iGIN * RS, *GA = IMG + pl.iGA * RS, *GB = IMG + pl.iGB * RS, *XS = IMG + pl.iXS * RS;
+    for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;          // padded k-steps read rows past an image: keep them finite
+    __syncthreads();
+    for (int p = tid; p < P; p += nthreads) {
+        PAR[p] = params[p];
+        if (pl.mv_lds) { MM[p] = exp_avg[p]; VV[p] = exp_avg_sq[p]; }
+    }
+    for (int e = tid; e < L * d; e += nthreads) lds[pl.oMSK + e] = (float)masks[e];
+    __syncthreads();
+    const float prior_c = 0.5f * (float)d * kLog2Pi;
+    const int64_t nb = (n + batch - 1) / batch;
+    for (int64_t kb = 0; kb < nb; ++kb) {
+        const int64_t s0 = kb * batch;
+        const int rows = (int)((n - s0 < batch) ? n - s0 : batch);
+        const float inv_B = 1.0f / (float)rows;
+        const int nw = (rows + 15) >> 4;
+        if (wave < nw) {
+            const int base = wave * 16;
+            const bool valid = base + r < rows;
+            const int64_t src = valid ? perm[s0 + base + r] : 0;
+            for (int j = q; j < d; j += 4) X[j * RS + r] = valid ? x[src * d + j] : 0.f;
+            for (int j = q; j < cd; j += 4) IN[(d + j) * RS + r] = valid ? c[src * cd + j] : 0.f;
+            float ld = 0.f;
+            // ---- forward: z, log|det J| (realnvp.py:91-101, nflow.py:107-117) ----
+            for (int l = 0; l < L; ++l) {
+                const float *m = MSK + l * d;
+                const float *pn = PAR + (size_t)l * 2 * s.npn;
+                wfence();
+                for (int j = q; j < d; j += 4) {
+                    const float xv = X[j * RS + r];
+                    XS[(l * d + j) * RS + r] = xv;                               // layer input, for the backward
+                    IN[j * RS + r] = m[j] != 0.f ? xv : 0.f;
+                }
+                net_fwd(pn, s, IN, ACT, T, lane);
+                net_fwd(pn + s.npn, s, IN, ACT, S, lane);
+                for (int j = q; j < d; j += 4)
+                    if (m[j] == 0.f) { const float sv = S[j * RS + r]; X[j * RS + r] = fmaf(X[j * RS + r], expf(sv), T[j * RS + r]); ld += sv; }
+            }
+            wfence();
+            {   // loss terms and the seed of the backward
+                float ss = 0.f;
+                for (int j = q; j < d; j += 4) { const float zv = X[j * RS + r]; ss = fmaf(zv, zv, ss); GY[j * RS + r] = valid ? zv * inv_B : 0.f; }
+                ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
+                ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+                float v = (valid && q == 0) ? ld + (-0.5f * ss - prior_c) : 0.f;
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (lane == 0) RED[wave] = v;
+            }
+            const float gld = valid ? -inv_B : 0.f;
+            // ---- backward (the hand-derived chain of SURVEY.md 3.3, as rnvp_lmm.hip) ----
+            for (int l = L - 1; l >= 0; --l) {
+                const float *m = MSK + l * d;
+                const float *pn = PAR + (size_t)l * 2 * s.npn;
+                float *stg = STG + (size_t)l * 2 * s.npn;
+                wfence();
+                for (int j = q; j < d; j += 4) {
+                    const float xv = XS[(l * d + j) * RS + r];
+                    X[j * RS + r] = xv;
+                    IN[j * RS + r] = m[j] != 0.f ? xv : 0.f;
+                    GIN[j * RS + r] = 0.f;
+                }
+                for (int net = 1; net >= 0; --net) {             // s first (exp(s) is needed below), then t
+                    const float *pnn = pn + (size_t)net * s.npn;
+                    net_fwd(pnn, s, IN, ACT, net ? S : T, lane);
+                    for (int j = q; j < d; j += 4) {             // d loss / d (net output): s: (1-m)(gy x e^s + gld), t: (1-m) gy
+                        float v = 0.f;
+                        if (m[j] == 0.f) {
+                            const float gy = GY[j * RS + r];
+                            v = net ? fmaf(gy * X[j * RS + r], expf(S[j * RS + r]), gld) : gy;
+                        }
+                        GA[j * RS + r] = v;
+                    }
+                    // Linear 0's input gradient lands in T: free here (the s net runs before T is recomputed; the t net's
+                    // output is not needed once its seed is written)
+                    net_bwd(pnn, stg + (size_t)net * s.npn, s, IN, ACT, GA, GB, T, lane);
+                    for (int j = q; j < d; j += 4)
+                        if (m[j] != 0.f) GIN[j * RS + r] += T[j * RS + r];                       // the nets see x * mask
+                    wfence();
+                }
+                for (int j = q; j < d; j += 4) {
+                    const float gy = GY[j * RS + r];
+                    GY[j * RS + r] = (m[j] != 0.f ? gy : gy * expf(S[j * RS + r])) + GIN[j * RS + r];
+                }
+            }
+        }
+        __syncthreads();
+        {   // stages in wave order -> gradient; Adam in place (torch.optim.Adam as separately rounded operations, rnvp_common.h)
+            AdamK a;                                     // scalar bookkeeping in double, like torch (make_adam, rnvp_adam.hip)
+            a.step_size = (float)(lr / (1.0 - b1t)); a.bc2_sqrt = (float)sqrt(1.0 - b2t);
+            b1t *= beta1; b2t *= beta2;
+            a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
+            a.wd = (float)wd; a.eps = (float)eps; a.use_wd = wd != 0.0;
+            const float *st0 = lds + pl.oSTG;
+            for (int p = tid; p < P; p += nthreads) {
+                float g = st0[p];
+                for (int w = 1; w < nw; ++w) g += st0[(size_t)w * P + p];
+                float pv = PAR[p];
+                if (pl.mv_lds) {
+                    float mv = MM[p], vv = VV[p];
+                    adam_one(pv, g, mv, vv, a);
+                    MM[p] = mv; VV[p] = vv;
+                } else {
+                    float mv = exp_avg[p], vv = exp_avg_sq[p];
+                    adam_one(pv, g, mv, vv, a);
+                    exp_avg[p] = mv; exp_avg_sq[p] = vv;
+                }
+                PAR[p] = pv;
+            }
+            if (tid == 0) {
+                float acc = 0.f;
+                for (int w = 0; w < nw; ++w) acc += RED[w];
+                loss_hist[kb] = -acc * inv_B;
+            }
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < P; p += nthreads) {
+        params[p] = PAR[p];
+        if (pl.mv_lds) { exp_avg[p] = MM[p]; exp_avg_sq[p] = VV[p]; }
+    }
+}
+
+// ---- register-chained form: ONE hidden layer of at most 32 units, d <= 16, d + cdim <= 31 (the reference's default shape) ----
+// Every vector of a row -- the net input [x * mask | c], a tile of 16 hidden units, s, t and their gradients -- is an f4
+// per lane and 16 elements: lane (q = lane >> 4, r = lane & 15) keeps elements 4e + q (e = 0..3) of row r.  An MFMA's D
+// operand comes out in exactly that form when the A rows are gathered in the order pi(i) = 4 (i & 3) + (i >> 2), and it IS
+// the B operand of the next GEMM's k-step e (K index = lane group) -- so a whole layer, forward and input-gradient chain,
+// runs register to register.  LDS holds the weights (A operands gathered straight from the flat parameters through
+// per-lane offsets computed once: independent of the data chain, issued early), the saved layer inputs (lane-private) and
+// a few transposition tiles per wave for the contractions over the 16 rows (weight gradients; a ones element in the input
+// tile yields d b1).  Padding is handled by zeros on ONE side of every product (inputs past d + cdim are zero, hidden
+// units past h are multiplied by a 0 / 1 lane mask, output features past d are passed through), so no gather is guarded.
+constexpr int TS = 17;
+constexpr int kRcMaxWaves = 8;
+constexpr int kDump = 64;              // per-net dump zone of the stage: where the padding lanes of a weight-gradient tile write
+
+struct RcPlan {
+    int W, P, mv_lds;
+    int stg_net;                                       // floats of one net's stage block: npn + kDump
+    int oPAR, oM, oV, oSTG, oRED, oXS, oTT;            // float offsets
+    int xs_floats, tt_floats, stg_floats;              // per wave
+    int total_floats;
+};
+
+// e^x to ~1.5 ulp from the hardware exp2: x log2(e) split into a rounded product and its error
+__device__ __forceinline__ float exp_acc(float xv) {
+    const float t = xv * 1.4426950408889634f;
+    float rr = fmaf(xv, 1.4426950408889634f, -t);
+    rr = fmaf(xv, 1.9259629911266175e-8f, rr);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, rr * 0.6931471805599453f, e);
+}
+template <int ACT> __device__ __forceinline__ float actf(float v) {
+    if (ACT != RNVP_ACT_TANH) return fmaxf(v, 0.f);
+    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+template <int ACT> __device__ __forceinline__ float dactf(float hv) {
+    if (ACT != RNVP_ACT_TANH) return hv > 0.f ? 1.f : 0.f;
+    return fmaf(-hv, hv, 1.f);
+}
+// sum over the 16 lanes of a DPP row (the tile's 16 rows of one lane group), result in every lane: four DPP moves
+// (quad swaps, half-row mirror, row mirror) instead of four trips through the LDS crossbar (ds_bpermute ~ 100 cycles each)
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);         // row_half_mirror
+    v += dpp_move<0x140>(v);         // row_mirror
+    return v;
+}
+// the lane's elements 4e + q of row r -> tile [element][TS]; operand of a contraction over rows: element i, rows 4ks + q
+__device__ __forceinline__ void tile_put(float *T, f4 v, int q, int r) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[(4 * e + q) * TS + r] = v[e];
+}
+__device__ __forceinline__ void tile_get(const float *T, int q, int i, float (&o)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o[ks] = T[i * TS + 4 * ks + q];
+}
+
+// MT hidden tiles, KIT k-steps of the net input (4 KIT >= d + cdim + 1), WMAX waves
+template <int MT, int KIT, int ACT, int WMAX>
+__global__ void __launch_bounds__(64 * WMAX)
+k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
+                  const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch,
+                  float *__restrict__ loss_hist, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1,
+                  double beta2, double eps, double wd, double b1t, double b2t) {
+    constexpr int NIT = KIT > 4 ? 2 : 1;               // 16-element tiles of the net input
+    constexpr int KXT = KIT < 4 ? KIT : 4;             // k-steps over the d <= 16 features of x
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, i = r;
+    const int d = s.d, cd = s.c, L = s.L, P = pl.P, h = s.nout[0], nin0 = d + cd, npn = s.npn;
+    const int w0 = s.woff[0], b0 = s.boff[0], w1 = s.woff[1], b1o = s.boff[1];
+    const int pi = 4 * (i & 3) + (i >> 2);                // the element a fragment's row i stands for
+    float *PAR = lds + pl.oPAR, *MM = lds + pl.oM, *VV = lds + pl.oV, *STG = lds + pl.oSTG + (size_t)wave * pl.stg_floats;
+    float *RED = lds + pl.oRED;
+    f4 *XS = reinterpret_cast<f4 *>(lds + pl.oXS + (size_t)wave * pl.xs_floats);
+    float *TT = lds + pl.oTT + (size_t)wave * pl.tt_floats;
+    float *T_in = TT, *T_go = TT + NIT * 16 * TS, *T_h = T_go + 2 * 16 * TS;      // [input tiles][g_out t, s][h, g_pre of t; of s]
+    for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;
+    __syncthreads();
+    for (int p = tid; p < P; p += nthreads) {
+        PAR[p] = params[p];
+        if (pl.mv_lds) { MM[p] = exp_avg[p]; VV[p] = exp_avg_sq[p]; }
+    }
+    __syncthreads();
+    const float prior_c = 0.5f * (float)d * kLog2Pi;
+    const int64_t nb = (n + batch - 1) / batch;
+
+    // ---- per-lane constants: gather offsets (floats, relative to a net's parameter block), padding masks, stage offsets ----
+    const int gW1 = w0 + pi * nin0 + q;                   // + m 16 nin0 + 4k : W1[16m + pi][4k + q]          (GEMM1)
+    const int gW2 = w1 + pi * h + q;                      // + 16m + 4e      : W2[pi][16m + 4e + q]          (GEMM2)
+    const int gW1t = w0 + q * nin0 + pi;                  // + (16m + 4e) nin0 : W1[16m + 4e + q][pi]        (g_in)
+    const int gB1 = b0 + q, gB2 = b1o + q;                // + 16m + 4e / + 4e
+    int gW2t[4];                                          // + 16m           : W2[4e + q][16m + pi]          (g_h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gW2t[e] = w1 + (4 * e + q) * h + pi;
+    f4 hm[MT];                                            // 1 for the real hidden units of a tile, 0 for its padding
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hm[m][e] = 16 * m + 4 * e + q < h ? 1.f : 0.f;
+    uint64_t mbits = 0;                                   // bit 4l + e: mask[l][4e + q]; padding features count as masked (passed through)
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * e + q;
+            if (j >= d || masks[l * d + j]) mbits |= 1ull << (4 * l + e);
+        }
+    bool xok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xok[e] = 4 * e + q < d;
+    // stage offsets (relative to a net's stage block) of the weight-gradient tiles' D registers
+    int sS2[MT][4], sS1[MT][NIT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int fo = 4 * q + e, hid_n = 16 * m + i, hid_m = 16 * m + 4 * q + e;
+            sS2[m][e] = (fo < d && hid_n < h) ? w1 + fo * h + hid_n : npn + lane;                    // d W2[fo][hid]
+#pragma unroll
+            for (int nt = 0; nt < NIT; ++nt) {
+                const int j = 16 * nt + i;
+                sS1[m][nt][e] = hid_m >= h ? npn + lane : (j < nin0 ? w0 + hid_m * nin0 + j : (j == nin0 ? b0 + hid_m : npn + lane));
+            }
+        }
+
+    // rows of a batch for this lane (zeros past d / cdim / the batch): x, and the condition placed behind x in the net input
+    auto row_of = [&](int64_t kb) -> int64_t {
+        if (kb >= nb) return -1;
+        const int64_t s0 = kb * batch;
+        const int64_t rows = (n - s0 < batch) ? n - s0 : batch;
+        const int64_t rr = (int64_t)wave * 16 + r;
+        return rr < rows ? perm[s0 + rr] : -1;
+    };
+    auto load_rows = [&](int64_t src, f4 &xo, f4 (&co)[NIT]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xo[e] = (src >= 0 && xok[e]) ? x[src * d + 4 * e + q] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * nt + 4 * e + q;
+                co[nt][e] = (src >= 0 && j >= d && j < nin0) ? c[src * cd + (j - d)] : 0.f;
+            }
+    };
+    // A fragments of one layer, both nets: forward (biases, W1, W2) and backward (W2^T for g_h, W1^T for g_in)
+    struct FwdW { float b1[2][MT][4], a1[2][MT][KIT], b2[2][4], a2[2][MT][4]; };
+    struct BwdW { float a2t[2][MT][KXT], a1t[2][MT][4]; };
+    auto load_fwd = [&](int l, FwdW &w) {
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            const float *pn = PAR + (size_t)(2 * l + net) * npn;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w.b1[net][m][e] = pn[gB1 + 16 * m + 4 * e]; w.a2[net][m][e] = pn[gW2 + 16 * m + 4 * e]; }
+#pragma unroll
+                for (int k = 0; k < KIT; ++k) w.a1[net][m][k] = pn[gW1 + m * 16 * nin0 + 4 * k];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w.b2[net][e] = pn[gB2 + 4 * e];
+        }
+    };
+    auto load_bwd = [&](int l, BwdW &w) {
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            const float *pn = PAR + (size_t)(2 * l + net) * npn;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int e = 0; e < KXT; ++e) w.a2t[net][m][e] = pn[gW2t[e] + 16 * m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w.a1t[net][m][e] = pn[gW1t + (16 * m + 4 * e) * nin0];
+            }
+        }
+    };
+    // both nets of one layer, their two independent chains interleaved instruction by instruction: hidden activations
+    // hh[net][m]; outputs o[1] of the s net and (need_t) o[0] of the t net
+    auto nets_fwd = [&](const FwdW &w, const f4 (&in)[NIT], f4 (&hh)[2][MT], f4 (&o)[2], auto need_t) {
+        constexpr int N0 = decltype(need_t)::value ? 0 : 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f4 acc[2];
+#pragma unroll
+            for (int net = 0; net < 2; ++net)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[net][e] = w.b1[net][m][e];
+#pragma unroll
+            for (int k = 0; k < KIT; ++k)
+#pragma unroll
+                for (int net = 0; net < 2; ++net) acc[net] = mfma16(w.a1[net][m][k], in[k >> 2][k & 3], acc[net]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int net = 0; net < 2; ++net) hh[net][m][e] = actf<ACT>(acc[net][e]) * hm[m][e];
+        }
+#pragma unroll
+        for (int net = N0; net < 2; ++net)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[net][e] = w.b2[net][e];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int net = N0; net < 2; ++net) o[net] = mfma16(w.a2[net][m][e], hh[net][m][e], o[net]);
+    };
+
+    // two batches ahead: row indices; one batch ahead: the rows themselves
+    int64_t src_next = row_of(0);
+    f4 nxq, ncq[NIT];
+    load_rows(src_next, nxq, ncq);
+    src_next = row_of(1);
+    for (int64_t kb = 0; kb < nb; ++kb) {
+        const int64_t s0 = kb * batch;
+        const int rows = (int)((n - s0 < batch) ? n - s0 : batch);
+        const float inv_B = 1.0f / (float)rows;
+        const int nw = (rows + 15) >> 4;
+        f4 xq = nxq, cin[NIT];
+#pragma unroll
+        for (int nt = 0; nt < NIT; ++nt) cin[nt] = ncq[nt];
+        load_rows(src_next, nxq, ncq);
+        src_next = row_of(kb + 2);
+#ifdef RC_STAMP
+        unsigned long long ts0 = __builtin_readcyclecounter(), ts1 = ts0, ts2 = ts0, ts3 = ts0, ts4 = ts0;
+#endif
+        if (wave < nw) {
+            const bool valid = wave * 16 + r < rows;
+            float ld = 0.f;
+            // ---- forward (realnvp.py:91-101, nflow.py:107-117); the next layer's fragments are requested a layer ahead ----
+            FwdW fw;
+            load_fwd(0, fw);
+            for (int l = 0; l < L; ++l) {
+                const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
+                XS[l * 64 + lane] = xq;                                    // layer input, for the backward (lane-private)
+                f4 in[NIT];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) in[0][e] = ((mb >> e) & 1u) ? xq[e] + cin[0][e] : cin[0][e];      // [x * mask | c]
+                if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
+                FwdW fn;
+                if (MT == 1) load_fwd(l + 1 < L ? l + 1 : l, fn);
+                f4 hh[2][MT], o[2];
+                nets_fwd(fw, in, hh, o, std::true_type{});
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    const float xn = fmaf(xq[e], exp_acc(o[1][e]), o[0][e]);
+                    xq[e] = mk ? xq[e] : xn;
+                    ld += mk ? 0.f : o[1][e];
+                }
+                if (MT == 1) fw = fn;
+                else if (l + 1 < L) load_fwd(l + 1, fw);
+            }
+            f4 gy;
+            {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ss = fmaf(xq[e], xq[e], ss); gy[e] = valid ? xq[e] * inv_B : 0.f; }
+                ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
+                ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+                float v = (valid && q == 0) ? ld + (-0.5f * ss - prior_c) : 0.f;
+                v = row16_sum(v);
+                if (lane == 0) RED[wave] = v;
+            }
+#ifdef RC_STAMP
+            __builtin_amdgcn_sched_barrier(0); ts1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
+            const float gld = valid ? -inv_B : 0.f;
+            f4 cinT[NIT];                                  // the condition part of the input TILE: + the ones element behind it (d b1)
+#pragma unroll
+            for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cinT[nt][e] = (16 * nt + 4 * e + q == nin0) ? 1.f : cin[nt][e];
+            if (NIT > 1) { wfence(); tile_put(T_in + (NIT - 1) * 16 * TS, cinT[NIT - 1], q, r); }
+            // ---- backward, the two nets of a layer side by side ----
+            FwdW bf;
+            BwdW bb;
+            load_fwd(L - 1, bf);
+            load_bwd(L - 1, bb);
+            for (int l = L - 1; l >= 0; --l) {
+                float *stg0 = STG + (size_t)l * 2 * pl.stg_net;
+                const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
+                xq = XS[l * 64 + lane];
+                FwdW nf;
+                BwdW nbw;
+                if (MT == 1) { const int lp = l > 0 ? l - 1 : 0; load_fwd(lp, nf); load_bwd(lp, nbw); }
+                f4 in[NIT], in0T;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    in[0][e] = mk ? xq[e] + cin[0][e] : cin[0][e];
+                    in0T[e] = mk ? xq[e] + cinT[0][e] : cinT[0][e];
+                }
+                if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
+                wfence();
+                tile_put(T_in, in0T, q, r);
+                f4 hh[2][MT], o[2];
+                nets_fwd(bf, in, hh, o, std::false_type{});
+                f4 es, go[2];                               // d loss / d (net output): s: (1-m)(gy x e^s + gld), t: (1-m) gy
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    es[e] = exp_acc(o[1][e]);
+                    go[1][e] = mk ? 0.f : fmaf(gy[e] * xq[e], es[e], gld);
+                    go[0][e] = mk ? 0.f : gy[e];
+                }
+                tile_put(T_go, go[0], q, r);
+                tile_put(T_go + 16 * TS, go[1], q, r);
+                f4 gp[2][MT], gin[2];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f4 gh[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int e = 0; e < KXT; ++e)
+#pragma unroll
+                        for (int net = 0; net < 2; ++net) gh[net] = mfma16(bb.a2t[net][m][e], go[net][e], gh[net]);
+#pragma unroll
+                    for (int net = 0; net < 2; ++net)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gp[net][m][e] = gh[net][e] * dactf<ACT>(hh[net][m][e]) * hm[m][e];
+                }
+                gin[0] = f4{0.f, 0.f, 0.f, 0.f}; gin[1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int net = 0; net < 2; ++net) gin[net] = mfma16(bb.a1t[net][m][e], gp[net][m][e], gin[net]);
+#pragma unroll
+                for (int net = 0; net < 2; ++net)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {           // d b2
+                        const float v = row16_sum(go[net][e]);
+                        if (r == 0 && xok[e]) stg0[net * pl.stg_net + b1o + 4 * e + q] = v;
+                    }
+                // weight gradients: contractions over the tile's 16 rows through the transposition tiles
+                wfence();
+                float inT[NIT][4], goT[2][4];
+#pragma unroll
+                for (int nt = 0; nt < NIT; ++nt) tile_get(T_in + nt * 16 * TS, q, i, inT[nt]);
+                tile_get(T_go, q, i, goT[0]);
+                tile_get(T_go + 16 * TS, q, i, goT[1]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    wfence();
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) {
+                        tile_put(T_h + net * 32 * TS, hh[net][m], q, r);
+                        tile_put(T_h + net * 32 * TS + 16 * TS, gp[net][m], q, r);
+                    }
+                    wfence();
+                    float hT[2][4], gpT[2][4];
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) {
+                        tile_get(T_h + net * 32 * TS, q, i, hT[net]);
+                        tile_get(T_h + net * 32 * TS + 16 * TS, q, i, gpT[net]);
+                    }
+                    f4 dw2[2], dw1[2][NIT];
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) {
+                        dw2[net] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int nt = 0; nt < NIT; ++nt) dw1[net][nt] = f4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int net = 0; net < 2; ++net) {
+                            dw2[net] = mfma16(goT[net][ks], hT[net][ks], dw2[net]);                        // [out feature 4q+e][hidden 16m + i]
+#pragma unroll
+                            for (int nt = 0; nt < NIT; ++nt)
+                                dw1[net][nt] = mfma16(gpT[net][ks], inT[nt][ks], dw1[net][nt]);            // [hidden 16m + 4q+e][input 16nt + i]
+                        }
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) {
+                        float *stg = stg0 + net * pl.stg_net;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            stg[sS2[m][e]] = dw2[net][e];
+#pragma unroll
+                            for (int nt = 0; nt < NIT; ++nt) stg[sS1[m][nt][e]] = dw1[net][nt][e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    gy[e] = xok[e] ? (mk ? gy[e] + (gin[1][e] + gin[0][e]) : gy[e] * es[e]) : 0.f;          // the nets see x * mask
+                }
+                if (MT == 1) { bf = nf; bb = nbw; }
+                else if (l > 0) { load_fwd(l - 1, bf); load_bwd(l - 1, bb); }
+            }
+        }
+#ifdef RC_STAMP
+        __builtin_amdgcn_sched_barrier(0); ts2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
+        __syncthreads();
+#ifdef RC_STAMP
+        __builtin_amdgcn_sched_barrier(0); ts3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
+        {   // stages in wave order -> gradient; Adam in place (torch.optim.Adam as separately rounded operations, rnvp_common.h)
+            AdamK a;                                     // scalar bookkeeping in double, like torch (make_adam, rnvp_adam.hip)
+            a.step_size = (float)(lr / (1.0 - b1t)); a.bc2_sqrt = (float)sqrt(1.0 - b2t);
+            b1t *= beta1; b2t *= beta2;
+            a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
+            a.wd = (float)wd; a.eps = (float)eps; a.use_wd = wd != 0.0;
+            const float *st0 = lds + pl.oSTG;
+            const float rnpn = 1.0f / (float)npn;
+            // two parameters per pass: their loads, divisions and square roots overlap
+            for (int p0 = tid; p0 < P; p0 += 2 * nthreads) {
+                const int p1 = p0 + nthreads;
+                const bool two = p1 < P;
+                int pp[2] = {p0, two ? p1 : p0};
+                float g[2], pv[2], mv[2], vv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int ln = (int)(((float)pp[u] + 0.5f) * rnpn);              // pp / npn (exact after the correction)
+                    if (ln * npn > pp[u]) --ln;
+                    else if ((ln + 1) * npn <= pp[u]) ++ln;
+                    const int sp = ln * pl.stg_net + (pp[u] - ln * npn);
+                    g[u] = st0[sp];
+                    for (int w = 1; w < nw; ++w) g[u] += st0[(size_t)w * pl.stg_floats + sp];
+                    pv[u] = PAR[pp[u]];
+                    if (pl.mv_lds) { mv[u] = MM[pp[u]]; vv[u] = VV[pp[u]]; }
+                    else { mv[u] = exp_avg[pp[u]]; vv[u] = exp_avg_sq[pp[u]]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) adam_one(pv[u], g[u], mv[u], vv[u], a);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
+                    PAR[pp[u]] = pv[u];
+                    if (pl.mv_lds) { MM[pp[u]] = mv[u]; VV[pp[u]] = vv[u]; }
+                    else { exp_avg[pp[u]] = mv[u]; exp_avg_sq[pp[u]] = vv[u]; }
+                }
+            }
+            if (tid == 0) {
+                float acc = 0.f;
+                for (int w = 0; w < nw; ++w) acc += RED[w];
+                loss_hist[kb] = -acc * inv_B;
+            }
+        }
+#ifdef RC_STAMP
+        __builtin_amdgcn_sched_barrier(0); ts4 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
+        __syncthreads();
+#ifdef RC_STAMP
+        if (kb == 20 && lane == 0)
+            printf("RCSTAMP wave %d: fwd %llu bwd %llu barrier %llu adam %llu barrier2+top %llu\n", wave, ts1 - ts0, ts2 - ts1, ts3 - ts2, ts4 - ts3,
+                   (unsigned long long)__builtin_readcyclecounter() - ts4);
+#endif
+    }
+    for (int p = tid; p < P; p += nthreads) {
+        params[p] = PAR[p];
+        if (pl.mv_lds) { exp_avg[p] = MM[p]; exp_avg_sq[p] = VV[p]; }
+    }
+}
+
+// k-steps of the net input incl. the ones element behind it
+int rc_kit(const KShape &k) { const int ki = (k.d + k.c + 1 + 3) / 4; return ki <= 2 ? 2 : (ki <= 4 ? 4 : 8); }
+
+bool make_rc_plan(const KShape &k, int64_t batch, RcPlan *out) {
+    // measured against the batch-by-batch loop (scripts/resident_time.py, profiles/): one hidden tile wins everywhere
+    // (21-37 vs 41-53 us per step), two win while the net input fits one tile (38 vs 49 us), beyond that the loop's
+    // multi-workgroup kernels are faster (h = 64: 75 vs 37 us)
+    if (k.nh != 1 || k.d > 16 || k.d + k.c > 31 || k.nout[0] > 32 || k.L > 16) return false;
+    if (k.nout[0] > 16 && rc_kit(k) > 4) return false;
+    if (batch < 1 || batch > 16 * kRcMaxWaves) return false;       // up to 8 waves: two per SIMD keep 256 registers each
+    RcPlan p;
+    std::memset(&p, 0, sizeof(p));
+    p.W = (int)((batch + 15) / 16);
+    p.P = 2 * k.npn * k.L;
+    p.stg_net = k.npn + kDump;
+    p.stg_floats = 2 * k.L * p.stg_net;
+    p.xs_floats = k.L * 64 * 4;
+    p.tt_floats = ((rc_kit(k) > 4 ? 2 : 1) + 6) * 16 * TS;
+    for (int mv = 1; mv >= 0; --mv) {
+        int f = 0;
+        p.oPAR = f; f += p.P;
+        p.oM = f; p.oV = f;
+        if (mv) { p.oM = f; f += p.P; p.oV = f; f += p.P; }
+        p.oSTG = f; f += p.W * p.stg_floats;
+        p.oRED = f; f += kMaxWaves;
+        f = (f + 3) & ~3;                       // the saved layer inputs are read and written as float4
+        p.oXS = f; f += p.W * p.xs_floats;
+        p.oTT = f; f += p.W * p.tt_floats;
+        f += 16 * 64 + 64;                      // the unguarded gathers of padding lanes stay inside the allocation
+        p.total_floats = f;
+        p.mv_lds = mv;
+        if ((size_t)f * sizeof(float) <= kLdsMax) { *out = p; return true; }
+    }
+    return false;
+}
+
+bool make_plan(const KShape &k, int64_t batch, RPlan *out) {
+    if (batch < 1 || batch > 16 * kMaxWaves) return false;
+    RPlan p;
+    std::memset(&p, 0, sizeof(p));
+    p.W = (int)((batch + 15) / 16);
+    p.P = 2 * k.npn * k.L;
+    const int wm = k.hmax > k.d ? k.hmax : k.d;
+    int o = 0;
+    p.iX = o; o += k.d;
+    p.iIN = o; o += k.d + k.c;
+    p.iACT = o; o += k.hs;
+    p.iT = o; o += k.d;
+    p.iS = o; o += k.d;
+    p.iGY = o; o += k.d;
+    p.iGIN = o; o += k.d;
+    p.iGA = o; o += wm;
+    p.iGB = o; o += wm;
+    p.iXS = o; o += k.L * k.d;
+    o += 4;                                     // a padded k-step reads up to 3 feature rows past the last image
+    p.img_floats = o * RS;
+    for (int mv = 1; mv >= 0; --mv) {
+        int f = 0;
+        p.oPAR = f; f += p.P;
+        p.oM = f; p.oV = f;
+        if (mv) { p.oM = f; f += p.P; p.oV = f; f += p.P; }
+        p.oSTG = f; f += p.W * p.P;
+        p.oIMG = f; f += p.W * p.img_floats;
+        p.oRED = f; f += kMaxWaves;
+        p.oMSK = f; f += k.L * k.d;
+        p.total_floats = f;
+        p.mv_lds = mv;
+        if ((size_t)f * sizeof(float) <= kLdsMax) { *out = p; return true; }
+    }
+    return false;
+}
+
+std::atomic<uint64_t> g_attr{0};
+
+}  // namespace
+
+bool fits(const KShape &k, int64_t batch_size) {
+    if (k.family == RNVP_FAMILY_VALU) return false;
+    RcPlan rc;
+    if (make_rc_plan(k, batch_size, &rc)) return true;
+#if RNVP_RESIDENT_GENERIC
+    RPlan p;
+    return make_plan(k, batch_size, &p);
+#else
+    return false;
+#endif
+}
+
+namespace {
+
+struct EpochArgs {
+    float *params; const uint8_t *masks; const float *x, *c; const int64_t *perm; int64_t n, batch_size;
+    float *loss_hist, *exp_avg, *exp_avg_sq; double lr, beta1, beta2, eps, wd; int64_t first_step;
+};
+
+template <int MT, int KIT, int ACT, int WMAX>
+int launch_rc_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    auto kern = k_fit_resident_rc<MT, KIT, ACT, WMAX>;
+    static std::atomic<uint64_t> attr_done{0};
+    const int rc = allow_big_lds(reinterpret_cast<const void *>(kern), (int)kLdsMax, attr_done);
+    if (rc) return rc;
+    {
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WMAX), (size_t)p.total_floats * sizeof(float), st, k, p, a.params, a.masks, a.x, a.c,
+                           a.perm, a.n, a.batch_size, a.loss_hist, a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.wd,
+                           std::pow(a.beta1, (double)a.first_step), std::pow(a.beta2, (double)a.first_step));
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+template <int MT, int KIT>
+int launch_rc(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    const bool th = k.act == RNVP_ACT_TANH;
+    if (p.W <= 4)       // one wave per SIMD: 512 registers
+        return th ? launch_rc_w<MT, KIT, RNVP_ACT_TANH, 4>(st, k, p, a) : launch_rc_w<MT, KIT, RNVP_ACT_RELU, 4>(st, k, p, a);
+    return th ? launch_rc_w<MT, KIT, RNVP_ACT_TANH, kRcMaxWaves>(st, k, p, a) : launch_rc_w<MT, KIT, RNVP_ACT_RELU, kRcMaxWaves>(st, k, p, a);
+}
+
+template <int MT>
+int launch_rc_kit(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    const int kit = rc_kit(k);
+    if (kit == 2) return launch_rc<MT, 2>(st, k, p, a);
+    if (kit == 4) return launch_rc<MT, 4>(st, k, p, a);
+    return launch_rc<MT, 8>(st, k, p, a);
+}
+
+}  // namespace
+
+int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *masks, const float *x, const float *c,
+              const int64_t *perm, int64_t n, int64_t batch_size, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+              double lr, double beta1, double beta2, double eps, double weight_decay, int64_t first_step) {
+    if (n == 0) return RNVP_OK;
+    RcPlan rcp;
+    if (make_rc_plan(k, batch_size, &rcp)) {
+        const EpochArgs a{params, masks, x, c, perm, n, batch_size, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                          first_step};
+        if (k.nout[0] <= 16) return launch_rc_kit<1>(st, k, rcp, a);
+        return launch_rc_kit<2>(st, k, rcp, a);
+    }
+    RPlan p;
+    if (!make_plan(k, batch_size, &p)) return RNVP_EUNSUPPORTED;
+    int rc = allow_big_lds(reinterpret_cast<const void *>(k_fit_resident), (int)kLdsMax, g_attr);
+    if (rc) return rc;
+    {
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
+        hipLaunchKernelGGL(k_fit_resident, dim3(1), dim3(64 * p.W), (size_t)p.total_floats * sizeof(float), st, k, p, params, masks, x, c,
+                           perm, n, batch_size, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                           std::pow(beta1, (double)first_step), std::pow(beta2, (double)first_step));
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+}  // namespace resident
+}  // namespace rnvp

@@ -854,3 +854,77 @@ def test_training_forward_on_split_bf16_keeps_the_gradient_tolerance(L, d, c, h,
         assert abs(l - float(lo)) < 1e-5 * max(1.0, abs(float(lo))), prec
         assert np.abs(g - go).max() < 5e-6 * np.abs(go).max() + 1e-9, prec
     assert not np.array_equal(res["f32"][1], res["bx3"][1])          # two different kernels did run
+
+
+RESIDENT_CASES = [
+    # L, d, c, hidden, act, n, batch, weight_decay, user_masks
+    (8, 2, 1, (10,), "tanh", 160, 32, 0.0, False),            # the reference's defaults on a 2-d sample with one condition
+    (8, 2, 0, (10,), "tanh", 100, 32, 0.0, False),            # ragged last batch (4 rows), no condition
+    (4, 5, 3, (10,), "tanh", 75, 25, 0.2, False),             # ragged row tiles; weight decay
+    (2, 16, 4, (16,), "relu", 300, 64, 0.0, False),           # 4 waves, two input tiles
+    (2, 3, 1, (10,), "tanh", 300, 128, 0.0, False),           # 8 waves
+    (2, 16, 15, (13,), "tanh", 70, 32, 0.0, False),           # the widest input: 31 columns
+    (3, 9, 6, (32,), "tanh", 100, 32, 0.0, False),            # two hidden tiles, 15 inputs
+    (16, 3, 2, (20,), "tanh", 64, 16, 0.0, False),            # 16 layers, two hidden tiles (one partly filled)
+    (5, 7, 2, (9,), "relu", 90, 7, 0.0, True),                # user masks, a batch smaller than one tile
+    (6, 13, 2, (17,), "tanh", 200, 48, 0.0, True),
+    (2, 1, 1, (10,), "tanh", 17, 5, 0.0, False),
+]
+
+
+@pytest.mark.parametrize("L,d,c,hidden,act,n,batch,wd,user_masks", RESIDENT_CASES)
+def test_resident_fit_epoch_vs_step_loop(L, d, c, hidden, act, n, batch, wd, user_masks):
+    """rnvp_fit_epoch on a model that fits one CU's LDS runs the whole epoch in one persistent workgroup
+    (rnvp_resident.hip); it must walk the same trajectory as the batch-by-batch rnvp_train_step loop (the kernels the
+    oracle and the reference fixtures pin) up to the rounding of a different summation order, and reproduce itself
+    bit for bit"""
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(L * 100 + d * 10 + n)
+    if user_masks:
+        masks = (rng.random((L, d)) < 0.5).astype(np.uint8); alt = 0
+    else:
+        masks = ((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8); alt = 1 if len(hidden) == 1 else 0
+    shape = _hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=alt)
+    assert _hip.fit_epoch_resident(shape, batch)
+    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=alt, family="valu"), batch)
+    assert not _hip.fit_epoch_resident(shape, 129) and not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (33,), act), batch)
+    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (10, 10), act), batch)
+    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(17, d, c, hidden, act), batch)
+    P = _hip.param_count(shape)
+    p0 = (rng.uniform(-1, 1, P) * 0.3).astype(np.float32)
+    x = _dev(rng.standard_normal((n, d)).astype(np.float32))
+    cc = _dev(rng.standard_normal((n, c)).astype(np.float32)) if c else None
+    mk = _dev(masks, torch.uint8)
+    perm = torch.from_numpy(rng.permutation(n).astype(np.int64)).cuda()
+    nb = (n + batch - 1) // batch
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, batch)
+    adam = (2e-3, 0.9, 0.999, 1e-8, wd)
+
+    def epoch_resident(first_step, p, m, v):
+        hist = torch.full((nb,), float("nan"), device="cuda"); gbuf = torch.empty(P, device="cuda")
+        _hip.fit_epoch(shape, p, mk, x, cc, perm, n, batch, gbuf, hist, m, v, *adam, first_step, ws)
+        return hist
+
+    def epoch_loop(first_step, p, m, v):
+        hist = torch.full((nb,), float("nan"), device="cuda"); gbuf = torch.empty(P, device="cuda")
+        for k in range(nb):
+            rows = min(batch, n - k * batch)
+            _hip.train_step(shape, p, mk, x, cc, perm[k * batch:k * batch + rows].contiguous(), rows, 1.0 / rows, gbuf, hist[k:k + 1], m, v,
+                            *adam, first_step + k, ws)
+        return hist
+
+    out = {}
+    for name, fn in (("resident", epoch_resident), ("loop", epoch_loop), ("again", epoch_resident)):
+        p = _dev(p0).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+        h1 = fn(1, p, m, v)
+        h2 = fn(1 + nb, p, m, v)                      # a second epoch continues the optimizer's step count
+        out[name] = [t.cpu().numpy().astype(np.float64) for t in (torch.cat([h1, h2]), p, m, v)]
+    for a, b in zip(out["resident"], out["again"]):
+        assert np.array_equal(a, b)
+    hr, pr, mr, vr = out["resident"]; hl, pl, ml, vl = out["loop"]
+    assert np.isfinite(hr).all() and np.isfinite(pr).all()
+    np.testing.assert_allclose(hr, hl, rtol=2e-5, atol=2e-5)
+    assert np.abs(pr - pl).mean() < 2e-6 and np.abs(pr - pl).max() < 2e-4
+    assert np.abs(mr - ml).max() < 1e-5 * max(1.0, np.abs(ml).max())
+    assert np.abs(vr - vl).max() < 1e-5 * max(1.0, np.abs(vl).max())
+    assert np.abs(pr - p0).max() > 1e-3            # it did train
