@@ -1,24 +1,26 @@
 // rnvp_resident.hip -- "resident" fit: one epoch of a SMALL flow at a SMALL batch size in ONE persistent workgroup (gfx950).
 //
-// The reference's defaults -- hidden=(10,), 8 layers, batch_size=32 (/root/reference/probaforms/models/realnvp.py:161-176),
-// its docstring network hidden=(10, 20, 15) (realnvp.py:22-38) -- are flows of a few thousand parameters stepped on a few
-// dozen rows: a step is a chain of ~50 tiny dependent GEMMs, and the three launches of the general path (weight re-pack,
-// loss + gradient, reduce + Adam) cost more than the arithmetic (41 us per step for d = 2, h = 10; 245 us for
-// hidden=(10,20,15)).  A CU's 160 KB of LDS holds such a model whole, so the batch loop of RealNVP.fit
+// The reference's defaults -- hidden=(10,), 8 layers, batch_size=32 (/root/reference/probaforms/models/realnvp.py:161-176)
+// -- are a flow of ~1000 parameters stepped on a few dozen rows: a step is a chain of ~50 tiny dependent GEMMs, and the
+// three launches of the general path (weight re-pack, loss + gradient, reduce + Adam) cost more than the arithmetic
+// (41 us per step for d = 2, h = 10).  A CU's 160 KB of LDS holds such a model whole, so the batch loop of RealNVP.fit
 // (realnvp.py:237-254) runs here as ONE launch per epoch:
 //   * the flat parameters (reference order) live in LDS for the whole epoch, and so do Adam's moments when they fit;
-//   * wave w owns rows 16w .. 16w+15 of every batch; its activations are a wave-private LDS image [feature][17], so the
-//     forward / backward chain of a step needs no workgroup barrier at all (a wave's DS operations execute in order);
-//   * every Linear is v_mfma_f32_16x16x4_f32 computed transposed (features on M, rows on N) as in rnvp_lmm.hip, the A
-//     operand read straight from the LDS-resident W (forward: W[out][in], input gradient: W[out][in]^T), the weight
-//     gradient dW = gP^T . in as a third MFMA contraction over the tile's 16 rows, written to the wave's stage;
+//   * wave w owns rows 16w .. 16w+15 of every batch and runs its forward / backward chain register to register on
+//     v_mfma_f32_16x16x4_f32 (layout below): no workgroup barrier inside a step;
+//   * the weight gradients of the wave's 16 rows are a third kind of MFMA contraction (over the rows, operands
+//     transposed through wave-private LDS tiles), written to the wave's stage in the reference's flat order;
 //   * one barrier, then all threads add the stages in wave order (deterministic), apply Adam in place in LDS and write
-//     the batch loss; one more barrier and the next batch starts.  Parameters and moments go back to HBM once per epoch.
+//     the batch loss; one more barrier and the next batch starts (its rows were requested a step ahead).  Parameters and
+//     moments go back to HBM once per epoch.
+// A single wave issues one VALU instruction per 4 cycles, so what bounds a step here is its INSTRUCTION COUNT (about
+// 180 per layer forward, 900 backward): everything that does not depend on the data -- gather offsets, padding masks,
+// stage offsets, mask bits -- is computed once per launch, and the next layer's weight fragments are requested while the
+// current layer computes.  Measured (scripts/resident_time.py, profiles/): 21 us per step for the defaults.
 // Same arithmetic per element as the other kernel families (tanh through exp2 / rcp, torch.optim.Adam as separately
 // rounded operations); the summation ORDER over rows and hidden units differs, so results agree with them to rounding,
 // not bit for bit -- run to run this path is bit-reproducible.
 #include "rnvp_common.h"
-#include "rnvp_generic_net.h"
 #include "rnvp_resident.h"
 
 #include <cmath>
@@ -28,12 +30,8 @@ namespace resident {
 namespace {
 
 using f4 = __attribute__((ext_vector_type(4))) float;
-constexpr int RS = 17;                 // row stride of an LDS image [feature][RS]: 16 rows + 1
 constexpr int kMaxWaves = 16;
 constexpr size_t kLdsMax = 160 * 1024;
-#ifndef RNVP_RESIDENT_GENERIC
-#define RNVP_RESIDENT_GENERIC 0      // the LDS-image form for several hidden layers: correct, but no faster than the step loop yet
-#endif
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -44,269 +42,7 @@ __device__ __forceinline__ void wfence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct RPlan {
-    int W;                 // waves of the workgroup = 16-row tiles of a full batch
-    int P;                 // parameters
-    int mv_lds;            // Adam's moments are LDS-resident too
-    int oPAR, oM, oV, oSTG, oIMG, oRED, oMSK;      // float offsets
-    int img_floats;        // one wave's image
-    int iX, iIN, iACT, iT, iS, iGY, iGIN, iGA, iGB, iXS;      // feature-row offsets inside an image
-    int total_floats;
-};
-
-// out^T[nout x 16] = act(W in^T + b) for the wave's tile; W [nout][nin], b [nout] are LDS-resident; act < 0: none
-__device__ __forceinline__ void lin_fwd(const float *Wk, const float *bk, int nin, int nout, const float *in, float *out,
-                                        int act, int lane) {
-    const int q = lane >> 4, i = lane & 15;
-    const int MT = (nout + 15) >> 4, KS = (nin + 3) >> 2;
-    for (int m = 0; m < MT; ++m) {
-        f4 acc;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const int o = 16 * m + 4 * q + e; acc[e] = o < nout ? bk[o] : 0.f; }
-        const int row = 16 * m + i;
-        const bool rok = row < nout;
-        const float *wrow = Wk + (rok ? row : 0) * nin;
-        for (int ks = 0; ks < KS; ++ks) {
-            const int col = 4 * ks + q;
-            const float a = (rok && col < nin) ? wrow[col] : 0.f;
-            acc = mfma16(a, in[col * RS + i], acc);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int o = 16 * m + 4 * q + e;
-            if (o < nout) out[o * RS + i] = act >= 0 ? act_fwd(acc[e], act) : acc[e];
-        }
-    }
-}
-
-// input gradient gprev^T[nin_eff x 16] = W^T gcur^T (first nin_eff inputs only)
-__device__ __forceinline__ void lin_bwd_in(const float *Wk, int nin, int nout, int nin_eff, const float *gcur, float *gprev, int lane) {
-    const int q = lane >> 4, i = lane & 15;
-    const int MT = (nin_eff + 15) >> 4, KS = (nout + 3) >> 2;
-    for (int m = 0; m < MT; ++m) {
-        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-        const int in = 16 * m + i;
-        const bool iok = in < nin_eff;
-        for (int ks = 0; ks < KS; ++ks) {
-            const int out = 4 * ks + q;
-            const float a = (iok && out < nout) ? Wk[out * nin + in] : 0.f;
-            acc = mfma16(a, gcur[out * RS + i], acc);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ii = 16 * m + 4 * q + e;
-            if (ii < nin_eff) gprev[ii * RS + i] = acc[e];
-        }
-    }
-}
-
-// weight gradient of the tile: dW[o][j] = sum_rows gP[o][row] in[j][row], db[o] = sum_rows gP[o][row] (the ones column),
-// written (not added) into the wave's stage in the reference's flat order
-__device__ __forceinline__ void lin_wgrad(const float *gP, const float *inp, int nin, int nout, float *stgW, float *stgB, int lane) {
-    const int q = lane >> 4, i = lane & 15;
-    const int MT = (nout + 15) >> 4, PT = (nin + 1 + 15) >> 4;
-    for (int m = 0; m < MT; ++m) {
-        const int o_a = 16 * m + i;
-        float a[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) a[ks] = o_a < nout ? gP[o_a * RS + 4 * ks + q] : 0.f;
-        for (int p = 0; p < PT; ++p) {
-            const int j = 16 * p + i;
-            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float b = j < nin ? inp[j * RS + 4 * ks + q] : (j == nin ? 1.f : 0.f);
-                acc = mfma16(a[ks], b, acc);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = 16 * m + 4 * q + e;
-                if (o < nout) {
-                    if (j < nin) stgW[o * nin + j] = acc[e];
-                    else if (j == nin) stgB[o] = acc[e];
-                }
-            }
-        }
-    }
-}
-
-// one s or t net forward on the wave's tile; hidden activations at running offsets in hbuf (kept for the backward)
-__device__ __forceinline__ void net_fwd(const float *pn, const KShape &s, const float *in0, float *hbuf, float *out, int lane) {
-    const float *cur = in0;
-    float *dst = hbuf;
-    for (int k = 0; k <= s.nh; ++k) {
-        const bool last = k == s.nh;
-        float *ob = last ? out : dst;
-        wfence();
-        lin_fwd(pn + s.woff[k], pn + s.boff[k], s.nin[k], s.nout[k], cur, ob, last ? -1 : s.act, lane);
-        cur = ob;
-        if (!last) dst += s.nout[k] * RS;
-    }
-    wfence();
-}
-
-// one net backward: GA holds d loss / d (net output); per Linear (last to first) activation derivative, weight gradient
-// into the stage, input gradient; Linear 0's input gradient (x columns only) lands in gx0 (not masked, not accumulated)
-__device__ __forceinline__ void net_bwd(const float *pn, float *stg, const KShape &s, const float *in0, const float *ACT, float *GA,
-                                        float *GB, float *gx0, int lane) {
-    const int q = lane >> 4, r = lane & 15;
-    float *gcur = GA, *gprev = GB;
-    int aoff = s.hs;
-    for (int k = s.nh; k >= 0; --k) {
-        const int nin = s.nin[k], nout = s.nout[k];
-        if (k < s.nh) {
-            aoff -= nout;
-            const float *ak = ACT + aoff * RS;
-            for (int f = q; f < nout; f += 4) {
-                const float a = ak[f * RS + r], gv = gcur[f * RS + r];
-                gcur[f * RS + r] = (s.act == RNVP_ACT_TANH) ? gv * (1.f - a * a) : (a > 0.f ? gv : 0.f);
-            }
-        }
-        wfence();
-        const float *inp = (k == 0) ? in0 : ACT + (aoff - nin) * RS;
-        lin_wgrad(gcur, inp, nin, nout, stg + s.woff[k], stg + s.boff[k], lane);
-        if (k == 0) lin_bwd_in(pn + s.woff[0], nin, nout, s.d, gcur, gx0, lane);
-        else lin_bwd_in(pn + s.woff[k], nin, nout, nin, gcur, gprev, lane);
-        wfence();
-        float *tmp = gcur; gcur = gprev; gprev = tmp;
-    }
-}
-
-__global__ void __launch_bounds__(64 * kMaxWaves)
-k_fit_resident(KShape s, RPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
-               const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch, float *__restrict__ loss_hist,
-               float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1, double beta2, double eps,
-               double wd, double b1t, double b2t) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15;
-    const int d = s.d, cd = s.c, L = s.L, P = pl.P;
-    float *PAR = lds + pl.oPAR, *MM = lds + pl.oM, *VV = lds + pl.oV, *STG = lds + pl.oSTG + (size_t)wave * P;
-    float *IMG = lds + pl.oIMG + (size_t)wave * pl.img_floats, *RED = lds + pl.oRED;
-    const float *MSK = lds + pl.oMSK;                  // masks as 0 / 1 floats
-    float *X = IMG + pl.iX * RS, *IN = IMG + pl.iIN * RS, *ACT = IMG + pl.iACT * RS, *T = IMG + pl.iT * RS, *S = IMG + pl.iS * RS;
-    float *GY = IMG + pl.iGY * RS, *GIN = IMG + pl.iGIN * RS, *GA = IMG + pl.iGA * RS, *GB = IMG + pl.iGB * RS, *XS = IMG + pl.iXS * RS;
-    for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;          // padded k-steps read rows past an image: keep them finite
-    __syncthreads();
-    for (int p = tid; p < P; p += nthreads) {
-        PAR[p] = params[p];
-        if (pl.mv_lds) { MM[p] = exp_avg[p]; VV[p] = exp_avg_sq[p]; }
-    }
-    for (int e = tid; e < L * d; e += nthreads) lds[pl.oMSK + e] = (float)masks[e];
-    __syncthreads();
-    const float prior_c = 0.5f * (float)d * kLog2Pi;
-    const int64_t nb = (n + batch - 1) / batch;
-    for (int64_t kb = 0; kb < nb; ++kb) {
-        const int64_t s0 = kb * batch;
-        const int rows = (int)((n - s0 < batch) ? n - s0 : batch);
-        const float inv_B = 1.0f / (float)rows;
-        const int nw = (rows + 15) >> 4;
-        if (wave < nw) {
-            const int base = wave * 16;
-            const bool valid = base + r < rows;
-            const int64_t src = valid ? perm[s0 + base + r] : 0;
-            for (int j = q; j < d; j += 4) X[j * RS + r] = valid ? x[src * d + j] : 0.f;
-            for (int j = q; j < cd; j += 4) IN[(d + j) * RS + r] = valid ? c[src * cd + j] : 0.f;
-            float ld = 0.f;
-            // ---- forward: z, log|det J| (realnvp.py:91-101, nflow.py:107-117) ----
-            for (int l = 0; l < L; ++l) {
-                const float *m = MSK + l * d;
-                const float *pn = PAR + (size_t)l * 2 * s.npn;
-                wfence();
-                for (int j = q; j < d; j += 4) {
-                    const float xv = X[j * RS + r];
-                    XS[(l * d + j) * RS + r] = xv;                               // layer input, for the backward
-                    IN[j * RS + r] = m[j] != 0.f ? xv : 0.f;
-                }
-                net_fwd(pn, s, IN, ACT, T, lane);
-                net_fwd(pn + s.npn, s, IN, ACT, S, lane);
-                for (int j = q; j < d; j += 4)
-                    if (m[j] == 0.f) { const float sv = S[j * RS + r]; X[j * RS + r] = fmaf(X[j * RS + r], expf(sv), T[j * RS + r]); ld += sv; }
-            }
-            wfence();
-            {   // loss terms and the seed of the backward
-                float ss = 0.f;
-                for (int j = q; j < d; j += 4) { const float zv = X[j * RS + r]; ss = fmaf(zv, zv, ss); GY[j * RS + r] = valid ? zv * inv_B : 0.f; }
-                ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
-                ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-                float v = (valid && q == 0) ? ld + (-0.5f * ss - prior_c) : 0.f;
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (lane == 0) RED[wave] = v;
-            }
-            const float gld = valid ? -inv_B : 0.f;
-            // ---- backward (the hand-derived chain of SURVEY.md 3.3, as rnvp_lmm.hip) ----
-            for (int l = L - 1; l >= 0; --l) {
-                const float *m = MSK + l * d;
-                const float *pn = PAR + (size_t)l * 2 * s.npn;
-                float *stg = STG + (size_t)l * 2 * s.npn;
-                wfence();
-                for (int j = q; j < d; j += 4) {
-                    const float xv = XS[(l * d + j) * RS + r];
-                    X[j * RS + r] = xv;
-                    IN[j * RS + r] = m[j] != 0.f ? xv : 0.f;
-                    GIN[j * RS + r] = 0.f;
-                }
-                for (int net = 1; net >= 0; --net) {             // s first (exp(s) is needed below), then t
-                    const float *pnn = pn + (size_t)net * s.npn;
-                    net_fwd(pnn, s, IN, ACT, net ? S : T, lane);
-                    for (int j = q; j < d; j += 4) {             // d loss / d (net output): s: (1-m)(gy x e^s + gld), t: (1-m) gy
-                        float v = 0.f;
-                        if (m[j] == 0.f) {
-                            const float gy = GY[j * RS + r];
-                            v = net ? fmaf(gy * X[j * RS + r], expf(S[j * RS + r]), gld) : gy;
-                        }
-                        GA[j * RS + r] = v;
-                    }
-                    // Linear 0's input gradient lands in T: free here (the s net runs before T is recomputed; the t net's
-                    // output is not needed once its seed is written)
-                    net_bwd(pnn, stg + (size_t)net * s.npn, s, IN, ACT, GA, GB, T, lane);
-                    for (int j = q; j < d; j += 4)
-                        if (m[j] != 0.f) GIN[j * RS + r] += T[j * RS + r];                       // the nets see x * mask
-                    wfence();
-                }
-                for (int j = q; j < d; j += 4) {
-                    const float gy = GY[j * RS + r];
-                    GY[j * RS + r] = (m[j] != 0.f ? gy : gy * expf(S[j * RS + r])) + GIN[j * RS + r];
-                }
-            }
-        }
-        __syncthreads();
-        {   // stages in wave order -> gradient; Adam in place (torch.optim.Adam as separately rounded operations, rnvp_common.h)
-            AdamK a;                                     // scalar bookkeeping in double, like torch (make_adam, rnvp_adam.hip)
-            a.step_size = (float)(lr / (1.0 - b1t)); a.bc2_sqrt = (float)sqrt(1.0 - b2t);
-            b1t *= beta1; b2t *= beta2;
-            a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
-            a.wd = (float)wd; a.eps = (float)eps; a.use_wd = wd != 0.0;
-            const float *st0 = lds + pl.oSTG;
-            for (int p = tid; p < P; p += nthreads) {
-                float g = st0[p];
-                for (int w = 1; w < nw; ++w) g += st0[(size_t)w * P + p];
-                float pv = PAR[p];
-                if (pl.mv_lds) {
-                    float mv = MM[p], vv = VV[p];
-                    adam_one(pv, g, mv, vv, a);
-                    MM[p] = mv; VV[p] = vv;
-                } else {
-                    float mv = exp_avg[p], vv = exp_avg_sq[p];
-                    adam_one(pv, g, mv, vv, a);
-                    exp_avg[p] = mv; exp_avg_sq[p] = vv;
-                }
-                PAR[p] = pv;
-            }
-            if (tid == 0) {
-                float acc = 0.f;
-                for (int w = 0; w < nw; ++w) acc += RED[w];
-                loss_hist[kb] = -acc * inv_B;
-            }
-        }
-        __syncthreads();
-    }
-    for (int p = tid; p < P; p += nthreads) {
-        params[p] = PAR[p];
-        if (pl.mv_lds) { exp_avg[p] = MM[p]; exp_avg_sq[p] = VV[p]; }
-    }
-}
-
-// ---- register-chained form: ONE hidden layer of at most 32 units, d <= 16, d + cdim <= 31 (the reference's default shape) ----
+// ---- layout: ONE hidden layer of at most 32 units, d <= 16, d + cdim <= 31 ----
 // Every vector of a row -- the net input [x * mask | c], a tile of 16 hidden units, s, t and their gradients -- is an f4
 // per lane and 16 elements: lane (q = lane >> 4, r = lane & 15) keeps elements 4e + q (e = 0..3) of row r.  An MFMA's D
 // operand comes out in exactly that form when the A rows are gathered in the order pi(i) = 4 (i & 3) + (i >> 2), and it IS
@@ -802,56 +538,13 @@ bool make_rc_plan(const KShape &k, int64_t batch, RcPlan *out) {
     return false;
 }
 
-bool make_plan(const KShape &k, int64_t batch, RPlan *out) {
-    if (batch < 1 || batch > 16 * kMaxWaves) return false;
-    RPlan p;
-    std::memset(&p, 0, sizeof(p));
-    p.W = (int)((batch + 15) / 16);
-    p.P = 2 * k.npn * k.L;
-    const int wm = k.hmax > k.d ? k.hmax : k.d;
-    int o = 0;
-    p.iX = o; o += k.d;
-    p.iIN = o; o += k.d + k.c;
-    p.iACT = o; o += k.hs;
-    p.iT = o; o += k.d;
-    p.iS = o; o += k.d;
-    p.iGY = o; o += k.d;
-    p.iGIN = o; o += k.d;
-    p.iGA = o; o += wm;
-    p.iGB = o; o += wm;
-    p.iXS = o; o += k.L * k.d;
-    o += 4;                                     // a padded k-step reads up to 3 feature rows past the last image
-    p.img_floats = o * RS;
-    for (int mv = 1; mv >= 0; --mv) {
-        int f = 0;
-        p.oPAR = f; f += p.P;
-        p.oM = f; p.oV = f;
-        if (mv) { p.oM = f; f += p.P; p.oV = f; f += p.P; }
-        p.oSTG = f; f += p.W * p.P;
-        p.oIMG = f; f += p.W * p.img_floats;
-        p.oRED = f; f += kMaxWaves;
-        p.oMSK = f; f += k.L * k.d;
-        p.total_floats = f;
-        p.mv_lds = mv;
-        if ((size_t)f * sizeof(float) <= kLdsMax) { *out = p; return true; }
-    }
-    return false;
-}
-
-std::atomic<uint64_t> g_attr{0};
-
 }  // namespace
 
 bool fits(const KShape &k, int64_t batch_size) {
     if (k.family == RNVP_FAMILY_VALU) return false;
     RcPlan rc;
     if (make_rc_plan(k, batch_size, &rc)) return true;
-#if RNVP_RESIDENT_GENERIC
-    RPlan p;
-    return make_plan(k, batch_size, &p);
-#else
     return false;
-#endif
 }
 
 namespace {
@@ -906,18 +599,7 @@ int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *mas
         if (k.nout[0] <= 16) return launch_rc_kit<1>(st, k, rcp, a);
         return launch_rc_kit<2>(st, k, rcp, a);
     }
-    RPlan p;
-    if (!make_plan(k, batch_size, &p)) return RNVP_EUNSUPPORTED;
-    int rc = allow_big_lds(reinterpret_cast<const void *>(k_fit_resident), (int)kLdsMax, g_attr);
-    if (rc) return rc;
-    {
-        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
-        hipLaunchKernelGGL(k_fit_resident, dim3(1), dim3(64 * p.W), (size_t)p.total_floats * sizeof(float), st, k, p, params, masks, x, c,
-                           perm, n, batch_size, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
-                           std::pow(beta1, (double)first_step), std::pow(beta2, (double)first_step));
-    }
-    RNVP_HIP_TRY(hipGetLastError());
-    return RNVP_OK;
+    return RNVP_EUNSUPPORTED;
 }
 
 }  // namespace resident
