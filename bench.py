@@ -270,6 +270,28 @@ def secondary_configs(Xh, Ch, dev):
         out["c2_batch%d" % bs] = {"workload": "the C2 flow at batch_size=%d%s: %d fused steps in one rnvp_fit_epoch call (tile-split "
                                               "training kernel)" % (bs, " (the reference's default)" if bs == 32 else "", nsteps),
                                   "us_per_step": us, "rows_per_s": bs / (us * 1e-6)}
+    # the reference's DEFAULT network on 2-d data (README example, BASELINE.json configs[0]): hidden=(10,), 8 layers, batch 32 --
+    # small enough that rnvp_fit_epoch runs the whole epoch as one persistent launch (rnvp_resident.hip)
+    torch.manual_seed(0)
+    d1, c1 = 2, 1
+    layers = [RealNVPLayer(d1, c1, (torch.arange(d1) + i) % 2, (10,), "tanh") for i in range(8)]
+    nf1 = NormalizingFlow(layers, StandardNormalPrior(d1, dev, host_rng=False))
+    for p in nf1.parameters():
+        p.data = p.data.to(dev)
+    eng1 = nf1.engine(); opt1 = _engine.FlatAdam(eng1.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+    bs, nsteps = 32, 2048
+    X1 = X[:bs * nsteps, :d1].contiguous(); C1 = C[:bs * nsteps, :c1].contiguous()
+    perm = torch.randperm(bs * nsteps, device=dev); losses = torch.zeros(nsteps, device=dev)
+    eng1.fit_epoch(opt1, X1, C1, perm, bs, losses)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    eng1.fit_epoch(opt1, X1, C1, perm, bs, losses)
+    e1.record(); torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) / nsteps * 1e3
+    out["c1_defaults_batch32"] = {"workload": "the reference's default network (d=2, cond=1, hidden=(10,), 8 layers) at its default "
+                                              "batch_size=32: %d steps in one rnvp_fit_epoch call" % nsteps,
+                                  "one_launch_per_epoch": bool(_hip.fit_epoch_resident(eng1.shape, bs)),
+                                  "us_per_step": us, "rows_per_s": bs / (us * 1e-6), "final_loss": float(losses[-1])}
     out["c2_precision_ab"] = precision_ab(Xh, Ch, dev)
     out.update(secondary_c3_c4(dev))
     return out

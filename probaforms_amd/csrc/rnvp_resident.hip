@@ -103,15 +103,16 @@ __device__ __forceinline__ void tile_get(const float *T, int q, int i, float (&o
     for (int ks = 0; ks < 4; ++ks) o[ks] = T[i * TS + 4 * ks + q];
 }
 
-// MT hidden tiles, KIT k-steps of the net input (4 KIT >= d + cdim + 1), WMAX waves
-template <int MT, int KIT, int ACT, int WMAX>
+// MT hidden tiles, KIT k-steps of the net input (4 KIT >= d + cdim + 1), WMAX waves, DT slots of x that hold features
+// (4 DT >= d: 2-d data needs one of the four)
+template <int MT, int KIT, int ACT, int WMAX, int DT>
 __global__ void __launch_bounds__(64 * WMAX)
 k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
                   const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch,
                   float *__restrict__ loss_hist, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1,
                   double beta2, double eps, double wd, double b1t, double b2t) {
     constexpr int NIT = KIT > 4 ? 2 : 1;               // 16-element tiles of the net input
-    constexpr int KXT = KIT < 4 ? KIT : 4;             // k-steps over the d <= 16 features of x
+    constexpr int KXT = KIT < DT ? KIT : DT;           // k-steps over the features of x
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, i = r;
     const int d = s.d, cd = s.c, L = s.L, P = pl.P, h = s.nout[0], nin0 = d + cd, npn = s.npn;
@@ -280,15 +281,16 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
                 const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
                 XS[l * 64 + lane] = xq;                                    // layer input, for the backward (lane-private)
                 f4 in[NIT];
+                in[0] = cin[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) in[0][e] = ((mb >> e) & 1u) ? xq[e] + cin[0][e] : cin[0][e];      // [x * mask | c]
+                for (int e = 0; e < DT; ++e) in[0][e] = ((mb >> e) & 1u) ? xq[e] + cin[0][e] : cin[0][e];     // [x * mask | c]
                 if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
                 FwdW fn;
                 if (MT == 1) load_fwd(l + 1 < L ? l + 1 : l, fn);
                 f4 hh[2][MT], o[2];
                 nets_fwd(fw, in, hh, o, std::true_type{});
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < DT; ++e) {
                     const bool mk = (mb >> e) & 1u;
                     const float xn = fmaf(xq[e], exp_acc(o[1][e]), o[0][e]);
                     xq[e] = mk ? xq[e] : xn;
@@ -301,7 +303,9 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
             {
                 float ss = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ss = fmaf(xq[e], xq[e], ss); gy[e] = valid ? xq[e] * inv_B : 0.f; }
+                for (int e = 0; e < 4; ++e) gy[e] = 0.f;
+#pragma unroll
+                for (int e = 0; e < DT; ++e) { ss = fmaf(xq[e], xq[e], ss); gy[e] = valid ? xq[e] * inv_B : 0.f; }
                 ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
                 ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
                 float v = (valid && q == 0) ? ld + (-0.5f * ss - prior_c) : 0.f;
@@ -331,8 +335,9 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
                 BwdW nbw;
                 if (MT == 1) { const int lp = l > 0 ? l - 1 : 0; load_fwd(lp, nf); load_bwd(lp, nbw); }
                 f4 in[NIT], in0T;
+                in[0] = cin[0]; in0T = cinT[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < DT; ++e) {
                     const bool mk = (mb >> e) & 1u;
                     in[0][e] = mk ? xq[e] + cin[0][e] : cin[0][e];
                     in0T[e] = mk ? xq[e] + cinT[0][e] : cinT[0][e];
@@ -343,15 +348,19 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
                 f4 hh[2][MT], o[2];
                 nets_fwd(bf, in, hh, o, std::false_type{});
                 f4 es, go[2];                               // d loss / d (net output): s: (1-m)(gy x e^s + gld), t: (1-m) gy
+                go[0] = f4{0.f, 0.f, 0.f, 0.f}; go[1] = f4{0.f, 0.f, 0.f, 0.f}; es = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < DT; ++e) {
                     const bool mk = (mb >> e) & 1u;
                     es[e] = exp_acc(o[1][e]);
                     go[1][e] = mk ? 0.f : fmaf(gy[e] * xq[e], es[e], gld);
                     go[0][e] = mk ? 0.f : gy[e];
                 }
-                tile_put(T_go, go[0], q, r);
-                tile_put(T_go + 16 * TS, go[1], q, r);
+#pragma unroll
+                for (int e = 0; e < DT; ++e) {              // the other elements of the two tiles stay at their initial zeros
+                    T_go[(4 * e + q) * TS + r] = go[0][e];
+                    T_go[16 * TS + (4 * e + q) * TS + r] = go[1][e];
+                }
                 f4 gp[2][MT], gin[2];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -375,7 +384,7 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
 #pragma unroll
                 for (int net = 0; net < 2; ++net)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {           // d b2
+                    for (int e = 0; e < DT; ++e) {          // d b2
                         const float v = row16_sum(go[net][e]);
                         if (r == 0 && xok[e]) stg0[net * pl.stg_net + b1o + 4 * e + q] = v;
                     }
@@ -429,7 +438,7 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < DT; ++e) {
                     const bool mk = (mb >> e) & 1u;
                     gy[e] = xok[e] ? (mk ? gy[e] + (gin[1][e] + gin[0][e]) : gy[e] * es[e]) : 0.f;          // the nets see x * mask
                 }
@@ -554,9 +563,9 @@ struct EpochArgs {
     float *loss_hist, *exp_avg, *exp_avg_sq; double lr, beta1, beta2, eps, wd; int64_t first_step;
 };
 
-template <int MT, int KIT, int ACT, int WMAX>
+template <int MT, int KIT, int ACT, int WMAX, int DT>
 int launch_rc_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
-    auto kern = k_fit_resident_rc<MT, KIT, ACT, WMAX>;
+    auto kern = k_fit_resident_rc<MT, KIT, ACT, WMAX, DT>;
     static std::atomic<uint64_t> attr_done{0};
     const int rc = allow_big_lds(reinterpret_cast<const void *>(kern), (int)kLdsMax, attr_done);
     if (rc) return rc;
@@ -570,12 +579,19 @@ int launch_rc_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArg
     return RNVP_OK;
 }
 
-template <int MT, int KIT>
-int launch_rc(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+template <int MT, int KIT, int DT>
+int launch_rc_d(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
     const bool th = k.act == RNVP_ACT_TANH;
     if (p.W <= 4)       // one wave per SIMD: 512 registers
-        return th ? launch_rc_w<MT, KIT, RNVP_ACT_TANH, 4>(st, k, p, a) : launch_rc_w<MT, KIT, RNVP_ACT_RELU, 4>(st, k, p, a);
-    return th ? launch_rc_w<MT, KIT, RNVP_ACT_TANH, kRcMaxWaves>(st, k, p, a) : launch_rc_w<MT, KIT, RNVP_ACT_RELU, kRcMaxWaves>(st, k, p, a);
+        return th ? launch_rc_w<MT, KIT, RNVP_ACT_TANH, 4, DT>(st, k, p, a) : launch_rc_w<MT, KIT, RNVP_ACT_RELU, 4, DT>(st, k, p, a);
+    return th ? launch_rc_w<MT, KIT, RNVP_ACT_TANH, kRcMaxWaves, DT>(st, k, p, a)
+              : launch_rc_w<MT, KIT, RNVP_ACT_RELU, kRcMaxWaves, DT>(st, k, p, a);
+}
+
+template <int MT, int KIT>
+int launch_rc(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    if (k.d <= 4) return launch_rc_d<MT, KIT, 1>(st, k, p, a);      // 2-d toy data, the reference's examples: one x slot
+    return launch_rc_d<MT, KIT, 4>(st, k, p, a);
 }
 
 template <int MT>
