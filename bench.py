@@ -539,7 +539,7 @@ def main():
     torch.cuda.synchronize()
     # HIP events around the hot kernels, recorded by the library on the stream it launches on, for every
     # launch of the timed region
-    _hip.profile_enable(args.steps * nb + 8)
+    _hip.profile_enable(args.steps * (nb + 1) + 8)
     if dp:
         dist.barrier()
     t0 = time.perf_counter()

@@ -14,4 +14,4 @@ print("fit %.3f s (%d steps, %.1f us/step, %.0f row-visits/s)  final loss %.4f  
       (t1 - t0, len(m.loss_history), (t1 - t0) / len(m.loss_history) * 1e6, 1000 * m.n_epochs / (t1 - t0),
        float(m.loss_history[-1]), t2 - t1))
 t0 = time.perf_counter(); m.fit(X, C); torch.cuda.synchronize(); t1 = time.perf_counter()
-print("second fit %.3f s (%.1f us/step)" % (t1 - t0, (t1 - t0) / 3200 * 1e6))
+print("second fit %.3f s (%.1f us/step)" % (t1 - t0, (t1 - t0) / (32 * m.n_epochs) * 1e6))
