@@ -218,3 +218,28 @@ def test_shape_struct_matches_the_c_header():
     assert _hip.FAMILIES == {"auto": 0, "valu": 1, "lmm": 2}
     assert _hip.SMALL_CALLS == {"invariant": 0, "latency": 1}
     assert _hip.PRECISIONS == {"auto": 0, "f32": 1, "bx3": 2}
+
+
+def test_kernel_selection_policy_is_host_logic():
+    """which kernels serve a shape is decided on the host and needs no GPU: the resident (one launch per epoch) fit for
+    the reference's default network, the CVAE families, invalid shapes refused"""
+    from probaforms_amd import _hip
+    R = _hip.RnvpShape.make
+    default = R(8, 2, 1, (10,), "tanh", alt_masks=1)                  # RealNVP() defaults on 2-d data with one condition
+    assert _hip.fit_epoch_resident(default, 32) and _hip.fit_epoch_resident(default, 1) and _hip.fit_epoch_resident(default, 64)
+    assert not _hip.fit_epoch_resident(default, 129)                  # more than 8 waves of 16 rows
+    assert not _hip.fit_epoch_resident(R(8, 2, 1, (10,), "tanh", family="valu"), 32)
+    assert not _hip.fit_epoch_resident(R(8, 16, 4, (128,), "tanh", alt_masks=1), 32)      # C2: 75 k parameters do not fit LDS
+    assert not _hip.fit_epoch_resident(R(8, 2, 1, (10, 20, 15), "tanh"), 32)              # several hidden layers: the step loop
+    assert not _hip.fit_epoch_resident(R(8, 2, 1, (33,), "tanh"), 32)
+    assert _hip.fit_epoch_resident(R(8, 2, 1, (32,), "relu"), 32) and not _hip.fit_epoch_resident(R(4, 16, 4, (32,), "relu"), 32)
+    assert not _hip.fit_epoch_resident(R(17, 2, 1, (10,), "tanh"), 32) and _hip.fit_epoch_resident(R(16, 2, 1, (10,), "tanh"), 32)
+    assert not _hip.fit_epoch_resident(R(2, 17, 0, (10,), "tanh"), 32) and not _hip.fit_epoch_resident(R(2, 16, 16, (10,), "tanh"), 32)
+    Cv = _hip.CvaeShape.make
+    assert _hip.cvae_kernel_path(Cv(16, 4, 2, (128,), "tanh")) == _hip.PATH_MFMA
+    assert _hip.cvae_kernel_path(Cv(16, 4, 2, (128,), "tanh", family="lmm")) == _hip.PATH_LMM
+    assert _hip.cvae_kernel_path(Cv(16, 4, 2, (128,), "tanh", family="generic")) == _hip.PATH_GENERIC
+    assert _hip.cvae_kernel_path(Cv(4, 2, 3, (7, 9), "relu")) == _hip.PATH_LMM
+    assert _hip.cvae_kernel_path(Cv(10, 5, 10, (700, 700), "relu")) == _hip.PATH_GENERIC
+    bad = Cv(4, 2, 3, (7, 9), "relu"); bad.family = 7
+    assert _hip.cvae_kernel_path(bad) not in (_hip.PATH_MFMA, _hip.PATH_LMM, _hip.PATH_GENERIC)       # RNVP_EINVAL
