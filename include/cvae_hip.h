@@ -61,6 +61,26 @@ int cvae_train_step(void *stream, const cvae_shape *shape, float *params,
                     double lr, double beta1, double beta2, double adam_eps, double weight_decay, int64_t step,
                     void *workspace, size_t workspace_bytes);
 
+/*
+ * One epoch of the batch loop of CVAE.fit (cvae.py:235-252) in one call: for every consecutive slice of `batch_size`
+ * entries of `perm` (the epoch's DataLoader permutation, int64 [n] on the device; the last slice may be ragged) run
+ * cvae_train_step with inv_B = 1 / rows_in_slice on eps[s0 .. s0 + rows) (eps [n, latent] holds the epoch's sample_z draws in
+ * batch order) and store that batch's loss in loss_hist[k] ([ceil(n / batch_size)], required).  `first_step` is the 1-based
+ * Adam step of the first batch; grad_buf [P] and the workspace as for cvae_train_step at batch_size rows.
+ * Small models -- one hidden layer of at most 16 units (32 while the widest input has at most 15 columns), d <= 16,
+ * latent <= 8, batch_size <= 128: the reference's defaults hidden=(10,), latent 2, batch 32 (cvae.py:145) -- run as ONE
+ * persistent launch per epoch with parameters, Adam state and gradient stages resident in one CU's LDS
+ * (rnvp_resident.hip; cvae_fit_epoch_resident says whether).  That form agrees with the batch-by-batch loop to rounding
+ * (another summation order) and reproduces itself bit for bit; family == 1 pins the loop.
+ */
+int cvae_fit_epoch(void *stream, const cvae_shape *shape, float *params,
+                   const float *x, const float *c, const int64_t *perm, const float *eps,
+                   int64_t n, int64_t batch_size, float kl_weight,
+                   float *grad_buf, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                   double lr, double beta1, double beta2, double adam_eps, double weight_decay, int64_t first_step,
+                   void *workspace, size_t workspace_bytes);
+int cvae_fit_epoch_resident(const cvae_shape *shape, int64_t batch_size);
+
 /* x_out [n,d] = Decoder([z || c])                                       cvae.py:108-113, 284-290
  * workspace (nullable; cvae_workspace_bytes) lets shapes on RNVP_PATH_MFMA run the MFMA kernels (the packed
  * weights live there); NULL runs the generic kernels. */

@@ -140,6 +140,9 @@ _SIGNATURES = {
     "cvae_loss_grad": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _SZ]),
     "cvae_train_step": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _F, _F, _VP, _VP, _VP, _VP,
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "cvae_fit_epoch": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _VP, _VP, _I64, _I64, _F, _VP, _VP, _VP, _VP,
+                                 _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "cvae_fit_epoch_resident": (C.c_int, [C.POINTER(CvaeShape), _I64]),
     "cvae_decode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
     "rnvp_profile_enable": (C.c_int, [C.c_int]),
@@ -391,6 +394,22 @@ def cvae_train_step(shape, params, x, c, row_index, eps, n_rows, inv_B, kl_weigh
           _ptr(loss_out, torch.float32, "loss_out"), _ptr(exp_avg, torch.float32, "exp_avg"),
           _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1), float(beta2), float(adam_eps),
           float(weight_decay), int(step), wp, wn))
+
+
+def cvae_fit_epoch_resident(shape, batch_size):
+    """True when cvae_fit_epoch runs this shape / batch size as one persistent launch per epoch (rnvp_resident.hip)"""
+    return bool(lib().cvae_fit_epoch_resident(C.byref(shape), int(batch_size)))
+
+
+def cvae_fit_epoch(shape, params, x, c, perm, eps, n, batch_size, kl_weight, grad_buf, loss_hist, exp_avg, exp_avg_sq,
+                   lr, beta1, beta2, adam_eps, weight_decay, first_step, ws):
+    """all batches of one epoch of CVAE.fit in one library call (eps [n, latent] in batch order)"""
+    wp, wn = _ws(ws)
+    _call("cvae_fit_epoch", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(x, torch.float32, "x"),
+          _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), _ptr(eps, torch.float32, "eps"), int(n), int(batch_size),
+          float(kl_weight), _ptr(grad_buf, torch.float32, "grad_buf"), _ptr(loss_hist, torch.float32, "loss_hist"),
+          _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr), float(beta1),
+          float(beta2), float(adam_eps), float(weight_decay), int(first_step), wp, wn))
 
 
 def cvae_decode(shape, params, z, c, n_rows, x_out, ws=None):

@@ -7,6 +7,7 @@
 #include "rnvp_common.h"
 #include "rnvp_generic_net.h"
 #include "rnvp_lmm.h"
+#include "rnvp_resident.h"
 
 namespace rnvp {
 namespace {
@@ -274,6 +275,36 @@ int cvae_train_step(void *stream, const cvae_shape *shape, float *params, const 
     if (rc) return rc;
     return rnvp_adam_step(stream, params, grad_buf, exp_avg, exp_avg_sq, (int64_t)cvae_param_count(shape), lr, beta1, beta2,
                           adam_eps, weight_decay, step);
+}
+
+int cvae_fit_epoch_resident(const cvae_shape *shape, int64_t batch_size) {
+    CvaeK k;
+    if (make_cvae(shape, &k) != RNVP_OK) return 0;
+    return resident::cvae_fits(k, shape->family, batch_size) ? 1 : 0;
+}
+
+int cvae_fit_epoch(void *stream, const cvae_shape *shape, float *params, const float *x, const float *c, const int64_t *perm,
+                   const float *eps, int64_t n, int64_t batch_size, float kl_weight, float *grad_buf, float *loss_hist,
+                   float *exp_avg, float *exp_avg_sq, double lr, double beta1, double beta2, double adam_eps, double weight_decay,
+                   int64_t first_step, void *workspace, size_t workspace_bytes) {
+    CvaeK k;
+    int rc = make_cvae(shape, &k);
+    if (rc) return rc;
+    if (n < 0 || batch_size < 1 || first_step < 1 || !loss_hist || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
+    if (n == 0) return RNVP_OK;
+    if (!params || !x || (k.c > 0 && !c) || !perm || !eps) return RNVP_EINVAL;
+    if (resident::cvae_fits(k, shape->family, batch_size))
+        return resident::cvae_fit_epoch(static_cast<hipStream_t>(stream), k, params, x, c, perm, eps, n, batch_size, kl_weight,
+                                        loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, weight_decay, first_step);
+    int64_t kb = 0;
+    for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++kb) {
+        const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
+        rc = cvae_train_step(stream, shape, params, x, c, perm + s0, eps + s0 * k.lat, rows, 1.0f / (float)rows, kl_weight, grad_buf,
+                             loss_hist + kb, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, weight_decay, first_step + kb, workspace,
+                             workspace_bytes);
+        if (rc) return rc;
+    }
+    return RNVP_OK;
 }
 
 int cvae_decode(void *stream, const cvae_shape *shape, const float *params, const float *z, const float *c,

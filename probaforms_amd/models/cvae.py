@@ -281,6 +281,7 @@ class CVAE(GenModel):
         if not host_noise:
             from .._engine import PermutationPrefetcher
             perms = PermutationPrefetcher(n, self.n_epochs).start()
+        epoch_losses = None              # per-batch losses of cvae_fit_epoch (the reference keeps only the per-epoch loss)
         pending = []                     # device scalars of the per-epoch losses, read back once (or one epoch behind)
         inflight = None                  # (slot, event): host buffers the GPU may still be copying from
 
@@ -314,6 +315,19 @@ class CVAE(GenModel):
                 else:
                     perm = _rank0(perms.get(epoch).to(dev))
                     eps_full = None
+                if world == 1 and host_noise:
+                    # one GPU, the reference's noise stream (already on the device for the whole epoch): all batches in ONE
+                    # library call -- a single persistent launch per epoch for the reference's default sizes (cvae_fit_epoch)
+                    g = core.grads()
+                    if epoch_losses is None or epoch_losses.numel() != len(bounds):
+                        epoch_losses = torch.zeros(len(bounds), dtype=torch.float32, device=dev)
+                    _hip.cvae_fit_epoch(core.shape, core.sync(), Xd, Cd, perm, eps_all, n, self.batch_size, self.KL_weight,
+                                        g[:core.P], epoch_losses, self.opt.exp_avg[:core.P], self.opt.exp_avg_sq[:core.P],
+                                        lr, b1, b2, eps_adam, wd, self.opt.step_count + 1, core.workspace(min(n, self.batch_size)))
+                    self.opt.step_count += len(bounds)
+                    pending.append(self.compute_loss(Xd, Cd, eps_full))      # cvae.py:254-259
+                    flush(1 if bar is not None else self.n_epochs)
+                    continue
                 for (s, e) in bounds:
                     B = e - s
                     eps = eps_all[s:e] if host_noise else _rank0(self._device_eps(B))

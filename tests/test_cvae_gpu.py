@@ -302,3 +302,66 @@ def test_device_noise_matches_host_noise_statistically():
     assert abs(out["host"] - out["device"]) < 0.05 * abs(out["host"]), out
     with pytest.raises(ValueError):
         CVAE(noise_rng="gpu")
+
+
+RESIDENT_CVAE = [
+    # d, c, lat, hidden, act, n, batch, weight_decay
+    (2, 1, 2, (10,), "tanh", 160, 32, 0.0),             # CVAE() defaults (cvae.py:145) on 2-d data with one condition
+    (5, 3, 2, (10,), "tanh", 100, 32, 0.0),             # the reference's own test sizes; ragged last batch
+    (5, 0, 2, (10,), "tanh", 75, 25, 0.2),              # no condition, ragged row tiles, weight decay
+    (16, 4, 8, (16,), "relu", 300, 128, 0.0),           # 8 waves, the widest latent
+    (16, 15, 3, (13,), "tanh", 70, 32, 0.0),            # 31 encoder inputs (two input tiles)
+    (9, 6, 5, (32,), "tanh", 100, 48, 0.0),             # two hidden tiles
+    (1, 0, 1, (3,), "tanh", 20, 7, 0.0),
+]
+
+
+@pytest.mark.parametrize("d,c,lat,hidden,act,n,batch,wd", RESIDENT_CVAE)
+def test_resident_cvae_fit_epoch_vs_step_loop(d, c, lat, hidden, act, n, batch, wd):
+    """cvae_fit_epoch on a model that fits one CU's LDS runs the epoch in one persistent workgroup (rnvp_resident.hip): the
+    same trajectory as the batch-by-batch cvae_train_step loop (pinned by the oracle and the reference fixtures above) up to
+    the rounding of another summation order, per-batch losses included; bit-identical run to run; family=generic pins the
+    loop inside the same entry point"""
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(d * 100 + lat * 10 + n)
+    shape = _hip.CvaeShape.make(d, c, lat, hidden, act)
+    loop_shape = _hip.CvaeShape.make(d, c, lat, hidden, act, family="generic")
+    assert _hip.cvae_fit_epoch_resident(shape, batch) and not _hip.cvae_fit_epoch_resident(loop_shape, batch)
+    assert not _hip.cvae_fit_epoch_resident(shape, 129)
+    assert not _hip.cvae_fit_epoch_resident(_hip.CvaeShape.make(d, c, lat, (10, 10), act), batch)
+    assert not _hip.cvae_fit_epoch_resident(_hip.CvaeShape.make(d, c, 9, hidden, act), batch)
+    P = _hip.cvae_param_count(shape)
+    p0 = (rng.uniform(-1, 1, P) * 0.4).astype(np.float32)
+    x = _dev(rng.standard_normal((n, d)).astype(np.float32))
+    cc = _dev(rng.standard_normal((n, c)).astype(np.float32)) if c else None
+    perm = torch.from_numpy(rng.permutation(n).astype(np.int64)).cuda()
+    eps = _dev(rng.standard_normal((2, n, lat)).astype(np.float32))
+    nb = (n + batch - 1) // batch
+    ws = torch.empty(_hip.cvae_workspace_bytes(shape, batch), dtype=torch.uint8, device="cuda")
+    adam = (2e-3, 0.9, 0.999, 1e-8, wd)
+    klw = 0.05
+
+    def epochs(sh, manual):
+        p = _dev(p0).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+        g = torch.empty(P, device="cuda"); hist = torch.full((2 * nb,), float("nan"), device="cuda")
+        for ep in range(2):                           # the second epoch continues the optimizer's step count
+            if not manual:
+                _hip.cvae_fit_epoch(sh, p, x, cc, perm, eps[ep], n, batch, klw, g, hist[ep * nb:(ep + 1) * nb], m, v, *adam, 1 + ep * nb, ws)
+                continue
+            for k in range(nb):
+                rows = min(batch, n - k * batch)
+                _hip.cvae_train_step(sh, p, x, cc, perm[k * batch:k * batch + rows].contiguous(), eps[ep, k * batch:k * batch + rows].contiguous(),
+                                     rows, 1.0 / rows, klw, g, hist[ep * nb + k:ep * nb + k + 1], m, v, *adam, 1 + ep * nb + k, ws)
+        return [t.cpu().numpy().astype(np.float64) for t in (hist, p, m, v)]
+
+    res, again, loop, manual = epochs(shape, False), epochs(shape, False), epochs(loop_shape, False), epochs(shape, True)
+    for a, b in zip(res, again):
+        assert np.array_equal(a, b)
+    for a, b in zip(loop, manual):                    # the entry point's loop IS the per-batch calls (other kernels: tolerance)
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)
+    assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
+    np.testing.assert_allclose(res[0], manual[0], rtol=2e-5, atol=2e-6)
+    assert np.abs(res[1] - manual[1]).mean() < 2e-6 and np.abs(res[1] - manual[1]).max() < 2e-4
+    assert np.abs(res[2] - manual[2]).max() < 1e-5 * max(1.0, np.abs(manual[2]).max())
+    assert np.abs(res[3] - manual[3]).max() < 1e-5 * max(1.0, np.abs(manual[3]).max())
+    assert np.abs(res[1] - p0).max() > 1e-3
