@@ -292,6 +292,25 @@ def secondary_configs(Xh, Ch, dev):
                                               "batch_size=32: %d steps in one rnvp_fit_epoch call" % nsteps,
                                   "one_launch_per_epoch": bool(_hip.fit_epoch_resident(eng1.shape, bs)),
                                   "us_per_step": us, "rows_per_s": bs / (us * 1e-6), "final_loss": float(losses[-1])}
+    # CVAE() defaults (cvae.py:145: hidden=(10,), latent 2, batch 32) on the same 2-d rows: cvae_fit_epoch, one launch per epoch
+    shape_v = _hip.CvaeShape.make(d1, c1, 2, (10,), "tanh")
+    Pv = _hip.cvae_param_count(shape_v)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pv = (torch.rand(Pv, device=dev, generator=gen) - 0.5) * 0.4; mv = torch.zeros(Pv, device=dev); vv = torch.zeros(Pv, device=dev)
+    epsv = torch.randn(bs * nsteps, 2, device=dev, generator=gen); gv = torch.empty(Pv, device=dev)
+    wsv = torch.empty(_hip.cvae_workspace_bytes(shape_v, bs), dtype=torch.uint8, device=dev)
+    def cvae_epoch(first):
+        _hip.cvae_fit_epoch(shape_v, pv, X1, C1, perm, epsv, bs * nsteps, bs, 0.001, gv, losses, mv, vv, 1e-3, 0.9, 0.999, 1e-8, 0.0, first, wsv)
+    cvae_epoch(1)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    cvae_epoch(1 + nsteps)
+    e1.record(); torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) / nsteps * 1e3
+    out["cvae_defaults_batch32"] = {"workload": "the reference's default CVAE (hidden=(10,), latent 2) on d=2, cond=1 rows at its default "
+                                                "batch_size=32: %d steps in one cvae_fit_epoch call" % nsteps,
+                                    "one_launch_per_epoch": bool(_hip.cvae_fit_epoch_resident(shape_v, bs)),
+                                    "us_per_step": us, "rows_per_s": bs / (us * 1e-6), "final_loss": float(losses[-1])}
     out["c2_precision_ab"] = precision_ab(Xh, Ch, dev)
     out.update(secondary_c3_c4(dev))
     return out
