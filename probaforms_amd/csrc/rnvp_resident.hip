@@ -103,6 +103,53 @@ __device__ __forceinline__ void tile_get(const float *T, int q, int i, float (&o
     for (int ks = 0; ks < 4; ++ks) o[ks] = T[i * TS + 4 * ks + q];
 }
 
+// this step's Adam scalars, the bookkeeping in double like torch (make_adam, rnvp_adam.hip); advances beta^t to the next step
+__device__ __forceinline__ AdamK step_adam(double lr, double beta1, double beta2, double eps, double wd, double &b1t, double &b2t) {
+    AdamK a;
+    a.step_size = (float)(lr / (1.0 - b1t)); a.bc2_sqrt = (float)sqrt(1.0 - b2t);
+    b1t *= beta1; b2t *= beta2;
+    a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
+    a.wd = (float)wd; a.eps = (float)eps; a.use_wd = wd != 0.0;
+    return a;
+}
+
+// After the barrier that ends a step's backward: the nw waves' stages are added in wave order (deterministic) and Adam is
+// applied in place to the LDS-resident parameters (torch.optim.Adam as separately rounded operations, rnvp_common.h).
+// Parameter p of net block p / npn sits at stage index (p / npn) * stg_net + p % npn; two parameters per pass so that their
+// loads, divisions and square roots overlap.
+__device__ __forceinline__ void adam_phase(const float *st0, int stg_floats, int stg_net, int npn, int P, int nw, float *PAR, float *MM,
+                                           float *VV, bool mv_lds, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                           const AdamK &a, int tid, int nthreads) {
+    const float rnpn = 1.0f / (float)npn;
+    for (int p0 = tid; p0 < P; p0 += 2 * nthreads) {
+        const int p1 = p0 + nthreads;
+        const bool two = p1 < P;
+        const int pp[2] = {p0, two ? p1 : p0};
+        float g[2], pv[2], mv[2], vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int ln = (int)(((float)pp[u] + 0.5f) * rnpn);              // pp / npn (exact after the correction)
+            if (ln * npn > pp[u]) --ln;
+            else if ((ln + 1) * npn <= pp[u]) ++ln;
+            const int sp = ln * stg_net + (pp[u] - ln * npn);
+            g[u] = st0[sp];
+            for (int w = 1; w < nw; ++w) g[u] += st0[(size_t)w * stg_floats + sp];
+            pv[u] = PAR[pp[u]];
+            if (mv_lds) { mv[u] = MM[pp[u]]; vv[u] = VV[pp[u]]; }
+            else { mv[u] = exp_avg[pp[u]]; vv[u] = exp_avg_sq[pp[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) adam_one(pv[u], g[u], mv[u], vv[u], a);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            PAR[pp[u]] = pv[u];
+            if (mv_lds) { MM[pp[u]] = mv[u]; VV[pp[u]] = vv[u]; }
+            else { exp_avg[pp[u]] = mv[u]; exp_avg_sq[pp[u]] = vv[u]; }
+        }
+    }
+}
+
 // MT hidden tiles, KIT k-steps of the net input (4 KIT >= d + cdim + 1), WMAX waves, DT slots of x that hold features
 // (4 DT >= d: 2-d data needs one of the four)
 template <int MT, int KIT, int ACT, int WMAX, int DT>
@@ -453,42 +500,9 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
 #ifdef RC_STAMP
         __builtin_amdgcn_sched_barrier(0); ts3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
-        {   // stages in wave order -> gradient; Adam in place (torch.optim.Adam as separately rounded operations, rnvp_common.h)
-            AdamK a;                                     // scalar bookkeeping in double, like torch (make_adam, rnvp_adam.hip)
-            a.step_size = (float)(lr / (1.0 - b1t)); a.bc2_sqrt = (float)sqrt(1.0 - b2t);
-            b1t *= beta1; b2t *= beta2;
-            a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
-            a.wd = (float)wd; a.eps = (float)eps; a.use_wd = wd != 0.0;
-            const float *st0 = lds + pl.oSTG;
-            const float rnpn = 1.0f / (float)npn;
-            // two parameters per pass: their loads, divisions and square roots overlap
-            for (int p0 = tid; p0 < P; p0 += 2 * nthreads) {
-                const int p1 = p0 + nthreads;
-                const bool two = p1 < P;
-                int pp[2] = {p0, two ? p1 : p0};
-                float g[2], pv[2], mv[2], vv[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    int ln = (int)(((float)pp[u] + 0.5f) * rnpn);              // pp / npn (exact after the correction)
-                    if (ln * npn > pp[u]) --ln;
-                    else if ((ln + 1) * npn <= pp[u]) ++ln;
-                    const int sp = ln * pl.stg_net + (pp[u] - ln * npn);
-                    g[u] = st0[sp];
-                    for (int w = 1; w < nw; ++w) g[u] += st0[(size_t)w * pl.stg_floats + sp];
-                    pv[u] = PAR[pp[u]];
-                    if (pl.mv_lds) { mv[u] = MM[pp[u]]; vv[u] = VV[pp[u]]; }
-                    else { mv[u] = exp_avg[pp[u]]; vv[u] = exp_avg_sq[pp[u]]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) adam_one(pv[u], g[u], mv[u], vv[u], a);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && !two) break;
-                    PAR[pp[u]] = pv[u];
-                    if (pl.mv_lds) { MM[pp[u]] = mv[u]; VV[pp[u]] = vv[u]; }
-                    else { exp_avg[pp[u]] = mv[u]; exp_avg_sq[pp[u]] = vv[u]; }
-                }
-            }
+        {
+            const AdamK a = step_adam(lr, beta1, beta2, eps, wd, b1t, b2t);
+            adam_phase(lds + pl.oSTG, pl.stg_floats, pl.stg_net, npn, P, nw, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
             if (tid == 0) {
                 float acc = 0.f;
                 for (int w = 0; w < nw; ++w) acc += RED[w];
@@ -511,6 +525,314 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
     }
 }
 
+// ---- two or three hidden layers of at most 16 units each (hidden=(10, 10), (16, 16, 16), ...): the same chain, one GEMM longer per
+// hidden layer.  Without this form such a flow falls to the any-shape kernels' five launches per step (240 us at batch 32):
+// a 14x cliff next to hidden=(10,).  A hidden -> hidden Linear is one 16x16 tile: its D operand is the next Linear's B
+// operand exactly like the last Linear's, its weight gradient one more contraction over the rows, its bias gradient a DPP
+// row sum.  Fragments are loaded layer by layer (no look-ahead: three Linears' worth per net would not fit 256 registers).
+template <int NH, int KIT, int ACT, int WMAX, int DT>
+__global__ void __launch_bounds__(64 * WMAX)
+k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
+                    const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch,
+                    float *__restrict__ loss_hist, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1,
+                    double beta2, double eps, double wd, double b1t, double b2t) {
+    constexpr int NIT = KIT > 4 ? 2 : 1;
+    constexpr int KXT = KIT < DT ? KIT : DT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, i = r;
+    const int d = s.d, cd = s.c, L = s.L, P = pl.P, nin0 = d + cd, npn = s.npn;
+    const int pi = 4 * (i & 3) + (i >> 2);
+    float *PAR = lds + pl.oPAR, *MM = lds + pl.oM, *VV = lds + pl.oV, *STG = lds + pl.oSTG + (size_t)wave * pl.stg_floats;
+    float *RED = lds + pl.oRED;
+    f4 *XS = reinterpret_cast<f4 *>(lds + pl.oXS + (size_t)wave * pl.xs_floats);
+    float *TT = lds + pl.oTT + (size_t)wave * pl.tt_floats;
+    float *T_in = TT, *T_g = TT + NIT * 16 * TS, *T_h = T_g + 2 * 16 * TS;        // [input tiles][g of t, s][h of t, s]
+    for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;
+    __syncthreads();
+    for (int p = tid; p < P; p += nthreads) {
+        PAR[p] = params[p];
+        if (pl.mv_lds) { MM[p] = exp_avg[p]; VV[p] = exp_avg_sq[p]; }
+    }
+    __syncthreads();
+    const float prior_c = 0.5f * (float)d * kLog2Pi;
+    const int64_t nb = (n + batch - 1) / batch;
+
+    // ---- per-lane constants.  Linear k maps nin_k -> nout_k (k = 0: the net input; k = NH: the d outputs) ----
+    int gF[NH + 1], gB[NH + 1], gT[NH + 1][4], sS[NH + 1][4], sS0[NIT][4], sBk[NH + 1][4];
+    f4 hm[NH];
+    const int dump = npn + lane;
+#pragma unroll
+    for (int k = 0; k <= NH; ++k) {
+        const int nin = s.nin[k], nout = s.nout[k], wo = s.woff[k], bo = s.boff[k];
+        gF[k] = wo + pi * nin + q;                       // + 4e : W_k[pi][4e + q]           (forward)
+        gB[k] = bo + q;                                  // + 4e
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gT[k][e] = wo + (4 * e + q) * nin + pi;      // W_k[4e + q][pi]                  (gradient of Linear k's input)
+            sS[k][e] = (4 * q + e < nout && i < nin) ? wo + (4 * q + e) * nin + i : dump;        // d W_k[4q + e][i]
+            sBk[k][e] = (4 * e + q < nout) ? bo + 4 * e + q : dump;                               // d b_k[4e + q] (lanes r == 0)
+        }
+        if (k < NH)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hm[k][e] = 4 * e + q < nout ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = 4 * q + e, j = 16 * nt + i;
+            sS0[nt][e] = u >= s.nout[0] ? dump : (j < nin0 ? s.woff[0] + u * nin0 + j : (j == nin0 ? s.boff[0] + u : dump));
+        }
+    uint64_t mbits = 0;
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * e + q;
+            if (j >= d || masks[l * d + j]) mbits |= 1ull << (4 * l + e);
+        }
+    bool xok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xok[e] = 4 * e + q < d;
+
+    auto row_of = [&](int64_t kb) -> int64_t {
+        if (kb >= nb) return -1;
+        const int64_t s0 = kb * batch;
+        const int64_t rows = (n - s0 < batch) ? n - s0 : batch;
+        const int64_t rr = (int64_t)wave * 16 + r;
+        return rr < rows ? perm[s0 + rr] : -1;
+    };
+    auto load_rows = [&](int64_t src, f4 &xo, f4 (&co)[NIT]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xo[e] = (src >= 0 && xok[e]) ? x[src * d + 4 * e + q] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * nt + 4 * e + q;
+                co[nt][e] = (src >= 0 && j >= d && j < nin0) ? c[src * cd + (j - d)] : 0.f;
+            }
+    };
+    // both nets of one layer, interleaved: hidden activations hh[net][k]; outputs o[1] (s) and, if asked for, o[0] (t)
+    auto nets_fwd = [&](const float *pl0, const f4 (&in)[NIT], f4 (&hh)[2][NH], f4 (&o)[2], auto need_t) {
+        constexpr int N0 = decltype(need_t)::value ? 0 : 1;
+        f4 acc[2];
+#pragma unroll
+        for (int net = 0; net < 2; ++net)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[net][e] = pl0[net * npn + gB[0] + 4 * e];
+#pragma unroll
+        for (int k = 0; k < KIT; ++k)
+#pragma unroll
+            for (int net = 0; net < 2; ++net) acc[net] = mfma16(pl0[net * npn + gF[0] + 4 * k], in[k >> 2][k & 3], acc[net]);
+#pragma unroll
+        for (int net = 0; net < 2; ++net)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hh[net][0][e] = actf<ACT>(acc[net][e]) * hm[0][e];
+#pragma unroll
+        for (int k = 1; k < NH; ++k) {
+#pragma unroll
+            for (int net = 0; net < 2; ++net)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[net][e] = pl0[net * npn + gB[k] + 4 * e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int net = 0; net < 2; ++net) acc[net] = mfma16(pl0[net * npn + gF[k] + 4 * e], hh[net][k - 1][e], acc[net]);
+#pragma unroll
+            for (int net = 0; net < 2; ++net)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh[net][k][e] = actf<ACT>(acc[net][e]) * hm[k][e];
+        }
+#pragma unroll
+        for (int net = N0; net < 2; ++net)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[net][e] = pl0[net * npn + gB[NH] + 4 * e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int net = N0; net < 2; ++net) o[net] = mfma16(pl0[net * npn + gF[NH] + 4 * e], hh[net][NH - 1][e], o[net]);
+    };
+
+    int64_t src_next = row_of(0);
+    f4 nxq, ncq[NIT];
+    load_rows(src_next, nxq, ncq);
+    src_next = row_of(1);
+    for (int64_t kb = 0; kb < nb; ++kb) {
+        const int64_t s0 = kb * batch;
+        const int rows = (int)((n - s0 < batch) ? n - s0 : batch);
+        const float inv_B = 1.0f / (float)rows;
+        const int nw = (rows + 15) >> 4;
+        f4 xq = nxq, cin[NIT];
+#pragma unroll
+        for (int nt = 0; nt < NIT; ++nt) cin[nt] = ncq[nt];
+        load_rows(src_next, nxq, ncq);
+        src_next = row_of(kb + 2);
+        if (wave < nw) {
+            const bool valid = wave * 16 + r < rows;
+            float ld = 0.f;
+            for (int l = 0; l < L; ++l) {                                  // forward (realnvp.py:91-101, nflow.py:107-117)
+                const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
+                XS[l * 64 + lane] = xq;
+                f4 in[NIT];
+                in[0] = cin[0];
+#pragma unroll
+                for (int e = 0; e < DT; ++e) in[0][e] = ((mb >> e) & 1u) ? xq[e] + cin[0][e] : cin[0][e];
+                if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
+                f4 hh[2][NH], o[2];
+                nets_fwd(PAR + (size_t)l * 2 * npn, in, hh, o, std::true_type{});
+#pragma unroll
+                for (int e = 0; e < DT; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    const float xn = fmaf(xq[e], exp_acc(o[1][e]), o[0][e]);
+                    xq[e] = mk ? xq[e] : xn;
+                    ld += mk ? 0.f : o[1][e];
+                }
+            }
+            f4 gy;
+            {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gy[e] = 0.f;
+#pragma unroll
+                for (int e = 0; e < DT; ++e) { ss = fmaf(xq[e], xq[e], ss); gy[e] = valid ? xq[e] * inv_B : 0.f; }
+                ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
+                ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+                float v = (valid && q == 0) ? ld + (-0.5f * ss - prior_c) : 0.f;
+                v = row16_sum(v);
+                if (lane == 0) RED[wave] = v;
+            }
+            const float gld = valid ? -inv_B : 0.f;
+            f4 cinT[NIT];
+#pragma unroll
+            for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cinT[nt][e] = (16 * nt + 4 * e + q == nin0) ? 1.f : cin[nt][e];
+            if (NIT > 1) { wfence(); tile_put(T_in + (NIT - 1) * 16 * TS, cinT[NIT - 1], q, r); }
+            for (int l = L - 1; l >= 0; --l) {                             // backward
+                const float *pl0 = PAR + (size_t)l * 2 * npn;
+                float *stg0 = STG + (size_t)l * 2 * pl.stg_net;
+                const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
+                xq = XS[l * 64 + lane];
+                f4 in[NIT], in0T;
+                in[0] = cin[0]; in0T = cinT[0];
+#pragma unroll
+                for (int e = 0; e < DT; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    in[0][e] = mk ? xq[e] + cin[0][e] : cin[0][e];
+                    in0T[e] = mk ? xq[e] + cinT[0][e] : cinT[0][e];
+                }
+                if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
+                wfence();
+                tile_put(T_in, in0T, q, r);
+                f4 hh[2][NH], o[2];
+                nets_fwd(pl0, in, hh, o, std::false_type{});
+                f4 es = f4{0.f, 0.f, 0.f, 0.f}, g[2];
+                g[0] = f4{0.f, 0.f, 0.f, 0.f}; g[1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < DT; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    es[e] = exp_acc(o[1][e]);
+                    g[1][e] = mk ? 0.f : fmaf(gy[e] * xq[e], es[e], gld);
+                    g[0][e] = mk ? 0.f : gy[e];
+                }
+                // Linear k = NH .. 1: bias gradient (row sums), weight gradient g^T . h_{k-1}, gradient of h_{k-1}
+#pragma unroll
+                for (int k = NH; k >= 1; --k) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int ke = (k == NH) ? KXT : 4;                    // slots of g that hold units
+#pragma unroll
+                    for (int net = 0; net < 2; ++net)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (e < ke) {
+                                const float v = row16_sum(g[net][e]);
+                                if (r == 0) stg0[net * pl.stg_net + sBk[k][e]] = v;
+                            }
+                    wfence();
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) {
+                        tile_put(T_g + net * 16 * TS, g[net], q, r);
+                        tile_put(T_h + net * 16 * TS, hh[net][k - 1], q, r);
+                    }
+                    f4 gh[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < ke)
+#pragma unroll
+                            for (int net = 0; net < 2; ++net) gh[net] = mfma16(pl0[net * npn + gT[k][e]], g[net][e], gh[net]);
+                    wfence();
+                    float gT_[2][4], hT_[2][4];
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) { tile_get(T_g + net * 16 * TS, q, i, gT_[net]); tile_get(T_h + net * 16 * TS, q, i, hT_[net]); }
+                    f4 dw[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int net = 0; net < 2; ++net) dw[net] = mfma16(gT_[net][ks], hT_[net][ks], dw[net]);      // [unit of k: 4q+e][unit of k-1: i]
+#pragma unroll
+                    for (int net = 0; net < 2; ++net)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            stg0[net * pl.stg_net + sS[k][e]] = dw[net][e];
+                            g[net][e] = gh[net][e] * dactf<ACT>(hh[net][k - 1][e]) * hm[k - 1][e];
+                        }
+                }
+                // Linear 0: weight + bias gradient against the input tile(s); input gradient for the x part
+                f4 gin[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int net = 0; net < 2; ++net) gin[net] = mfma16(pl0[net * npn + gT[0][e]], g[net][e], gin[net]);
+                wfence();
+                tile_put(T_g, g[0], q, r);
+                tile_put(T_g + 16 * TS, g[1], q, r);
+                wfence();
+                float g0T[2][4], inT[NIT][4];
+                tile_get(T_g, q, i, g0T[0]); tile_get(T_g + 16 * TS, q, i, g0T[1]);
+#pragma unroll
+                for (int nt = 0; nt < NIT; ++nt) tile_get(T_in + nt * 16 * TS, q, i, inT[nt]);
+                f4 dw0[2][NIT];
+#pragma unroll
+                for (int net = 0; net < 2; ++net)
+#pragma unroll
+                    for (int nt = 0; nt < NIT; ++nt) dw0[net][nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int net = 0; net < 2; ++net)
+#pragma unroll
+                        for (int nt = 0; nt < NIT; ++nt) dw0[net][nt] = mfma16(g0T[net][ks], inT[nt][ks], dw0[net][nt]);
+#pragma unroll
+                for (int net = 0; net < 2; ++net)
+#pragma unroll
+                    for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) stg0[net * pl.stg_net + sS0[nt][e]] = dw0[net][nt][e];
+#pragma unroll
+                for (int e = 0; e < DT; ++e) {
+                    const bool mk = (mb >> e) & 1u;
+                    gy[e] = xok[e] ? (mk ? gy[e] + (gin[1][e] + gin[0][e]) : gy[e] * es[e]) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const AdamK a = step_adam(lr, beta1, beta2, eps, wd, b1t, b2t);
+            adam_phase(lds + pl.oSTG, pl.stg_floats, pl.stg_net, npn, P, nw, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
+            if (tid == 0) {
+                float acc = 0.f;
+                for (int w = 0; w < nw; ++w) acc += RED[w];
+                loss_hist[kb] = -acc * inv_B;
+            }
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < P; p += nthreads) {
+        params[p] = PAR[p];
+        if (pl.mv_lds) { exp_avg[p] = MM[p]; exp_avg_sq[p] = VV[p]; }
+    }
+}
+
 // k-steps of the net input incl. the ones element behind it
 int rc_kit(const KShape &k) { const int ki = (k.d + k.c + 1 + 3) / 4; return ki <= 2 ? 2 : (ki <= 4 ? 4 : 8); }
 
@@ -518,8 +840,13 @@ bool make_rc_plan(const KShape &k, int64_t batch, RcPlan *out) {
     // measured against the batch-by-batch loop (scripts/resident_time.py, profiles/): one hidden tile wins everywhere
     // (21-37 vs 41-53 us per step), two win while the net input fits one tile (38 vs 49 us), beyond that the loop's
     // multi-workgroup kernels are faster (h = 64: 75 vs 37 us)
-    if (k.nh != 1 || k.d > 16 || k.d + k.c > 31 || k.nout[0] > 32 || k.L > 16) return false;
-    if (k.nout[0] > 16 && rc_kit(k) > 4) return false;
+    if (k.nh < 1 || k.nh > 3 || k.d > 16 || k.d + k.c > 31 || k.L > 16) return false;
+    if (k.nh == 1) {
+        if (k.nout[0] > 32 || (k.nout[0] > 16 && rc_kit(k) > 4)) return false;
+    } else {
+        for (int i = 0; i < k.nh; ++i)          // two or three hidden layers: one tile each (k_fit_resident_deep)
+            if (k.nout[i] > 16) return false;
+    }
     if (batch < 1 || batch > 16 * kRcMaxWaves) return false;       // up to 8 waves: two per SIMD keep 256 registers each
     RcPlan p;
     std::memset(&p, 0, sizeof(p));
@@ -833,36 +1160,9 @@ k_cvae_fit_resident(CvaeK s, CvPlan pl, float *__restrict__ params, const float 
             }
         }
         __syncthreads();
-        {   // stages in wave order -> gradient; Adam in place (torch.optim.Adam as separately rounded operations, rnvp_common.h)
-            AdamK a;
-            a.step_size = (float)(lr / (1.0 - b1t)); a.bc2_sqrt = (float)sqrt(1.0 - b2t);
-            b1t *= beta1; b2t *= beta2;
-            a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
-            a.wd = (float)wd; a.eps = (float)adam_eps; a.use_wd = wd != 0.0;
-            const float *st0 = lds + pl.oSTG;
-            for (int p0 = tid; p0 < P; p0 += 2 * nthreads) {
-                const int p1 = p0 + nthreads;
-                const bool two = p1 < P;
-                const int pp[2] = {p0, two ? p1 : p0};
-                float g[2], pv[2], mv[2], vv[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    g[u] = st0[pp[u]];
-                    for (int w = 1; w < nw; ++w) g[u] += st0[(size_t)w * pl.stg_floats + pp[u]];
-                    pv[u] = PAR[pp[u]];
-                    if (pl.mv_lds) { mv[u] = MM[pp[u]]; vv[u] = VV[pp[u]]; }
-                    else { mv[u] = exp_avg[pp[u]]; vv[u] = exp_avg_sq[pp[u]]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) adam_one(pv[u], g[u], mv[u], vv[u], a);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && !two) break;
-                    PAR[pp[u]] = pv[u];
-                    if (pl.mv_lds) { MM[pp[u]] = mv[u]; VV[pp[u]] = vv[u]; }
-                    else { exp_avg[pp[u]] = mv[u]; exp_avg_sq[pp[u]] = vv[u]; }
-                }
-            }
+        {
+            const AdamK a = step_adam(lr, beta1, beta2, adam_eps, wd, b1t, b2t);
+            adam_phase(lds + pl.oSTG, pl.stg_floats, P, P, P, nw, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
             if (tid == 0 && loss_hist) {
                 float acc = 0.f;
                 for (int w = 0; w < nw; ++w) acc += RED[w];
@@ -956,6 +1256,40 @@ int launch_rc(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs 
     return launch_rc_d<MT, KIT, 4>(st, k, p, a);
 }
 
+template <int NH, int KIT, int ACT, int WMAX, int DT>
+int launch_deep_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    auto kern = k_fit_resident_deep<NH, KIT, ACT, WMAX, DT>;
+    static std::atomic<uint64_t> attr_done{0};
+    const int rc = allow_big_lds(reinterpret_cast<const void *>(kern), (int)kLdsMax, attr_done);
+    if (rc) return rc;
+    {
+        KernelTimer timer(st, RNVP_PROFILE_TRAIN);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WMAX), (size_t)p.total_floats * sizeof(float), st, k, p, a.params, a.masks, a.x, a.c,
+                           a.perm, a.n, a.batch_size, a.loss_hist, a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.wd,
+                           std::pow(a.beta1, (double)a.first_step), std::pow(a.beta2, (double)a.first_step));
+    }
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+template <int NH, int KIT, int DT>
+int launch_deep_d(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    const bool th = k.act == RNVP_ACT_TANH;
+    if (p.W <= 4)
+        return th ? launch_deep_w<NH, KIT, RNVP_ACT_TANH, 4, DT>(st, k, p, a) : launch_deep_w<NH, KIT, RNVP_ACT_RELU, 4, DT>(st, k, p, a);
+    return th ? launch_deep_w<NH, KIT, RNVP_ACT_TANH, kRcMaxWaves, DT>(st, k, p, a)
+              : launch_deep_w<NH, KIT, RNVP_ACT_RELU, kRcMaxWaves, DT>(st, k, p, a);
+}
+
+template <int NH>
+int launch_deep(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    const int kit = rc_kit(k);
+    const bool small_d = k.d <= 4;
+    if (kit == 2) return small_d ? launch_deep_d<NH, 2, 1>(st, k, p, a) : launch_deep_d<NH, 2, 4>(st, k, p, a);
+    if (kit == 4) return small_d ? launch_deep_d<NH, 4, 1>(st, k, p, a) : launch_deep_d<NH, 4, 4>(st, k, p, a);
+    return small_d ? launch_deep_d<NH, 8, 1>(st, k, p, a) : launch_deep_d<NH, 8, 4>(st, k, p, a);
+}
+
 template <int MT>
 int launch_rc_kit(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
     const int kit = rc_kit(k);
@@ -974,6 +1308,8 @@ int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *mas
     if (make_rc_plan(k, batch_size, &rcp)) {
         const EpochArgs a{params, masks, x, c, perm, n, batch_size, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
                           first_step};
+        if (k.nh == 2) return launch_deep<2>(st, k, rcp, a);
+        if (k.nh == 3) return launch_deep<3>(st, k, rcp, a);
         if (k.nout[0] <= 16) return launch_rc_kit<1>(st, k, rcp, a);
         return launch_rc_kit<2>(st, k, rcp, a);
     }

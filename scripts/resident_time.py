@@ -35,5 +35,6 @@ def run(L, d, c, hidden, act, batch, nb=256):
 
 for cfg in [(8, 2, 1, (10,), "tanh", 32), (8, 2, 1, (10,), "relu", 32), (8, 2, 1, (10,), "tanh", 8), (8, 2, 1, (10,), "tanh", 64), (8, 2, 1, (16,), "tanh", 32),
             (8, 5, 3, (10,), "tanh", 32), (8, 8, 7, (16,), "tanh", 32), (8, 8, 8, (16,), "tanh", 32), (8, 2, 1, (32,), "tanh", 32), (8, 2, 1, (32,), "tanh", 64),
-            (8, 2, 1, (64,), "tanh", 32), (4, 2, 1, (64,), "tanh", 64), (8, 16, 4, (10,), "tanh", 32), (4, 16, 4, (32,), "tanh", 32), (16, 2, 1, (10,), "tanh", 32)]:
+            (8, 2, 1, (64,), "tanh", 32), (4, 2, 1, (64,), "tanh", 64), (8, 16, 4, (10,), "tanh", 32), (4, 16, 4, (32,), "tanh", 32), (16, 2, 1, (10,), "tanh", 32),
+            (8, 2, 1, (10, 10), "tanh", 32), (8, 2, 1, (10, 10, 10), "tanh", 32), (8, 5, 3, (16, 16), "relu", 32), (8, 2, 1, (10, 20, 15), "tanh", 32)]:
     run(*cfg)

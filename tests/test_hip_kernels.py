@@ -869,6 +869,11 @@ RESIDENT_CASES = [
     (5, 7, 2, (9,), "relu", 90, 7, 0.0, True),                # user masks, a batch smaller than one tile
     (6, 13, 2, (17,), "tanh", 200, 48, 0.0, True),
     (2, 1, 1, (10,), "tanh", 17, 5, 0.0, False),
+    (8, 2, 1, (10, 10), "tanh", 160, 32, 0.0, False),         # two hidden layers (k_fit_resident_deep)
+    (4, 5, 3, (10, 16, 7), "tanh", 75, 25, 0.2, False),       # three, ragged tiles, weight decay
+    (3, 16, 4, (16, 16), "relu", 200, 64, 0.0, False),        # full tiles, two input tiles
+    (5, 3, 1, (5, 9, 4), "relu", 90, 96, 0.0, True),          # user masks, one batch larger than the data
+    (16, 2, 0, (3, 2), "tanh", 40, 8, 0.0, False),
 ]
 
 
@@ -888,7 +893,8 @@ def test_resident_fit_epoch_vs_step_loop(L, d, c, hidden, act, n, batch, wd, use
     assert _hip.fit_epoch_resident(shape, batch)
     assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=alt, family="valu"), batch)
     assert not _hip.fit_epoch_resident(shape, 129) and not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (33,), act), batch)
-    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (10, 10), act), batch)
+    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (10, 20), act), batch)            # a hidden tile per layer only
+    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (4, 4, 4, 4), act), batch)
     assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(17, d, c, hidden, act), batch)
     P = _hip.param_count(shape)
     p0 = (rng.uniform(-1, 1, P) * 0.3).astype(np.float32)
