@@ -314,7 +314,7 @@ int rnvp_fit_epoch(void *stream, const rnvp_shape *shape, float *params, const u
         const int rc = make_kshape(shape, &ks);
         if (rc) return rc;
         if (n > 0 && resident::fits(ks, batch_size)) {
-            if (bad_ptrs(ks, params, masks, x, c) || !masks || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
+            if (bad_ptrs(ks, params, masks, x, c) || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
             return resident::fit_epoch(static_cast<hipStream_t>(stream), ks, params, masks, x, c, perm, n, batch_size, loss_hist,
                                        exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step);
         }

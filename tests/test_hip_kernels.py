@@ -919,14 +919,23 @@ def test_resident_fit_epoch_vs_step_loop(L, d, c, hidden, act, n, batch, wd, use
                             *adam, first_step + k, ws)
         return hist
 
+    def epoch_nullmasks(first_step, p, m, v):        # alt_masks declared: the masks pointer may be NULL
+        hist = torch.full((nb,), float("nan"), device="cuda"); gbuf = torch.empty(P, device="cuda")
+        _hip.fit_epoch(shape, p, None, x, cc, perm, n, batch, gbuf, hist, m, v, *adam, first_step, ws)
+        return hist
+
     out = {}
-    for name, fn in (("resident", epoch_resident), ("loop", epoch_loop), ("again", epoch_resident)):
+    runs = [("resident", epoch_resident), ("loop", epoch_loop), ("again", epoch_resident)] + ([("nullmasks", epoch_nullmasks)] if alt else [])
+    for name, fn in runs:
         p = _dev(p0).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
         h1 = fn(1, p, m, v)
         h2 = fn(1 + nb, p, m, v)                      # a second epoch continues the optimizer's step count
         out[name] = [t.cpu().numpy().astype(np.float64) for t in (torch.cat([h1, h2]), p, m, v)]
     for a, b in zip(out["resident"], out["again"]):
         assert np.array_equal(a, b)
+    if alt:
+        for a, b in zip(out["resident"], out["nullmasks"]):
+            assert np.array_equal(a, b)
     hr, pr, mr, vr = out["resident"]; hl, pl, ml, vl = out["loop"]
     assert np.isfinite(hr).all() and np.isfinite(pr).all()
     np.testing.assert_allclose(hr, hl, rtol=2e-5, atol=2e-5)
