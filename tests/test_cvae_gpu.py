@@ -313,6 +313,7 @@ RESIDENT_CVAE = [
     (16, 15, 3, (13,), "tanh", 70, 32, 0.0),            # 31 encoder inputs (two input tiles)
     (9, 6, 5, (32,), "tanh", 100, 48, 0.0),             # two hidden tiles
     (1, 0, 1, (3,), "tanh", 20, 7, 0.0),
+    (2, 1, 2, (10,), "tanh", 5, 1, 0.0),                # one row per batch
 ]
 
 

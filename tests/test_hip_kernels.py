@@ -874,6 +874,8 @@ RESIDENT_CASES = [
     (3, 16, 4, (16, 16), "relu", 200, 64, 0.0, False),        # full tiles, two input tiles
     (5, 3, 1, (5, 9, 4), "relu", 90, 96, 0.0, True),          # user masks, one batch larger than the data
     (16, 2, 0, (3, 2), "tanh", 40, 8, 0.0, False),
+    (2, 2, 1, (10,), "tanh", 5, 1, 0.0, False),               # one row per batch
+    (2, 3, 0, (4, 4), "relu", 3, 1, 0.1, True),
 ]
 
 
