@@ -265,7 +265,7 @@ int rnvp_fit_epoch(void *stream, const rnvp_shape *shape,
 
 /*
  * 1 when rnvp_fit_epoch runs this shape at this batch size as ONE persistent launch per epoch ("resident" fit,
- * rnvp_resident.hip): one hidden layer of at most 16 units (at most 32 while d + cdim <= 15) or two or three of at most 16
+ * rnvp_resident.hip): one hidden layer of at most 16 units (at most 32 while d + cdim <= 15) or two or three of at most 32
  * each, d <= 16, d + cdim <= 31, at most 16 layers, batch_size <= 128, and the model with its per-wave gradient stages inside one CU's 160 KB of LDS -- the
  * reference's default network (hidden=(10,), 8 layers, batch_size=32: realnvp.py:161-176).  Parameters stay in LDS for
  * the whole epoch, a step is a register-to-register MFMA chain per 16-row wave, Adam runs in place: 15 us per step

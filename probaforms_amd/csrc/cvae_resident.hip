@@ -72,7 +72,7 @@ k_cvae_fit_resident(CvaeK s, CvPlan pl, float *__restrict__ params, const float 
     bool xok[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) xok[e] = 4 * e + q < d;
-    const int dump = P + lane;
+    const int dump = P + (lane & 15);
     int sS2e[MT][4], sS2d[MT][4], sS1e[MT][NIT][4], sS1d[MT][NIT][4], sB2e[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int hr = head_row(4 * e + q); sB2e[e] = hr >= 0 ? b1e + hr : dump; }
@@ -332,7 +332,6 @@ bool make_cv_plan(const CvaeK &k, int64_t batch, CvPlan *out) {
         p.oSTG = f; f += p.W * p.stg_floats;
         p.oRED = f; f += kMaxWaves;
         p.oTT = f; f += p.W * p.tt_floats;
-        f += 16 * 64 + 64;                      // the unguarded gathers of padding lanes stay inside the allocation
         p.total_floats = f;
         p.mv_lds = mv;
         if ((size_t)f * sizeof(float) <= kLdsMax) { *out = p; return true; }

@@ -90,11 +90,11 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int fo = 4 * q + e, hid_n = 16 * m + i, hid_m = 16 * m + 4 * q + e;
-            sS2[m][e] = (fo < d && hid_n < h) ? w1 + fo * h + hid_n : npn + lane;                    // d W2[fo][hid]
+            sS2[m][e] = (fo < d && hid_n < h) ? w1 + fo * h + hid_n : npn + (lane & 15);                    // d W2[fo][hid]
 #pragma unroll
             for (int nt = 0; nt < NIT; ++nt) {
                 const int j = 16 * nt + i;
-                sS1[m][nt][e] = hid_m >= h ? npn + lane : (j < nin0 ? w0 + hid_m * nin0 + j : (j == nin0 ? b0 + hid_m : npn + lane));
+                sS1[m][nt][e] = hid_m >= h ? npn + (lane & 15) : (j < nin0 ? w0 + hid_m * nin0 + j : (j == nin0 ? b0 + hid_m : npn + (lane & 15)));
             }
         }
 
@@ -430,8 +430,8 @@ bool make_rc_plan(const KShape &k, int64_t batch, RcPlan *out) {
     if (k.nh == 1) {
         if (k.nout[0] > 32 || (k.nout[0] > 16 && rc_kit(k) > 4)) return false;
     } else {
-        for (int i = 0; i < k.nh; ++i)          // two or three hidden layers: one tile each (k_fit_resident_deep)
-            if (k.nout[i] > 16) return false;
+        for (int i = 0; i < k.nh; ++i)          // two or three hidden layers: one or two tiles each (k_fit_resident_deep)
+            if (k.nout[i] > 32) return false;
     }
     if (batch < 1 || batch > 16 * kRcMaxWaves) return false;       // up to 8 waves: two per SIMD keep 256 registers each
     RcPlan p;
@@ -440,7 +440,9 @@ bool make_rc_plan(const KShape &k, int64_t batch, RcPlan *out) {
     p.P = 2 * k.npn * k.L;
     p.stg_net = k.npn + kDump;
     p.stg_floats = 2 * k.L * p.stg_net;
-    p.tt_floats = ((rc_kit(k) > 4 ? 2 : 1) + 6) * 16 * TS;
+    bool wide = false;
+    for (int i = 0; i < k.nh; ++i) wide = wide || k.nout[i] > 16;
+    p.tt_floats = ((rc_kit(k) > 4 ? 2 : 1) + (k.nh > 1 && wide ? 8 : 6)) * 16 * TS;
     const int mt = k.nout[0] <= 16 ? 1 : 2;
     for (int sv = (k.nh == 1 && p.W <= 4 ? 1 : 0); sv >= 0; --sv)
     for (int mv = 1; mv >= 0; --mv) {
@@ -455,7 +457,8 @@ bool make_rc_plan(const KShape &k, int64_t batch, RcPlan *out) {
         f = (f + 3) & ~3;                       // the saved layer inputs are read and written as float4
         p.oXS = f; f += p.W * p.xs_floats;
         p.oTT = f; f += p.W * p.tt_floats;
-        f += 16 * 64 + 64;                      // the unguarded gathers of padding lanes stay inside the allocation
+        // (the unguarded gathers of padding lanes reach at most ~1 000 floats past a net's block: into the stages / tiles, never
+        // past the allocation -- the transposition tiles alone are 1 900 floats per wave)
         p.total_floats = f;
         p.mv_lds = mv;
         if ((size_t)f * sizeof(float) <= kLdsMax) { *out = p; return true; }

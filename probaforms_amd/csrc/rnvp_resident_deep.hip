@@ -1,4 +1,4 @@
-// rnvp_resident_deep.hip -- resident fit (rnvp_resident.hip) for flows with two or three hidden layers of one tile each.
+// rnvp_resident_deep.hip -- resident fit (rnvp_resident.hip) for flows with two or three hidden layers of one or two tiles each.
 #include "rnvp_resident_dev.h"
 
 namespace rnvp {
@@ -10,7 +10,9 @@ namespace {
 // a 14x cliff next to hidden=(10,).  A hidden -> hidden Linear is one 16x16 tile: its D operand is the next Linear's B
 // operand exactly like the last Linear's, its weight gradient one more contraction over the rows, its bias gradient a DPP
 // row sum.  Fragments are loaded layer by layer (no look-ahead: three Linears' worth per net would not fit 256 registers).
-template <int NH, int KIT, int ACT, int WMAX, int DT>
+// MTH = 2: every hidden layer is carried as two tiles (up to 32 units; the docstring network hidden=(10, 20, 15) of
+// realnvp.py:22-38): a hidden -> hidden Linear becomes 2 x 2 tile products, padding tiles multiply zeros.
+template <int NH, int KIT, int ACT, int WMAX, int DT, int MTH>
 __global__ void __launch_bounds__(64 * WMAX)
 k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
                     const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch,
@@ -26,7 +28,7 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
     float *RED = lds + pl.oRED;
     f4 *XS = reinterpret_cast<f4 *>(lds + pl.oXS + (size_t)wave * pl.xs_floats);
     float *TT = lds + pl.oTT + (size_t)wave * pl.tt_floats;
-    float *T_in = TT, *T_g = TT + NIT * 16 * TS, *T_h = T_g + 2 * 16 * TS;        // [input tiles][g of t, s][h of t, s]
+    float *T_in = TT, *T_g = TT + NIT * 16 * TS, *T_h = T_g + 2 * MTH * 16 * TS;  // [input tiles][g: net, tile][h: net, tile]
     for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;
     __syncthreads();
     for (int p = tid; p < P; p += nthreads) {
@@ -38,9 +40,9 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
     const int64_t nb = (n + batch - 1) / batch;
 
     // ---- per-lane constants.  Linear k maps nin_k -> nout_k (k = 0: the net input; k = NH: the d outputs) ----
-    int gF[NH + 1], gB[NH + 1], gT[NH + 1][4], sS[NH + 1][4], sS0[NIT][4], sBk[NH + 1][4];
-    f4 hm[NH];
-    const int dump = npn + lane;
+    int gF[NH + 1], gB[NH + 1], gT[NH + 1][4], sS[NH + 1][4], sS0[NIT][4], sBk[NH + 1][4];      // tile (0, 0); + tile strides below
+    f4 hm[NH][MTH];
+    const int dump = npn + (lane & 15);
 #pragma unroll
     for (int k = 0; k <= NH; ++k) {
         const int nin = s.nin[k], nout = s.nout[k], wo = s.woff[k], bo = s.boff[k];
@@ -54,8 +56,13 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
         }
         if (k < NH)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hm[k][e] = 4 * e + q < nout ? 1.f : 0.f;
+            for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hm[k][m][e] = 16 * m + 4 * e + q < nout ? 1.f : 0.f;
     }
+    // stage position of element (unit u of Linear k's outputs, column j) of d W_k; of d b_k[u]
+    auto stage_w = [&](int k, int u, int j) -> int { return (u < s.nout[k] && j < s.nin[k]) ? s.woff[k] + u * s.nin[k] + j : dump; };
+    auto stage_b = [&](int k, int u) -> int { return u < s.nout[k] ? s.boff[k] + u : dump; };
 #pragma unroll
     for (int nt = 0; nt < NIT; ++nt)
 #pragma unroll
@@ -94,45 +101,59 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
                 co[nt][e] = (src >= 0 && j >= d && j < nin0) ? c[src * cd + (j - d)] : 0.f;
             }
     };
-    // both nets of one layer, interleaved: hidden activations hh[net][k]; outputs o[1] (s) and, if asked for, o[0] (t)
-    auto nets_fwd = [&](const float *pl0, const f4 (&in)[NIT], f4 (&hh)[2][NH], f4 (&o)[2], auto need_t) {
+    // both nets of one layer, interleaved: hidden activations hh[net][k][tile]; outputs o[1] (s) and, if asked for, o[0] (t)
+    auto nets_fwd = [&](const float *pl0, const f4 (&in)[NIT], f4 (&hh)[2][NH][MTH], f4 (&o)[2], auto need_t) {
         constexpr int N0 = decltype(need_t)::value ? 0 : 1;
-        f4 acc[2];
 #pragma unroll
-        for (int net = 0; net < 2; ++net)
+        for (int m = 0; m < MTH; ++m) {
+            f4 acc[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[net][e] = pl0[net * npn + gB[0] + 4 * e];
+            for (int net = 0; net < 2; ++net)
 #pragma unroll
-        for (int k = 0; k < KIT; ++k)
+                for (int e = 0; e < 4; ++e) acc[net][e] = pl0[net * npn + gB[0] + 16 * m + 4 * e];
 #pragma unroll
-            for (int net = 0; net < 2; ++net) acc[net] = mfma16(pl0[net * npn + gF[0] + 4 * k], in[k >> 2][k & 3], acc[net]);
+            for (int k = 0; k < KIT; ++k)
 #pragma unroll
-        for (int net = 0; net < 2; ++net)
+                for (int net = 0; net < 2; ++net)
+                    acc[net] = mfma16(pl0[net * npn + gF[0] + m * 16 * nin0 + 4 * k], in[k >> 2][k & 3], acc[net]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hh[net][0][e] = actf<ACT>(acc[net][e]) * hm[0][e];
+            for (int net = 0; net < 2; ++net)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh[net][0][m][e] = actf<ACT>(acc[net][e]) * hm[0][m][e];
+        }
 #pragma unroll
         for (int k = 1; k < NH; ++k) {
+            const int nin = s.nin[k];
 #pragma unroll
-            for (int net = 0; net < 2; ++net)
+            for (int m = 0; m < MTH; ++m) {
+                f4 acc[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[net][e] = pl0[net * npn + gB[k] + 4 * e];
+                for (int net = 0; net < 2; ++net)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e) acc[net][e] = pl0[net * npn + gB[k] + 16 * m + 4 * e];
 #pragma unroll
-                for (int net = 0; net < 2; ++net) acc[net] = mfma16(pl0[net * npn + gF[k] + 4 * e], hh[net][k - 1][e], acc[net]);
+                for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
-            for (int net = 0; net < 2; ++net)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hh[net][k][e] = actf<ACT>(acc[net][e]) * hm[k][e];
+                        for (int net = 0; net < 2; ++net)
+                            acc[net] = mfma16(pl0[net * npn + gF[k] + m * 16 * nin + 16 * mi + 4 * e], hh[net][k - 1][mi][e], acc[net]);
+#pragma unroll
+                for (int net = 0; net < 2; ++net)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hh[net][k][m][e] = actf<ACT>(acc[net][e]) * hm[k][m][e];
+            }
         }
 #pragma unroll
         for (int net = N0; net < 2; ++net)
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[net][e] = pl0[net * npn + gB[NH] + 4 * e];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
-            for (int net = N0; net < 2; ++net) o[net] = mfma16(pl0[net * npn + gF[NH] + 4 * e], hh[net][NH - 1][e], o[net]);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int net = N0; net < 2; ++net) o[net] = mfma16(pl0[net * npn + gF[NH] + 16 * mi + 4 * e], hh[net][NH - 1][mi][e], o[net]);
     };
 
     int64_t src_next = row_of(0);
@@ -160,7 +181,7 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
 #pragma unroll
                 for (int e = 0; e < DT; ++e) in[0][e] = ((mb >> e) & 1u) ? xq[e] + cin[0][e] : cin[0][e];
                 if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
-                f4 hh[2][NH], o[2];
+                f4 hh[2][NH][MTH], o[2];
                 nets_fwd(PAR + (size_t)l * 2 * npn, in, hh, o, std::true_type{});
 #pragma unroll
                 for (int e = 0; e < DT; ++e) {
@@ -206,90 +227,138 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
                 if (NIT > 1) in[NIT - 1] = cin[NIT - 1];
                 wfence();
                 tile_put(T_in, in0T, q, r);
-                f4 hh[2][NH], o[2];
+                f4 hh[2][NH][MTH], o[2];
                 nets_fwd(pl0, in, hh, o, std::false_type{});
-                f4 es = f4{0.f, 0.f, 0.f, 0.f}, g[2];
-                g[0] = f4{0.f, 0.f, 0.f, 0.f}; g[1] = f4{0.f, 0.f, 0.f, 0.f};
+                f4 es = f4{0.f, 0.f, 0.f, 0.f}, g[2][MTH];      // g: gradient at the outputs of the Linear in hand, per tile
+#pragma unroll
+                for (int net = 0; net < 2; ++net)
+#pragma unroll
+                    for (int m = 0; m < MTH; ++m) g[net][m] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < DT; ++e) {
                     const bool mk = (mb >> e) & 1u;
                     es[e] = exp_acc(o[1][e]);
-                    g[1][e] = mk ? 0.f : fmaf(gy[e] * xq[e], es[e], gld);
-                    g[0][e] = mk ? 0.f : gy[e];
+                    g[1][0][e] = mk ? 0.f : fmaf(gy[e] * xq[e], es[e], gld);
+                    g[0][0][e] = mk ? 0.f : gy[e];
                 }
                 // Linear k = NH .. 1: bias gradient (row sums), weight gradient g^T . h_{k-1}, gradient of h_{k-1}
 #pragma unroll
                 for (int k = NH; k >= 1; --k) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int ke = (k == NH) ? KXT : 4;                    // slots of g that hold units
+                    const int MG = (k == NH) ? 1 : MTH;                    // tiles of g (the d outputs are one tile)
+                    const int ke = (k == NH) ? KXT : 4;                    // slots of a g tile that hold units
+                    const int nin = s.nin[k];
 #pragma unroll
                     for (int net = 0; net < 2; ++net)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (e < ke) {
-                                const float v = row16_sum(g[net][e]);
-                                if (r == 0) stg0[net * pl.stg_net + sBk[k][e]] = v;
-                            }
+                        for (int mg = 0; mg < MTH; ++mg)
+                            if (mg < MG)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (e < ke) {
+                                        const float v = row16_sum(g[net][mg][e]);
+                                        if (r == 0) stg0[net * pl.stg_net + (MTH == 1 ? sBk[k][e] : stage_b(k, 16 * mg + 4 * e + q))] = v;
+                                    }
                     wfence();
-#pragma unroll
-                    for (int net = 0; net < 2; ++net) {
-                        tile_put(T_g + net * 16 * TS, g[net], q, r);
-                        tile_put(T_h + net * 16 * TS, hh[net][k - 1], q, r);
-                    }
-                    f4 gh[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (e < ke)
-#pragma unroll
-                            for (int net = 0; net < 2; ++net) gh[net] = mfma16(pl0[net * npn + gT[k][e]], g[net][e], gh[net]);
-                    wfence();
-                    float gT_[2][4], hT_[2][4];
-#pragma unroll
-                    for (int net = 0; net < 2; ++net) { tile_get(T_g + net * 16 * TS, q, i, gT_[net]); tile_get(T_h + net * 16 * TS, q, i, hT_[net]); }
-                    f4 dw[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int net = 0; net < 2; ++net) dw[net] = mfma16(gT_[net][ks], hT_[net][ks], dw[net]);      // [unit of k: 4q+e][unit of k-1: i]
 #pragma unroll
                     for (int net = 0; net < 2; ++net)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            stg0[net * pl.stg_net + sS[k][e]] = dw[net][e];
-                            g[net][e] = gh[net][e] * dactf<ACT>(hh[net][k - 1][e]) * hm[k - 1][e];
+                        for (int m = 0; m < MTH; ++m) {
+                            if (m < MG) tile_put(T_g + (net * MTH + m) * 16 * TS, g[net][m], q, r);
+                            tile_put(T_h + (net * MTH + m) * 16 * TS, hh[net][k - 1][m], q, r);
                         }
+                    f4 gh[2][MTH];
+#pragma unroll
+                    for (int mi = 0; mi < MTH; ++mi) {
+                        gh[0][mi] = f4{0.f, 0.f, 0.f, 0.f}; gh[1][mi] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int mg = 0; mg < MTH; ++mg)
+                            if (mg < MG)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (e < ke)
+#pragma unroll
+                                        for (int net = 0; net < 2; ++net)
+                                            gh[net][mi] = mfma16(pl0[net * npn + gT[k][e] + mg * 16 * nin + 16 * mi], g[net][mg][e], gh[net][mi]);
+                    }
+                    wfence();
+#pragma unroll
+                    for (int mg = 0; mg < MTH; ++mg) {
+                        if (mg >= MG) continue;
+                        float gT_[2][4];
+                        tile_get(T_g + (0 * MTH + mg) * 16 * TS, q, i, gT_[0]);
+                        tile_get(T_g + (1 * MTH + mg) * 16 * TS, q, i, gT_[1]);
+#pragma unroll
+                        for (int mi = 0; mi < MTH; ++mi) {
+                            float hT_[2][4];
+                            tile_get(T_h + (0 * MTH + mi) * 16 * TS, q, i, hT_[0]);
+                            tile_get(T_h + (1 * MTH + mi) * 16 * TS, q, i, hT_[1]);
+                            f4 dw[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                                for (int net = 0; net < 2; ++net) dw[net] = mfma16(gT_[net][ks], hT_[net][ks], dw[net]);      // [unit of k][unit of k-1]
+#pragma unroll
+                            for (int net = 0; net < 2; ++net)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    stg0[net * pl.stg_net + (MTH == 1 ? sS[k][e] : stage_w(k, 16 * mg + 4 * q + e, 16 * mi + i))] = dw[net][e];
+                        }
+                    }
+#pragma unroll
+                    for (int net = 0; net < 2; ++net)
+#pragma unroll
+                        for (int mi = 0; mi < MTH; ++mi)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g[net][mi][e] = gh[net][mi][e] * dactf<ACT>(hh[net][k - 1][mi][e]) * hm[k - 1][mi][e];
                 }
                 // Linear 0: weight + bias gradient against the input tile(s); input gradient for the x part
                 f4 gin[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int m = 0; m < MTH; ++m)
 #pragma unroll
-                    for (int net = 0; net < 2; ++net) gin[net] = mfma16(pl0[net * npn + gT[0][e]], g[net][e], gin[net]);
-                wfence();
-                tile_put(T_g, g[0], q, r);
-                tile_put(T_g + 16 * TS, g[1], q, r);
-                wfence();
-                float g0T[2][4], inT[NIT][4];
-                tile_get(T_g, q, i, g0T[0]); tile_get(T_g + 16 * TS, q, i, g0T[1]);
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NIT; ++nt) tile_get(T_in + nt * 16 * TS, q, i, inT[nt]);
-                f4 dw0[2][NIT];
+                        for (int net = 0; net < 2; ++net) gin[net] = mfma16(pl0[net * npn + gT[0][e] + m * 16 * nin0], g[net][m][e], gin[net]);
+                wfence();
 #pragma unroll
                 for (int net = 0; net < 2; ++net)
 #pragma unroll
-                    for (int nt = 0; nt < NIT; ++nt) dw0[net][nt] = f4{0.f, 0.f, 0.f, 0.f};
+                    for (int m = 0; m < MTH; ++m) tile_put(T_g + (net * MTH + m) * 16 * TS, g[net][m], q, r);
+                wfence();
+                float inT[NIT][4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int nt = 0; nt < NIT; ++nt) tile_get(T_in + nt * 16 * TS, q, i, inT[nt]);
+#pragma unroll
+                for (int m = 0; m < MTH; ++m) {
+                    float g0T[2][4];
+                    tile_get(T_g + (0 * MTH + m) * 16 * TS, q, i, g0T[0]);
+                    tile_get(T_g + (1 * MTH + m) * 16 * TS, q, i, g0T[1]);
+                    f4 dw0[2][NIT];
 #pragma unroll
                     for (int net = 0; net < 2; ++net)
 #pragma unroll
-                        for (int nt = 0; nt < NIT; ++nt) dw0[net][nt] = mfma16(g0T[net][ks], inT[nt][ks], dw0[net][nt]);
+                        for (int nt = 0; nt < NIT; ++nt) dw0[net][nt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int net = 0; net < 2; ++net)
+                    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                    for (int nt = 0; nt < NIT; ++nt)
+                        for (int net = 0; net < 2; ++net)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) stg0[net * pl.stg_net + sS0[nt][e]] = dw0[net][nt][e];
+                            for (int nt = 0; nt < NIT; ++nt) dw0[net][nt] = mfma16(g0T[net][ks], inT[nt][ks], dw0[net][nt]);
+#pragma unroll
+                    for (int net = 0; net < 2; ++net)
+#pragma unroll
+                        for (int nt = 0; nt < NIT; ++nt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                int pos;
+                                if (MTH == 1) pos = sS0[nt][e];
+                                else {
+                                    const int u = 16 * m + 4 * q + e, j = 16 * nt + i;
+                                    pos = j == nin0 ? stage_b(0, u) : stage_w(0, u, j);
+                                }
+                                stg0[net * pl.stg_net + pos] = dw0[net][nt][e];
+                            }
+                }
 #pragma unroll
                 for (int e = 0; e < DT; ++e) {
                     const bool mk = (mb >> e) & 1u;
@@ -315,9 +384,9 @@ k_fit_resident_deep(KShape s, RcPlan pl, float *__restrict__ params, const uint8
     }
 }
 
-template <int NH, int KIT, int ACT, int WMAX, int DT>
-int launch_deep_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
-    auto kern = k_fit_resident_deep<NH, KIT, ACT, WMAX, DT>;
+template <int NH, int KIT, int ACT, int WMAX, int DT, int MTH>
+int launch_deep_m(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    auto kern = k_fit_resident_deep<NH, KIT, ACT, WMAX, DT, MTH>;
     static std::atomic<uint64_t> attr_done{0};
     const int rc = allow_big_lds(reinterpret_cast<const void *>(kern), (int)kLdsMax, attr_done);
     if (rc) return rc;
@@ -329,6 +398,13 @@ int launch_deep_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochA
     }
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
+}
+
+template <int NH, int KIT, int ACT, int WMAX, int DT>
+int launch_deep_w(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a) {
+    bool wide = false;                       // a hidden layer of more than one tile: every hidden layer runs as two
+    for (int i = 0; i < k.nh; ++i) wide = wide || k.nout[i] > 16;
+    return wide ? launch_deep_m<NH, KIT, ACT, WMAX, DT, 2>(st, k, p, a) : launch_deep_m<NH, KIT, ACT, WMAX, DT, 1>(st, k, p, a);
 }
 
 template <int NH, int KIT, int DT>

@@ -52,7 +52,7 @@ __device__ __forceinline__ void wfence() {
 // units past h are multiplied by a 0 / 1 lane mask, output features past d are passed through), so no gather is guarded.
 constexpr int TS = 17;
 constexpr int kRcMaxWaves = 8;
-constexpr int kDump = 64;              // per-net dump zone of the stage: where the padding lanes of a weight-gradient tile write
+constexpr int kDump = 16;              // per-net dump zone of the stage: where the padding lanes of a weight-gradient tile write (lane & 15)
 
 
 // e^x to ~1.5 ulp from the hardware exp2: x log2(e) split into a rounded product and its error

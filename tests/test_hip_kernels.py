@@ -874,6 +874,9 @@ RESIDENT_CASES = [
     (3, 16, 4, (16, 16), "relu", 200, 64, 0.0, False),        # full tiles, two input tiles
     (5, 3, 1, (5, 9, 4), "relu", 90, 96, 0.0, True),          # user masks, one batch larger than the data
     (16, 2, 0, (3, 2), "tanh", 40, 8, 0.0, False),
+    (8, 2, 1, (10, 20, 15), "tanh", 96, 32, 0.0, False),      # the docstring network (realnvp.py:22-38): a two-tile hidden layer
+    (3, 5, 3, (32, 32), "relu", 70, 32, 0.1, False),          # two full tiles per hidden layer
+    (2, 16, 4, (17, 9), "tanh", 50, 25, 0.0, True),
     (2, 2, 1, (10,), "tanh", 5, 1, 0.0, False),               # one row per batch
     (2, 3, 0, (4, 4), "relu", 3, 1, 0.1, True),
 ]
@@ -895,7 +898,7 @@ def test_resident_fit_epoch_vs_step_loop(L, d, c, hidden, act, n, batch, wd, use
     assert _hip.fit_epoch_resident(shape, batch)
     assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, hidden, act, alt_masks=alt, family="valu"), batch)
     assert not _hip.fit_epoch_resident(shape, 129) and not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (33,), act), batch)
-    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (10, 20), act), batch)            # a hidden tile per layer only
+    assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (10, 33), act), batch)            # at most two tiles per hidden layer
     assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(L, d, c, (4, 4, 4, 4), act), batch)
     assert not _hip.fit_epoch_resident(_hip.RnvpShape.make(17, d, c, hidden, act), batch)
     P = _hip.param_count(shape)

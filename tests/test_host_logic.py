@@ -230,7 +230,8 @@ def test_kernel_selection_policy_is_host_logic():
     assert not _hip.fit_epoch_resident(default, 129)                  # more than 8 waves of 16 rows
     assert not _hip.fit_epoch_resident(R(8, 2, 1, (10,), "tanh", family="valu"), 32)
     assert not _hip.fit_epoch_resident(R(8, 16, 4, (128,), "tanh", alt_masks=1), 32)      # C2: 75 k parameters do not fit LDS
-    assert not _hip.fit_epoch_resident(R(8, 2, 1, (10, 20, 15), "tanh"), 32)              # a layer wider than one tile: the step loop
+    assert _hip.fit_epoch_resident(R(8, 2, 1, (10, 20, 15), "tanh"), 32)                  # the docstring network: two tiles per hidden layer
+    assert not _hip.fit_epoch_resident(R(8, 2, 1, (10, 33), "tanh"), 32)
     assert _hip.fit_epoch_resident(R(8, 2, 1, (10, 10), "tanh"), 32) and _hip.fit_epoch_resident(R(8, 2, 1, (10, 16, 15), "relu"), 32)
     assert not _hip.fit_epoch_resident(R(8, 2, 1, (4, 4, 4, 4), "tanh"), 32)
     assert not _hip.fit_epoch_resident(R(8, 2, 1, (33,), "tanh"), 32)
