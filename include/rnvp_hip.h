@@ -264,6 +264,20 @@ int rnvp_fit_epoch(void *stream, const rnvp_shape *shape,
                    int64_t first_step, void *workspace, size_t workspace_bytes);
 
 /*
+ * n_epochs epochs in one call: `perms` holds n_epochs permutations of the n rows back to back (int64 [n_epochs][n]), loss_hist
+ * [n_epochs][ceil(n / batch_size)]; everything else as rnvp_fit_epoch, which is this call with n_epochs = 1.  Where
+ * rnvp_fit_epoch_resident says so the whole call is ONE persistent launch (the parameters never leave LDS between epochs);
+ * otherwise the epochs' batches are enqueued back to back.  RealNVP.fit uses it when no per-epoch progress text is asked for.
+ */
+int rnvp_fit_epochs(void *stream, const rnvp_shape *shape,
+                    float *params, const uint8_t *masks,
+                    const float *x, const float *c, const int64_t *perms, int64_t n, int64_t batch_size, int64_t n_epochs,
+                    float *grad_buf, float *loss_hist,
+                    float *exp_avg, float *exp_avg_sq,
+                    double lr, double beta1, double beta2, double eps, double weight_decay,
+                    int64_t first_step, void *workspace, size_t workspace_bytes);
+
+/*
  * 1 when rnvp_fit_epoch runs this shape at this batch size as ONE persistent launch per epoch ("resident" fit,
  * rnvp_resident.hip): one hidden layer of at most 16 units (at most 32 while d + cdim <= 15) or two or three of at most 32
  * each, d <= 16, d + cdim <= 31, at most 16 layers, batch_size <= 128, and the model with its per-wave gradient stages inside one CU's 160 KB of LDS -- the

@@ -430,6 +430,17 @@ class FlowEngine:
                        opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
         opt.step_count += len(batch_bounds(n, batch_size))
 
+    def fit_epochs(self, opt, x, c, perms, batch_size, losses):
+        """single-GPU: every batch of SEVERAL epochs in one library call (rnvp_fit_epochs): perms [n_epochs, n], losses
+        [n_epochs, batches per epoch].  For a model that fits one CU's LDS that is ONE launch for the whole fit."""
+        lr, b1, b2, eps, wd = opt.hyper
+        n_epochs, n = perms.shape
+        g = self.ensure_gbuf()
+        ws = self.workspace(_hip.OP_TRAIN, min(n, batch_size))
+        _hip.fit_epochs(self.shape, self.params, self.masks, x, c, perms, n, batch_size, n_epochs, g[:self.P], losses,
+                        opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
+        opt.step_count += n_epochs * len(batch_bounds(n, batch_size))
+
     def fit_epoch_dp(self, opt, comm, x, c, perm, batch_size, losses):
         """data parallel: all batches of one epoch in ONE library call on ONE stream (rnvp_fit_epoch_dp): per batch this
         rank's loss + gradient, the all-reduce of [gradient | loss] on the library's RCCL communicator, loss read-out +
@@ -627,6 +638,19 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
             t = torch.tensor(perms.seeds, dtype=torch.int64, device=dev)
             broadcast_(t, src=0)
             perms.seeds = [int(v) for v in t.cpu()]
+        # One GPU, nobody watching the epochs go by (verbose == 0), a model small enough to live in one CU's LDS: the whole fit
+        # is one library call (one persistent launch: the parameters never leave LDS between epochs).  The permutations of all
+        # epochs are a few MB at the sizes such models are fitted on.
+        if (world == 1 and prior is None and epoch_hook is None and n_epochs > 0 and dev.type == "cuda"
+                and n_epochs * n <= (1 << 24) and _hip.fit_epoch_resident(engine.shape, batch_size)):
+            host = torch.empty((n_epochs, n), dtype=torch.int64, pin_memory=True)
+            for e in range(n_epochs):
+                host[e].copy_(perms.get(e))
+            losses = torch.zeros((n_epochs, len(bounds)), dtype=torch.float32, device=dev)
+            engine.fit_epochs(opt, X, C, host.to(dev, non_blocking=True), batch_size, losses)
+            flat = losses.reshape(-1).cpu()
+            loss_history.extend(flat[i].clone() for i in range(flat.numel()))
+            return loss_history
         _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world, prior)
     finally:
         perms.close()

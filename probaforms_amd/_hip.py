@@ -128,6 +128,8 @@ _SIGNATURES = {
                                   _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "rnvp_fit_epoch": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
                                  _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "rnvp_fit_epochs": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I64, _VP, _VP, _VP, _VP,
+                                  _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "rnvp_dp_unique_id": (C.c_int, [_VP]),
     "rnvp_dp_init": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rnvp_dp_destroy": (C.c_int, [_VP]),
@@ -323,6 +325,17 @@ def fit_epoch(shape, params, masks, x, c, perm, n, batch_size, grad_buf, loss_hi
     _call("rnvp_fit_epoch", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
           _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), int(n),
           int(batch_size), _ptr(grad_buf, torch.float32, "grad_buf"), _ptr(loss_hist, torch.float32, "loss_hist"),
+          _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
+          float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn))
+
+
+def fit_epochs(shape, params, masks, x, c, perms, n, batch_size, n_epochs, grad_buf, loss_hist, exp_avg, exp_avg_sq,
+               lr, beta1, beta2, eps, weight_decay, first_step, ws):
+    """n_epochs epochs in one library call: perms [n_epochs, n], loss_hist [n_epochs, batches per epoch]"""
+    wp, wn = _ws(ws)
+    _call("rnvp_fit_epochs", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+          _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perms, torch.int64, "perms"), int(n),
+          int(batch_size), int(n_epochs), _ptr(grad_buf, torch.float32, "grad_buf"), _ptr(loss_hist, torch.float32, "loss_hist"),
           _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
           float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn))
 

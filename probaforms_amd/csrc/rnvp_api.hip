@@ -303,31 +303,42 @@ int rnvp_fit_epoch_resident(const rnvp_shape *shape, int64_t batch_size) {
     return resident::fits(ks, batch_size) ? 1 : 0;
 }
 
+int rnvp_fit_epochs(void *stream, const rnvp_shape *shape, float *params, const uint8_t *masks,
+                    const float *x, const float *c, const int64_t *perms, int64_t n, int64_t batch_size, int64_t n_epochs,
+                    float *grad_buf, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                    double lr, double beta1, double beta2, double eps, double weight_decay,
+                    int64_t first_step, void *workspace, size_t workspace_bytes) {
+    if (n < 0 || batch_size < 1 || n_epochs < 0 || !perms || !loss_hist || first_step < 1) return RNVP_EINVAL;
+    KShape ks;
+    const int rc0 = make_kshape(shape, &ks);
+    if (rc0) return rc0;
+    const int64_t nb = (n + batch_size - 1) / batch_size;
+    // a model that fits one CU's LDS at a batch of at most 128 rows: all epochs in one persistent launch
+    if (n > 0 && n_epochs > 0 && resident::fits(ks, batch_size)) {
+        if (bad_ptrs(ks, params, masks, x, c) || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
+        return resident::fit_epoch(static_cast<hipStream_t>(stream), ks, params, masks, x, c, perms, n, batch_size, n_epochs, loss_hist,
+                                   exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step);
+    }
+    for (int64_t e = 0; e < n_epochs; ++e) {
+        int64_t k = 0;
+        for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
+            const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
+            const int rc = rnvp_train_step(stream, shape, params, masks, x, c, perms + e * n + s0, rows, 1.0f / (float)rows,
+                                           grad_buf, loss_hist + e * nb + k, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+                                           weight_decay, first_step + e * nb + k, workspace, workspace_bytes);
+            if (rc) return rc;
+        }
+    }
+    return RNVP_OK;
+}
+
 int rnvp_fit_epoch(void *stream, const rnvp_shape *shape, float *params, const uint8_t *masks,
                    const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
                    float *grad_buf, float *loss_hist, float *exp_avg, float *exp_avg_sq,
                    double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t first_step, void *workspace, size_t workspace_bytes) {
-    if (n < 0 || batch_size < 1 || !perm || !loss_hist || first_step < 1) return RNVP_EINVAL;
-    {   // a model that fits one CU's LDS at a batch of at most 256 rows: the whole epoch in one persistent launch
-        KShape ks;
-        const int rc = make_kshape(shape, &ks);
-        if (rc) return rc;
-        if (n > 0 && resident::fits(ks, batch_size)) {
-            if (bad_ptrs(ks, params, masks, x, c) || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
-            return resident::fit_epoch(static_cast<hipStream_t>(stream), ks, params, masks, x, c, perm, n, batch_size, loss_hist,
-                                       exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step);
-        }
-    }
-    int64_t k = 0;
-    for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
-        const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
-        const int rc = rnvp_train_step(stream, shape, params, masks, x, c, perm + s0, rows, 1.0f / (float)rows,
-                                       grad_buf, loss_hist + k, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
-                                       weight_decay, first_step + k, workspace, workspace_bytes);
-        if (rc) return rc;
-    }
-    return RNVP_OK;
+    return rnvp_fit_epochs(stream, shape, params, masks, x, c, perm, n, batch_size, 1, grad_buf, loss_hist, exp_avg, exp_avg_sq, lr,
+                           beta1, beta2, eps, weight_decay, first_step, workspace, workspace_bytes);
 }
 
 }  // extern "C"

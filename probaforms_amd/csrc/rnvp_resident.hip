@@ -32,7 +32,7 @@ namespace {
 template <int MT, int KIT, int ACT, int WMAX, int DT, bool SAVE>
 __global__ void __launch_bounds__(64 * WMAX)
 k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
-                  const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch,
+                  const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch, int64_t n_epochs,
                   float *__restrict__ loss_hist, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1,
                   double beta2, double eps, double wd, double b1t, double b2t) {
     constexpr int NIT = KIT > 4 ? 2 : 1;               // 16-element tiles of the net input
@@ -56,7 +56,13 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
     }
     __syncthreads();
     const float prior_c = 0.5f * (float)d * kLog2Pi;
-    const int64_t nb = (n + batch - 1) / batch;
+    // perm holds n_epochs permutations of n rows back to back; every epoch is cut into the same batches (the last one ragged)
+    const int64_t nb_e = (n + batch - 1) / batch, nb = nb_e * n_epochs;
+    auto batch_at = [&](int64_t kb, int64_t &s0, int64_t &rows) {
+        const int64_t ep = kb / nb_e, k = kb - ep * nb_e;
+        s0 = ep * n + k * batch;
+        rows = (n - k * batch < batch) ? n - k * batch : batch;
+    };
 
     // ---- per-lane constants: gather offsets (floats, relative to a net's parameter block), padding masks, stage offsets ----
     const int gW1 = w0 + pi * nin0 + q;                   // + m 16 nin0 + 4k : W1[16m + pi][4k + q]          (GEMM1)
@@ -101,8 +107,8 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
     // rows of a batch for this lane (zeros past d / cdim / the batch): x, and the condition placed behind x in the net input
     auto row_of = [&](int64_t kb) -> int64_t {
         if (kb >= nb) return -1;
-        const int64_t s0 = kb * batch;
-        const int64_t rows = (n - s0 < batch) ? n - s0 : batch;
+        int64_t s0, rows;
+        batch_at(kb, s0, rows);
         const int64_t rr = (int64_t)wave * 16 + r;
         return rr < rows ? perm[s0 + rr] : -1;
     };
@@ -186,8 +192,10 @@ k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t
     load_rows(src_next, nxq, ncq);
     src_next = row_of(1);
     for (int64_t kb = 0; kb < nb; ++kb) {
-        const int64_t s0 = kb * batch;
-        const int rows = (int)((n - s0 < batch) ? n - s0 : batch);
+        int64_t s0, rows64;
+        batch_at(kb, s0, rows64);
+        (void)s0;
+        const int rows = (int)rows64;
         const float inv_B = 1.0f / (float)rows;
         const int nw = (rows + 15) >> 4;
         f4 xq = nxq, cin[NIT];
@@ -486,7 +494,7 @@ int launch_rc_s(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArg
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);
         hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WMAX), (size_t)p.total_floats * sizeof(float), st, k, p, a.params, a.masks, a.x, a.c,
-                           a.perm, a.n, a.batch_size, a.loss_hist, a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.wd,
+                           a.perm, a.n, a.batch_size, a.n_epochs, a.loss_hist, a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.wd,
                            std::pow(a.beta1, (double)a.first_step), std::pow(a.beta2, (double)a.first_step));
     }
     RNVP_HIP_TRY(hipGetLastError());
@@ -527,12 +535,12 @@ int launch_rc_kit(hipStream_t st, const KShape &k, const RcPlan &p, const EpochA
 }  // namespace
 
 int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *masks, const float *x, const float *c,
-              const int64_t *perm, int64_t n, int64_t batch_size, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+              const int64_t *perm, int64_t n, int64_t batch_size, int64_t n_epochs, float *loss_hist, float *exp_avg, float *exp_avg_sq,
               double lr, double beta1, double beta2, double eps, double weight_decay, int64_t first_step) {
-    if (n == 0) return RNVP_OK;
+    if (n == 0 || n_epochs == 0) return RNVP_OK;
     RcPlan rcp;
     if (make_rc_plan(k, batch_size, &rcp)) {
-        const EpochArgs a{params, masks, x, c, perm, n, batch_size, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+        const EpochArgs a{params, masks, x, c, perm, n, batch_size, n_epochs, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
                           first_step};
         if (k.nh > 1) return launch_deep(st, k, rcp, a);
         if (k.nout[0] <= 16) return launch_rc_kit<1>(st, k, rcp, a);

@@ -21,7 +21,7 @@ struct RcPlan {
 };
 
 struct EpochArgs {
-    float *params; const uint8_t *masks; const float *x, *c; const int64_t *perm; int64_t n, batch_size;
+    float *params; const uint8_t *masks; const float *x, *c; const int64_t *perm; int64_t n, batch_size, n_epochs;
     float *loss_hist, *exp_avg, *exp_avg_sq; double lr, beta1, beta2, eps, wd; int64_t first_step;
 };
 

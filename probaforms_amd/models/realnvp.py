@@ -241,7 +241,8 @@ class RealNVP(GenModel):
             else:
                 bar.set_description("loss: %.4f" % float(losses[-1]))
 
-        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook, prior=prior, perms=perms)
+        fit_epochs(eng, self.opt, Xd, Cd, self.batch_size, self.n_epochs, self.loss_history, hook if bar is not None else None,
+                   prior=prior, perms=perms)
         if bar is not None:
             bar.close()
 

@@ -948,3 +948,33 @@ def test_resident_fit_epoch_vs_step_loop(L, d, c, hidden, act, n, batch, wd, use
     assert np.abs(mr - ml).max() < 1e-5 * max(1.0, np.abs(ml).max())
     assert np.abs(vr - vl).max() < 1e-5 * max(1.0, np.abs(vl).max())
     assert np.abs(pr - p0).max() > 1e-3            # it did train
+
+
+@pytest.mark.parametrize("L,d,c,hidden,batch", [(8, 2, 1, (10,), 32), (4, 5, 3, (10, 12), 25), (2, 16, 4, (128,), 64)])
+def test_fit_epochs_equals_consecutive_fit_epoch_calls(L, d, c, hidden, batch):
+    """rnvp_fit_epochs (several epochs, one library call; one persistent launch where the model is LDS-resident) walks
+    exactly the trajectory of one rnvp_fit_epoch call per epoch, bit for bit, on the resident kernels and on the loop"""
+    from probaforms_amd import _hip
+    rng = np.random.default_rng(L + d)
+    n, E = 90, 3
+    masks = _dev(((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8), torch.uint8)
+    shape = _hip.RnvpShape.make(L, d, c, hidden, "tanh", alt_masks=1 if len(hidden) == 1 else 0)
+    P = _hip.param_count(shape)
+    p0 = (rng.uniform(-1, 1, P) * 0.3).astype(np.float32)
+    x = _dev(rng.standard_normal((n, d)).astype(np.float32)); cc = _dev(rng.standard_normal((n, c)).astype(np.float32))
+    perms = torch.from_numpy(np.stack([rng.permutation(n) for _ in range(E)]).astype(np.int64)).cuda()
+    nb = (n + batch - 1) // batch
+    ws = _ws(_hip, shape, _hip.OP_TRAIN, batch)
+    out = []
+    for one_call in (True, False):
+        p = _dev(p0).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+        g = torch.empty(P, device="cuda"); hist = torch.full((E, nb), float("nan"), device="cuda")
+        if one_call:
+            _hip.fit_epochs(shape, p, masks, x, cc, perms, n, batch, E, g, hist, m, v, 2e-3, 0.9, 0.999, 1e-8, 0.0, 1, ws)
+        else:
+            for e in range(E):
+                _hip.fit_epoch(shape, p, masks, x, cc, perms[e], n, batch, g, hist[e], m, v, 2e-3, 0.9, 0.999, 1e-8, 0.0, 1 + e * nb, ws)
+        out.append((hist.clone(), p.clone(), m.clone(), v.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(out[0][0]).all())
