@@ -1,22 +1,26 @@
-// rnvp_resident.hip -- "resident" fit: one epoch of a SMALL flow at a SMALL batch size in ONE persistent workgroup (gfx950).
+// rnvp_resident.hip -- "resident" fit: the batch loop of a SMALL flow at a SMALL batch size in ONE persistent workgroup (gfx950).
 //
 // The reference's defaults -- hidden=(10,), 8 layers, batch_size=32 (/root/reference/probaforms/models/realnvp.py:161-176)
 // -- are a flow of ~1000 parameters stepped on a few dozen rows: a step is a chain of ~50 tiny dependent GEMMs, and the
 // three launches of the general path (weight re-pack, loss + gradient, reduce + Adam) cost more than the arithmetic
 // (41 us per step for d = 2, h = 10).  A CU's 160 KB of LDS holds such a model whole, so the batch loop of RealNVP.fit
-// (realnvp.py:237-254) runs here as ONE launch per epoch:
-//   * the flat parameters (reference order) live in LDS for the whole epoch, and so do Adam's moments when they fit;
+// (realnvp.py:235-254) runs here as ONE launch per epoch -- or per fit: rnvp_fit_epochs hands over several epochs'
+// permutations at once:
+//   * the flat parameters (reference order) live in LDS for the whole launch, and so do Adam's moments when they fit;
 //   * wave w owns rows 16w .. 16w+15 of every batch and runs its forward / backward chain register to register on
-//     v_mfma_f32_16x16x4_f32 (layout below): no workgroup barrier inside a step;
+//     v_mfma_f32_16x16x4_f32 (the per-lane layout is described in rnvp_resident_dev.h): no workgroup barrier inside a step;
 //   * the weight gradients of the wave's 16 rows are a third kind of MFMA contraction (over the rows, operands
 //     transposed through wave-private LDS tiles), written to the wave's stage in the reference's flat order;
 //   * one barrier, then all threads add the stages in wave order (deterministic), apply Adam in place in LDS and write
 //     the batch loss; one more barrier and the next batch starts (its rows were requested a step ahead).  Parameters and
-//     moments go back to HBM once per epoch.
-// A single wave issues one VALU instruction per 4 cycles, so what bounds a step here is its INSTRUCTION COUNT (about
-// 180 per layer forward, 900 backward): everything that does not depend on the data -- gather offsets, padding masks,
-// stage offsets, mask bits -- is computed once per launch, and the next layer's weight fragments are requested while the
-// current layer computes.  Measured (scripts/resident_time.py, profiles/): 21 us per step for the defaults.
+//     moments go back to HBM once, at the end of the launch.
+// A single wave issues one VALU instruction per 4 cycles, so what bounds a step here is its INSTRUCTION COUNT: everything
+// that does not depend on the data -- gather offsets, padding masks, stage offsets, mask bits -- is computed once per
+// launch, the next layer's weight fragments are requested while the current layer computes, and (up to four waves) the
+// forward keeps the hidden activations for the backward.  Measured (scripts/resident_time.py, profiles/r03_resident_time.txt):
+// 15 us per step for the defaults against 41.
+// This file: ONE hidden layer (one or two tiles).  Two or three hidden layers: rnvp_resident_deep.hip; the conditional VAE:
+// cvae_resident.hip.
 // Same arithmetic per element as the other kernel families (tanh through exp2 / rcp, torch.optim.Adam as separately
 // rounded operations); the summation ORDER over rows and hidden units differs, so results agree with them to rounding,
 // not bit for bit -- run to run this path is bit-reproducible.

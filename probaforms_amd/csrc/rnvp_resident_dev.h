@@ -1,6 +1,6 @@
 // rnvp_resident_dev.h -- device helpers, plans and launch arguments shared by the resident-fit translation units
 // (rnvp_resident.hip: one hidden layer; rnvp_resident_deep.hip: two or three; cvae_resident.hip: the conditional VAE).
-// Split three ways so that the ~130 kernel instantiations compile in parallel.
+// Split three ways so that the ~110 kernel instantiations compile in parallel.
 #pragma once
 #include <cmath>
 
@@ -40,7 +40,7 @@ __device__ __forceinline__ void wfence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- layout: ONE hidden layer of at most 32 units, d <= 16, d + cdim <= 31 ----
+// ---- the per-lane layout shared by the three kernels (d <= 16, d + cdim <= 31, hidden tiles of 16 units) ----
 // Every vector of a row -- the net input [x * mask | c], a tile of 16 hidden units, s, t and their gradients -- is an f4
 // per lane and 16 elements: lane (q = lane >> 4, r = lane & 15) keeps elements 4e + q (e = 0..3) of row r.  An MFMA's D
 // operand comes out in exactly that form when the A rows are gathered in the order pi(i) = 4 (i & 3) + (i >> 2), and it IS
