@@ -978,3 +978,32 @@ def test_fit_epochs_equals_consecutive_fit_epoch_calls(L, d, c, hidden, batch):
     for a, b in zip(*out):
         assert torch.equal(a, b)
     assert bool(torch.isfinite(out[0][0]).all())
+
+
+@pytest.mark.parametrize("name", ["c1_L4", "c1_L8", "tm", "tm_nocond", "reg1d", "d8", "relu_sh", "tanh_mh", "relu_mh"])
+@pytest.mark.parametrize("wd", [0.0, 0.2])
+def test_resident_adam_trajectory_vs_reference(name, wd):
+    """the reference's own 3-step Adam trajectory on one batch (G4: parameters, both moments, losses from the reference run)
+    through the resident fit: three one-batch epochs in ONE launch (rnvp_fit_epochs), every resident kernel form (one
+    hidden layer of one and two tiles, two hidden layers, tanh / relu, with and without a condition, d = 1)"""
+    from probaforms_amd import _hip
+    cs = load_case(name)
+    g = cs["gold"]; k = "G4_adam_wd%g" % wd
+    if k + "_p" not in g:
+        pytest.skip("fixture holds no Adam trajectory for this case")
+    n = cs["X"].shape[0]
+    alt = _hip.RnvpShape.classify_masks(cs["masks"])
+    shape = _hip.RnvpShape.make(cs["L"], cs["d"], cs["c"], cs["hidden"], cs["act"], alt_masks=alt)
+    assert _hip.fit_epoch_resident(shape, n)
+    P = cs["params"].size
+    x, c = _dev(cs["X"]), _dev(cs["C"])
+    p = _dev(cs["params"]).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+    gb = torch.empty(P, device="cuda"); loss = torch.empty(3, device="cuda")
+    perms = torch.arange(n, device="cuda").repeat(3).contiguous()
+    _hip.fit_epochs(shape, p, _dev(cs["masks"], torch.uint8), x, c, perms, n, n, 3, gb, loss, m, v, 0.01, 0.9, 0.999, 1e-8, wd, 1,
+                    _ws(_hip, shape, _hip.OP_TRAIN, n))
+    mr, vr, pr = g[k + "_m"][2], g[k + "_v"][2], g[k + "_p"][2]
+    np.testing.assert_allclose(m.cpu().numpy(), mr, rtol=2e-5, atol=3e-6 * np.abs(mr).max())
+    np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=4e-5, atol=6e-6 * np.abs(vr).max())
+    assert np.abs(p.cpu().numpy() - pr).mean() < 2e-6
+    np.testing.assert_allclose(loss.cpu().numpy(), g[k + "_loss"], rtol=5e-5, atol=5e-5)
