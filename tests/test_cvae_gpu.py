@@ -366,3 +366,22 @@ def test_resident_cvae_fit_epoch_vs_step_loop(d, c, lat, hidden, act, n, batch, 
     assert np.abs(res[2] - manual[2]).max() < 1e-5 * max(1.0, np.abs(manual[2]).max())
     assert np.abs(res[3] - manual[3]).max() < 1e-5 * max(1.0, np.abs(manual[3]).max())
     assert np.abs(res[1] - p0).max() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["default", "nocond"])
+def test_resident_cvae_adam_trajectory_vs_reference(name):
+    """the reference's own 3-step trajectory (parameters and losses from the reference run with the recorded eps draws)
+    through the resident CVAE kernel: one cvae_fit_epoch call per step on the fixture's batch"""
+    _hip, g, shape, klw, C = _load(name)
+    n = g["X"].shape[0]; P = g["init_params"].size
+    assert _hip.cvae_fit_epoch_resident(shape, n)
+    x, cc = _dev(g["X"]), _dev(C)
+    p = _dev(g["init_params"]).clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+    gb = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda")
+    ws = torch.empty(_hip.cvae_workspace_bytes(shape, n), dtype=torch.uint8, device="cuda")
+    perm = torch.arange(n, device="cuda")
+    for step in range(3):
+        _hip.cvae_fit_epoch(shape, p, x, cc, perm, _dev(g["adam_eps"][step]), n, n, klw, gb, loss, m, v, 0.01, 0.9, 0.999, 1e-8, 0.0,
+                            step + 1, ws)
+        assert abs(float(loss) - g["adam_loss"][step]) < 5e-5 * max(1.0, abs(float(loss)))
+        assert np.abs(p.cpu().numpy() - g["adam_p"][step]).mean() < 2e-6
