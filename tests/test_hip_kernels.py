@@ -1007,3 +1007,31 @@ def test_resident_adam_trajectory_vs_reference(name, wd):
     np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=4e-5, atol=6e-6 * np.abs(vr).max())
     assert np.abs(p.cpu().numpy() - pr).mean() < 2e-6
     np.testing.assert_allclose(loss.cpu().numpy(), g[k + "_loss"], rtol=5e-5, atol=5e-5)
+
+
+def test_epoch_entry_points_argument_checks():
+    """the epoch-level entry points refuse what they cannot run (status codes, nothing launched) and treat empty work as a no-op"""
+    from probaforms_amd import _hip
+    shape = _hip.RnvpShape.make(2, 2, 1, (10,), "tanh", alt_masks=1)
+    P = _hip.param_count(shape)
+    p = torch.zeros(P, device="cuda"); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda"); g = torch.empty(P, device="cuda")
+    x = torch.randn(8, 2, device="cuda"); c = torch.randn(8, 1, device="cuda"); perm = torch.arange(8, device="cuda")
+    hist = torch.full((4,), 7.0, device="cuda"); ws = _ws(_hip, shape, _hip.OP_TRAIN, 4)
+    adam = (1e-3, 0.9, 0.999, 1e-8, 0.0)
+    _hip.fit_epochs(shape, p, None, x, c, perm, 8, 4, 0, g, hist, m, v, *adam, 1, ws)          # no epochs: nothing happens
+    _hip.fit_epoch(shape, p, None, x, c, perm, 0, 4, g, hist, m, v, *adam, 1, ws)               # no rows
+    assert float(hist.min()) == 7.0 and float(p.abs().max()) == 0.0
+    for bad in (dict(batch=0), dict(first=0), dict(hist=None), dict(perm=None), dict(x=None), dict(m=None)):
+        with pytest.raises(RuntimeError):
+            _hip.fit_epochs(shape, p, None, bad.get("x", x), c, bad.get("perm", perm), 8, bad.get("batch", 4), 1, g, bad.get("hist", hist),
+                            bad.get("m", m), v, *adam, bad.get("first", 1), ws)
+    cs = _hip.CvaeShape.make(2, 1, 2, (10,), "tanh")
+    Pc = _hip.cvae_param_count(cs)
+    pc = torch.zeros(Pc, device="cuda"); mc = torch.zeros(Pc, device="cuda"); vc = torch.zeros(Pc, device="cuda"); gc = torch.empty(Pc, device="cuda")
+    eps = torch.randn(8, 2, device="cuda"); wsc = torch.empty(_hip.cvae_workspace_bytes(cs, 4), dtype=torch.uint8, device="cuda")
+    _hip.cvae_fit_epoch(cs, pc, x, c, perm, eps, 0, 4, 0.001, gc, hist, mc, vc, *adam, 1, wsc)   # no rows
+    for bad in (dict(batch=0), dict(first=0), dict(hist=None), dict(eps=None), dict(perm=None)):
+        with pytest.raises(RuntimeError):
+            _hip.cvae_fit_epoch(cs, pc, x, c, bad.get("perm", perm), bad.get("eps", eps), 8, bad.get("batch", 4), 0.001, gc, bad.get("hist", hist),
+                                mc, vc, *adam, bad.get("first", 1), wsc)
+    assert float(hist.min()) == 7.0
