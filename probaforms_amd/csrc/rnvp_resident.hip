@@ -543,9 +543,12 @@ int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *mas
               double lr, double beta1, double beta2, double eps, double weight_decay, int64_t first_step) {
     if (n == 0 || n_epochs == 0) return RNVP_OK;
     RcPlan rcp;
+    const EpochArgs a{params, masks, x, c, perm, n, batch_size, n_epochs, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                      first_step};
+#ifndef RNVP_NO_NS
+    if (make_ns_plan(k, batch_size, &rcp)) return launch_ns(st, k, rcp, a);       // <= 32 rows: a wave per (row tile, net)
+#endif
     if (make_rc_plan(k, batch_size, &rcp)) {
-        const EpochArgs a{params, masks, x, c, perm, n, batch_size, n_epochs, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
-                          first_step};
         if (k.nh > 1) return launch_deep(st, k, rcp, a);
         if (k.nout[0] <= 16) return launch_rc_kit<1>(st, k, rcp, a);
         return launch_rc_kit<2>(st, k, rcp, a);
