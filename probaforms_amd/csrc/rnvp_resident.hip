@@ -546,7 +546,7 @@ int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *mas
     const EpochArgs a{params, masks, x, c, perm, n, batch_size, n_epochs, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
                       first_step};
 #ifndef RNVP_NO_NS
-    if (make_ns_plan(k, batch_size, &rcp)) return launch_ns(st, k, rcp, a);       // <= 32 rows: a wave per (row tile, net)
+    if (ns_applies(k, batch_size)) return launch_ns(st, k, a);                    // <= 32 rows: a wave per (row tile, net)
 #endif
     if (make_rc_plan(k, batch_size, &rcp)) {
         if (k.nh > 1) return launch_deep(st, k, rcp, a);

@@ -15,7 +15,7 @@ struct RcPlan {
     int W, P, mv_lds;
     int save;                                          // the forward's hidden activations are kept for the backward (nh == 1)
     int stg_net;                                       // floats of one net's stage block: npn + kDump
-    int oPAR, oM, oV, oSTG, oRED, oXS, oTT, oEX;       // float offsets (oEX: the wave pairs' exchange buffers, net-split form)
+    int oPAR, oM, oV, oSTG, oRED, oXS, oTT;            // float offsets
     int xs_floats, tt_floats, stg_floats;              // per wave
     int total_floats;
 };
@@ -149,8 +149,8 @@ inline int rc_kit(const KShape &k) { const int ki = (k.d + k.c + 1 + 3) / 4; ret
 // rnvp_resident_deep.hip: nh = 2 or 3
 int launch_deep(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a);
 // rnvp_resident_ns.hip: nh = 1, batches of at most 32 rows, a wave per (row tile, net)
-bool make_ns_plan(const KShape &k, int64_t batch, RcPlan *out);
-int launch_ns(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a);
+bool ns_applies(const KShape &k, int64_t batch);
+int launch_ns(hipStream_t st, const KShape &k, const EpochArgs &a);
 
 }  // namespace resident
 }  // namespace rnvp

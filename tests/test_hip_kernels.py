@@ -879,6 +879,9 @@ RESIDENT_CASES = [
     (2, 16, 4, (17, 9), "tanh", 50, 25, 0.0, True),
     (2, 2, 1, (10,), "tanh", 5, 1, 0.0, False),               # one row per batch
     (2, 3, 0, (4, 4), "relu", 3, 1, 0.1, True),
+    (4, 8, 3, (16,), "relu", 96, 32, 0.1, True),              # net-split form (rnvp_resident_ns.hip): a full hidden tile, 12 input columns
+    (3, 4, 2, (12,), "tanh", 60, 17, 0.0, False),             # its second row tile holds one row; the widest trimmed hidden tile
+    (8, 2, 1, (32,), "tanh", 64, 32, 0.0, False),             # two hidden tiles on a one-k-step input
 ]
 
 
