@@ -184,9 +184,21 @@ def flatten_parameters(params, device):
     kernels see the same memory.  Returns the flat tensor."""
     total = sum(p.numel() for p in params)
     pad = (-total) % 4                                   # float4 kernels: keep 16-byte multiples
-    flat = torch.zeros(total + pad, dtype=torch.float32, device=device)
-    off = 0
     with torch.no_grad():
+        if params and all(p.device.type == "cpu" for p in params):
+            # freshly built modules: gather on the host, ONE upload (a default flow has 32 small tensors)
+            parts = [p.detach().reshape(-1).to(torch.float32) for p in params]
+            if pad:
+                parts.append(torch.zeros(pad, dtype=torch.float32))
+            flat = torch.cat(parts).to(device)
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+            return flat
+        flat = torch.zeros(total + pad, dtype=torch.float32, device=device)
+        off = 0
         for p in params:
             n = p.numel()
             view = flat[off:off + n].view(p.shape)
@@ -649,7 +661,7 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
             losses = torch.zeros((n_epochs, len(bounds)), dtype=torch.float32, device=dev)
             engine.fit_epochs(opt, X, C, host.to(dev, non_blocking=True), batch_size, losses)
             flat = losses.reshape(-1).cpu()
-            loss_history.extend(flat[i].clone() for i in range(flat.numel()))
+            loss_history.extend(flat.unbind(0))          # 0-d tensors like the reference's (realnvp.py:254), views of one buffer
             return loss_history
         _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook, perms, bounds, rank, world, prior)
     finally:
@@ -678,7 +690,7 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
 
     def read_back(epoch, losses):
         host = losses.cpu()
-        loss_history.extend(host[i].clone() for i in range(host.numel()))
+        loss_history.extend(host.unbind(0))
         if epoch_hook is not None:
             epoch_hook(epoch, host)                      # the epoch's per-batch losses, in batch order
 
