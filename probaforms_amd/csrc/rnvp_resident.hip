@@ -33,8 +33,12 @@ namespace {
 // MT hidden tiles, KIT k-steps of the net input (4 KIT >= d + cdim + 1), WMAX waves, DT slots of x that hold features
 // (4 DT >= d: 2-d data needs one of the four); SAVE: the forward keeps every layer's hidden activations and s in a
 // lane-private LDS area and the backward reads them back instead of recomputing both nets (when that area fits)
+// threads of a launch: a one-tile-per-layer kernel of up to four row waves gets four more waves that only share the Adam phase
+// (where the register budget allows it; they wait at the two barriers of a step meanwhile)
+template <int MT, int KIT, int WMAX, bool SAVE> constexpr int rc_threads() { return MT == 1 && (KIT <= 4 || SAVE) && WMAX == 4 ? 512 : 64 * WMAX; }
+
 template <int MT, int KIT, int ACT, int WMAX, int DT, bool SAVE>
-__global__ void __launch_bounds__(64 * WMAX)
+__global__ void __launch_bounds__((rc_threads<MT, KIT, WMAX, SAVE>()))
 k_fit_resident_rc(KShape s, RcPlan pl, float *__restrict__ params, const uint8_t *__restrict__ masks, const float *__restrict__ x,
                   const float *__restrict__ c, const int64_t *__restrict__ perm, int64_t n, int64_t batch, int64_t n_epochs,
                   float *__restrict__ loss_hist, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, double lr, double beta1,
@@ -497,7 +501,7 @@ int launch_rc_s(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArg
     if (rc) return rc;
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);
-        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WMAX), (size_t)p.total_floats * sizeof(float), st, k, p, a.params, a.masks, a.x, a.c,
+        hipLaunchKernelGGL(kern, dim3(1), dim3(rc_threads<MT, KIT, WMAX, SAVE>()), (size_t)p.total_floats * sizeof(float), st, k, p, a.params, a.masks, a.x, a.c,
                            a.perm, a.n, a.batch_size, a.n_epochs, a.loss_hist, a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.wd,
                            std::pow(a.beta1, (double)a.first_step), std::pow(a.beta2, (double)a.first_step));
     }

@@ -112,6 +112,15 @@ __device__ __forceinline__ void adam_phase(const float *st0, int stg_floats, int
                                            float *VV, bool mv_lds, float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
                                            const AdamK &a, int tid, int nthreads) {
     const float rnpn = 1.0f / (float)npn;
+    // moments in HBM (a model whose moments do not fit LDS): the next pass's are requested before this pass computes
+    float nm[2] = {0.f, 0.f}, nv[2] = {0.f, 0.f};
+    auto request = [&](int p0) {
+        if (mv_lds || p0 >= P) return;
+        const int p1 = p0 + nthreads < P ? p0 + nthreads : p0;
+        nm[0] = exp_avg[p0]; nv[0] = exp_avg_sq[p0];
+        nm[1] = exp_avg[p1]; nv[1] = exp_avg_sq[p1];
+    };
+    request(tid);
     for (int p0 = tid; p0 < P; p0 += 2 * nthreads) {
         const int p1 = p0 + nthreads;
         const bool two = p1 < P;
@@ -127,8 +136,9 @@ __device__ __forceinline__ void adam_phase(const float *st0, int stg_floats, int
             for (int w = 1; w < nw; ++w) g[u] += st0[(size_t)w * stg_floats + sp];
             pv[u] = PAR[pp[u]];
             if (mv_lds) { mv[u] = MM[pp[u]]; vv[u] = VV[pp[u]]; }
-            else { mv[u] = exp_avg[pp[u]]; vv[u] = exp_avg_sq[pp[u]]; }
+            else { mv[u] = nm[u]; vv[u] = nv[u]; }
         }
+        request(p0 + 2 * nthreads);
 #pragma unroll
         for (int u = 0; u < 2; ++u) adam_one(pv[u], g[u], mv[u], vv[u], a);
 #pragma unroll
@@ -140,7 +150,6 @@ __device__ __forceinline__ void adam_phase(const float *st0, int stg_floats, int
         }
     }
 }
-
 
 }  // namespace
 

@@ -3,7 +3,7 @@ import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from probaforms_amd import _hip
-L, d, c, hidden, batch, nb = 8, 2, 1, (10,), 32, 32
+L, d, c, hidden, batch, nb = [eval(v) for v in os.environ.get("SHAPE", "8;2;1;(10,);32;32").split(";")]
 n = nb * batch
 masks = torch.tensor(((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8)).cuda()
 shape = _hip.RnvpShape.make(L, d, c, hidden, "tanh", alt_masks=1)
