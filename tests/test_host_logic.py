@@ -132,6 +132,18 @@ def test_flatten_parameters_keeps_state_dict_live():
     assert not _engine.is_flat(plist, flat)
 
 
+def test_flatten_parameters_one_gather_pads_and_casts():
+    """freshly built (host) parameters are gathered and moved in one copy: reference order, float32, zero padding to a
+    multiple of four floats, every parameter a live view"""
+    ps = [torch.nn.Parameter(torch.arange(3, dtype=torch.float64).reshape(3, 1) / 7), torch.nn.Parameter(torch.tensor([0.5, -2.0]))]
+    flat = _engine.flatten_parameters(ps, "cpu")
+    assert flat.dtype == torch.float32 and flat.numel() == 8 and _engine.is_flat(ps, flat)
+    assert torch.equal(flat, torch.tensor([0.0, 1 / 7, 2 / 7, 0.5, -2.0, 0.0, 0.0, 0.0], dtype=torch.float32))
+    assert ps[0].shape == (3, 1) and ps[1].shape == (2,)
+    flat[3] = 9.0
+    assert float(ps[1][0]) == 9.0
+
+
 def test_install_as_probaforms_import_path():
     """drop-in name: after install_as_probaforms() the reference's import line resolves to the build"""
     import subprocess, sys
