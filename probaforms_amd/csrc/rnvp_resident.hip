@@ -18,9 +18,11 @@
 // that does not depend on the data -- gather offsets, padding masks, stage offsets, mask bits -- is computed once per
 // launch, the next layer's weight fragments are requested while the current layer computes, and (up to four waves) the
 // forward keeps the hidden activations for the backward.  Measured (scripts/resident_time.py, profiles/r03_resident_time.txt):
-// 15 us per step for the defaults against 41.
-// This file: ONE hidden layer (one or two tiles).  Two or three hidden layers: rnvp_resident_deep.hip; the conditional VAE:
-// cvae_resident.hip.
+// 15 us per step for the defaults against 41 -- and 10.8 in the net-split form that takes batches of at most 32 rows
+// (rnvp_resident_ns.hip: a wave per row tile AND net, weight gradients on helper waves).
+// This file: ONE hidden layer (one or two tiles), one wave per row tile -- batches of 33 to 128 rows, and smaller ones whose
+// records do not fit the net-split form's LDS plan.  Two or three hidden layers: rnvp_resident_deep.hip; the conditional
+// VAE: cvae_resident.hip.
 // Same arithmetic per element as the other kernel families (tanh through exp2 / rcp, torch.optim.Adam as separately
 // rounded operations); the summation ORDER over rows and hidden units differs, so results agree with them to rounding,
 // not bit for bit -- run to run this path is bit-reproducible.

@@ -1,6 +1,7 @@
 // rnvp_resident_dev.h -- device helpers, plans and launch arguments shared by the resident-fit translation units
-// (rnvp_resident.hip: one hidden layer; rnvp_resident_deep.hip: two or three; cvae_resident.hip: the conditional VAE).
-// Split three ways so that the ~110 kernel instantiations compile in parallel.
+// (rnvp_resident.hip: one hidden layer; rnvp_resident_ns.hip: its net-split form for batches of at most 32 rows;
+// rnvp_resident_deep.hip: two or three hidden layers; cvae_resident.hip: the conditional VAE).
+// Split four ways so that the ~130 kernel instantiations compile in parallel.
 #pragma once
 #include <cmath>
 
