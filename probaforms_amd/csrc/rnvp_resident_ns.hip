@@ -9,8 +9,10 @@
 //     workgroup barrier per meeting is enough; what does not depend on the partner (the next layer's weights, its saved
 //     activations, e^s, tanh') is placed between posting and the barrier;
 //   * the weight gradients feed nothing inside a step: the chain only LEAVES their operands -- net input, output gradient,
-//     hidden activations, pre-activation gradient -- as transposed tiles in LDS (a ring of three per-layer records), and
-//     waves 4-7 contract them over the rows one layer behind the chain, one (tile, net) each, between the same barriers.
+//     hidden activations, pre-activation gradient -- as transposed tiles in LDS (two per-layer records, used in turn), and
+//     waves 4-7 contract them over the rows one layer behind the chain, between the same barriers: each takes one net and
+//     one of its two contractions over BOTH row tiles (summed inside the MFMA accumulators, tile 0 first), so there is one
+//     gradient stage however many tiles a batch has.
 // The Adam scalars of a step (double precision division and square root) are computed by one of those waves while the
 // chain runs its forward; all eight share the Adam phase.  Products with padding (the fourth slot of a hidden tile of at
 // most 12 units, the second k-step of an input of at most 3 columns) are exact zeros and are not issued.
@@ -23,12 +25,12 @@ namespace resident {
 namespace {
 
 constexpr int kNsWaves = 8, kNsThreads = 64 * kNsWaves;      // waves 0-3: (tile, net) chains; 4-7: weight gradients; all: Adam
-constexpr int kNsSlots = 3;                                  // ring of the backward's per-layer records
+constexpr int kNsSlots = 2;                                  // the backward's per-layer records: the chain fills one, the helpers read the other
 
 struct NsPlan {
     int W, P, mv_lds;                                  // row tiles, parameters, moments in LDS
     int stg_net, stg_floats;
-    int oPAR, oM, oV, oSTG, oRED, oADK, oEX, oFW, oBW, oT2;     // float offsets
+    int oPAR, oM, oV, oSTG, oDB2, oRED, oADK, oEX, oFW, oBW, oT2;     // float offsets
     int total_floats;
 };
 
@@ -64,7 +66,6 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
     float *PAR = lds + pl.oPAR, *MM = lds + pl.oM, *VV = lds + pl.oV, *RED = lds + pl.oRED;
     AdamK *ADK = reinterpret_cast<AdamK *>(lds + pl.oADK);
     const int ctile = tile < 2 ? tile : 0;                // waves 4-7 never touch the per-tile areas of the chain
-    float *STGt = lds + pl.oSTG + (size_t)ctile * pl.stg_floats;
     float *FWt = lds + pl.oFW + (size_t)ctile * L * FW_LAYER, *BWt = lds + pl.oBW + (size_t)ctile * kNsSlots * BW_SLOT;
     f4 *EX = reinterpret_cast<f4 *>(lds + pl.oEX) + (size_t)ctile * 256;               // [parity][role][lane]
     for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;
@@ -164,42 +165,64 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
         }
     };
 
-    // weight gradients of one (tile, net, layer): contractions over the tile's 16 rows of the operands the chain left in LDS
-    auto wgrad_job = [&](int jt, int jn, int jl, int sl) {
-            const float *bws = lds + pl.oBW + (size_t)(jt * kNsSlots + sl) * BW_SLOT;
-            const float *fwl = lds + pl.oFW + (size_t)(jt * L + jl) * FW_LAYER;
-            float *stg = lds + pl.oSTG + (size_t)jt * pl.stg_floats + (size_t)(2 * jl + jn) * pl.stg_net;
-            float inT[NIT][4], goT[4];
+    // weight gradients of one net of one layer, summed over the batch's row tiles inside the MFMA accumulators (tile 0's rows
+    // first: a fixed order) and written to the ONE stage: d W2 (+ d b2, the two tiles' DPP row sums added) and / or d W1 (+ d b1)
+    auto wgrad_tiles = [&](int jn, int jl, int sl, auto parts_tag, auto ntiles_tag) {
+        constexpr int NTL = decltype(ntiles_tag)::value;      // row tiles: all operands are requested before the first product
+        constexpr bool do_w2 = (decltype(parts_tag)::value & 1) != 0, do_w1 = (decltype(parts_tag)::value & 2) != 0;
+        float *stg = lds + pl.oSTG + (size_t)(2 * jl + jn) * pl.stg_net;
+        if (do_w2 && lane < 16 && lane < d) {      // d b2: the tiles' DPP row sums
+            const float *db = lds + pl.oDB2 + (2 * jl + jn) * 16 + lane;
+            stg[b1o + lane] = NTL > 1 ? db[0] + db[2 * 16 * L] : db[0];
+        }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                inT[0][ks] = bws[tgI + 4 * ks];
-                if (NIT > 1) inT[NIT - 1][ks] = lds[pl.oT2 + jt * HT + tgH + 4 * ks];
-                goT[ks] = bws[oGO + jn * RGO * TS + tgG + 4 * ks];
+        for (int m = 0; m < MT; ++m) {
+            f4 dw2 = f4{0.f, 0.f, 0.f, 0.f}, dw1[NIT];
+#pragma unroll
+            for (int nt = 0; nt < NIT; ++nt) dw1[nt] = f4{0.f, 0.f, 0.f, 0.f};
+            float goT[NTL][4], hT[NTL][4], inT[NTL][NIT][4], gpT[NTL][4];
+#pragma unroll
+            for (int jt = 0; jt < NTL; ++jt) {
+                const float *bws = lds + pl.oBW + (size_t)(jt * kNsSlots + sl) * BW_SLOT;
+                const float *fwl = lds + pl.oFW + (size_t)(jt * L + jl) * FW_LAYER;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (do_w2) {
+                        goT[jt][ks] = bws[oGO + jn * RGO * TS + tgG + 4 * ks];
+                        hT[jt][ks] = fwl[2 * XF + (jn * MT + m) * HT + tgH + 4 * ks];
+                    }
+                    if (do_w1) {
+                        inT[jt][0][ks] = bws[tgI + 4 * ks];
+                        if (NIT > 1) inT[jt][NIT - 1][ks] = lds[pl.oT2 + jt * HT + tgH + 4 * ks];
+                        gpT[jt][ks] = bws[oGP + (jn * MT + m) * HT + tgH + 4 * ks];
+                    }
+                }
             }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float hT[4], gpT[4];
+            for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    hT[ks] = fwl[2 * XF + (jn * MT + m) * HT + tgH + 4 * ks];
-                    gpT[ks] = bws[oGP + (jn * MT + m) * HT + tgH + 4 * ks];
-                }
-                f4 dw2 = f4{0.f, 0.f, 0.f, 0.f}, dw1[NIT];
+                    if (do_w2) dw2 = mfma16(goT[jt][ks], hT[jt][ks], dw2);                             // [out feature 4q+e][hidden 16m + i]
+                    if (do_w1) {
 #pragma unroll
-                for (int nt = 0; nt < NIT; ++nt) dw1[nt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    dw2 = mfma16(goT[ks], hT[ks], dw2);                                   // [out feature 4q+e][hidden 16m + i]
-#pragma unroll
-                    for (int nt = 0; nt < NIT; ++nt) dw1[nt] = mfma16(gpT[ks], inT[nt][ks], dw1[nt]);   // [hidden 16m + 4q+e][input 16nt + i]
+                        for (int nt = 0; nt < NIT; ++nt) dw1[nt] = mfma16(gpT[jt][ks], inT[jt][nt][ks], dw1[nt]);   // [hidden 16m + 4q+e][input 16nt + i]
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    stg[sS2[m][e]] = dw2[e];
+            for (int e = 0; e < 4; ++e) {
+                if (do_w2) stg[sS2[m][e]] = dw2[e];
+                if (do_w1) {
 #pragma unroll
                     for (int nt = 0; nt < NIT; ++nt) stg[sS1[m][nt][e]] = dw1[nt][e];
                 }
             }
+        }
+    };
+    // two row tiles: a helper takes one contraction of a net over both tiles; one tile: both contractions of a net
+    auto wgrad_job = [&](int jn, int jl, int sl, bool second, int ntiles) {
+        if (ntiles == 1) wgrad_tiles(jn, jl, sl, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+        else if (!second) wgrad_tiles(jn, jl, sl, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        else wgrad_tiles(jn, jl, sl, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
     };
 
     int meetings = 0;                                     // parity of the pair's exchange buffer
@@ -311,8 +334,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
         // ---- backward: this wave's net; the gradient at the layer input by both waves.  What a layer needs besides the
         // incoming gradient is prepared a layer ahead (pre), behind the posting of the previous meeting ----
         struct Pre { f4 x, es, dh[MT]; };
-        auto pre = [&](int l, int slot, Pre &p) {
-            const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
+        auto pre = [&](int l, Pre &p) {
             const float *fwl = FWt + (size_t)l * FW_LAYER;
             p.x = f4{0.f, 0.f, 0.f, 0.f}; p.es = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -323,24 +345,17 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
 #pragma unroll
                 for (int e = 0; e < 4; ++e) p.dh[m][e] = (e == 3 && h3) ? 0.f : dactf<ACT>(Hm[4 * e * TS]) * hm[m][e];
             }
-            if (role == 0) {                              // the input tile of both nets' weight gradients
-                float *TIN = BWt + (size_t)slot * BW_SLOT + tp;
-#pragma unroll
-                for (int e = 0; e < KE; ++e) {
-                    if (e == 1 && k1) continue;                                         // (zeros, as initialised)
-                    const float v = (e < DT && ((mb >> e) & 1u)) ? p.x[e < DT ? e : 0] + cinT0[e] : cinT0[e];
-                    TIN[4 * e * TS] = v;
-                }
-            }
         };
         BwdW bw;
         Pre cur;
-        if (active) { load_bwd(L - 1, bw); pre(L - 1, 0, cur); }
-        // waves 4-7: the weight gradients of the layer the chain has just left, one (tile, net) each, on the SIMDs the chain
-        // leaves idle (a one-tile batch: waves 6 and 7, next to the idle waves 2 and 3)
-        const int hj = wave < 4 ? 4 : (nw == 1 ? (wave - 4) ^ 2 : wave - 4);
-        const bool helper = hj < 2 * nw;
-        int slot = 0, pslot = 0;                          // ring of kNsSlots records: the helpers read one, the chain fills the next two
+        if (active) { load_bwd(L - 1, bw); pre(L - 1, cur); }
+        // waves 4-7: the weight gradients of the layer the chain has just left, on the SIMDs the chain leaves idle.  Two row
+        // tiles: wave 4 + j takes net j & 1, d W2 (j < 2) or d W1 (j >= 2) over both tiles; one tile: waves 6 and 7 (next to the
+        // idle waves 2 and 3) take a net each, both contractions
+        const bool helper = wave >= 4 && (nw > 1 || wave >= 6);
+        const int hnet = wave & 1;
+        const bool hsecond = wave >= 6;
+        int slot = 0, pslot = 0;                          // the record the chain fills / the one the helpers read
         for (int l = L - 1; l >= 0; --l) {
             const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
             const int nslot = slot == kNsSlots - 1 ? 0 : slot + 1;
@@ -348,7 +363,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
             BwdW bn;
             Pre nxt;
             if (active) {
-                float *stg = STGt + (size_t)(2 * l + role) * pl.stg_net;
+                float *db2 = lds + pl.oDB2 + (size_t)((tile * 2 * L) + 2 * l + role) * 16;
                 float *bws = BWt + (size_t)slot * BW_SLOT;
                 f4 go = f4{0.f, 0.f, 0.f, 0.f};                                 // d loss / d (this net's output)
 #pragma unroll
@@ -377,7 +392,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
 #pragma unroll
                 for (int e = 0; e < DT; ++e) {                                  // d b2 (while the MFMA chain runs)
                     const float v = row16_sum(go[e]);
-                    if (r == 0 && xok[e]) stg[b1o + 4 * e + q] = v;
+                    if (r == 0 && xok[e]) db2[4 * e + q] = v;
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -387,10 +402,17 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
                         bws[oGP + (role * MT + m) * HT + tp + 4 * e * TS] = gp[m][e];
                     }
                 EX[(meetings & 1) * 128 + role * 64 + lane] = gin;
-                if (l > 0) { load_bwd(l - 1, bn); pre(l - 1, nslot, nxt); }
+                if (role == 0) {                          // the input tile of both nets' weight gradients (behind the posting)
+#pragma unroll
+                    for (int e = 0; e < KE; ++e) {
+                        if (e == 1 && k1) continue;                                     // (zeros, as initialised)
+                        bws[tp + 4 * e * TS] = (e < DT && ((mb >> e) & 1u)) ? cur.x[e < DT ? e : 0] + cinT0[e] : cinT0[e];
+                    }
+                }
+                if (l > 0) { load_bwd(l - 1, bn); pre(l - 1, nxt); }
             } else if (helper && l < L - 1) {
 #ifndef NS_NOWG
-                wgrad_job(hj >> 1, hj & 1, l + 1, pslot);
+                wgrad_job(hnet, l + 1, pslot, hsecond, nw);
 #endif
             }
             __syncthreads();
@@ -408,7 +430,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
             pslot = slot;
             slot = nslot;
         }
-        if (helper) wgrad_job(hj >> 1, hj & 1, 0, pslot);
+        if (helper) wgrad_job(hnet, 0, pslot, hsecond, nw);
         __syncthreads();
 #ifdef RC_STAMP
         __builtin_amdgcn_sched_barrier(0); ts2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +438,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
 #endif
         {
             const AdamK a = *ADK;
-            adam_phase(lds + pl.oSTG, pl.stg_floats, pl.stg_net, npn, P, nw, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
+            adam_phase(lds + pl.oSTG, pl.stg_floats, pl.stg_net, npn, P, 1, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
             if (tid == 0) {
                 float acc = 0.f;
                 for (int w = 0; w < nw; ++w) acc += RED[w];
@@ -456,7 +478,8 @@ bool make_ns_plan(const KShape &k, int64_t batch, NsPlan *out) {
         p.oPAR = f; f += p.P;
         p.oM = f; p.oV = f;
         if (mv) { p.oM = f; f += p.P; p.oV = f; f += p.P; }
-        p.oSTG = f; f += p.W * p.stg_floats;
+        p.oSTG = f; f += p.stg_floats;                   // ONE stage: the row tiles are summed inside the weight-gradient jobs
+        p.oDB2 = f; f += p.W * 2 * k.L * 16;             // the chain's d b2 row sums per (tile, net, feature)
         p.oRED = f; f += kMaxWaves;
         p.oADK = f; f += 8;
         f = (f + 3) & ~3;
