@@ -282,7 +282,7 @@ int rnvp_fit_epochs(void *stream, const rnvp_shape *shape,
  * rnvp_resident.hip): one hidden layer of at most 16 units (at most 32 while d + cdim <= 15) or two or three of at most 32
  * each, d <= 16, d + cdim <= 31, at most 16 layers, batch_size <= 128, and the model with its per-wave gradient stages inside one CU's 160 KB of LDS -- the
  * reference's default network (hidden=(10,), 8 layers, batch_size=32: realnvp.py:161-176).  Parameters stay in LDS for
- * the whole epoch, a step is a register-to-register MFMA chain per 16-row wave -- at batch_size <= 32 per wave pair, one
+ * the whole epoch, a step is a register-to-register MFMA chain per 16-row wave -- at batch_size <= 64 per wave pair, one
  * wave per net, with the weight gradients on helper waves (rnvp_resident_ns.hip) -- and Adam runs in place: 10.8 us per step
  * instead of 41 for the defaults.  The result agrees with the batch-by-batch loop to rounding (another summation order)
  * and reproduces itself bit for bit.  0: the loop of rnvp_train_step described above.  family == RNVP_FAMILY_VALU pins

@@ -18,9 +18,9 @@
 // that does not depend on the data -- gather offsets, padding masks, stage offsets, mask bits -- is computed once per
 // launch, the next layer's weight fragments are requested while the current layer computes, and (up to four waves) the
 // forward keeps the hidden activations for the backward.  Measured (scripts/resident_time.py, profiles/r03_resident_time.txt):
-// 15 us per step for the defaults against 41 -- and 10.8 in the net-split form that takes batches of at most 32 rows
+// 15 us per step for the defaults against 41 -- and 10.8 in the net-split form that takes batches of at most 64 rows
 // (rnvp_resident_ns.hip: a wave per row tile AND net, weight gradients on helper waves).
-// This file: ONE hidden layer (one or two tiles), one wave per row tile -- batches of 33 to 128 rows, and smaller ones whose
+// This file: ONE hidden layer (one or two tiles), one wave per row tile -- batches of 65 to 128 rows, and smaller ones whose
 // records do not fit the net-split form's LDS plan.  Two or three hidden layers: rnvp_resident_deep.hip; the conditional
 // VAE: cvae_resident.hip.
 // Same arithmetic per element as the other kernel families (tanh through exp2 / rcp, torch.optim.Adam as separately
@@ -552,7 +552,7 @@ int fit_epoch(hipStream_t st, const KShape &k, float *params, const uint8_t *mas
     const EpochArgs a{params, masks, x, c, perm, n, batch_size, n_epochs, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
                       first_step};
 #ifndef RNVP_NO_NS
-    if (ns_applies(k, batch_size)) return launch_ns(st, k, a);                    // <= 32 rows: a wave per (row tile, net)
+    if (ns_applies(k, batch_size)) return launch_ns(st, k, a);                    // <= 64 rows: a wave per (row tile, net)
 #endif
     if (make_rc_plan(k, batch_size, &rcp)) {
         if (k.nh > 1) return launch_deep(st, k, rcp, a);

@@ -1,5 +1,5 @@
 // rnvp_resident_dev.h -- device helpers, plans and launch arguments shared by the resident-fit translation units
-// (rnvp_resident.hip: one hidden layer; rnvp_resident_ns.hip: its net-split form for batches of at most 32 rows;
+// (rnvp_resident.hip: one hidden layer; rnvp_resident_ns.hip: its net-split form for batches of at most 64 rows;
 // rnvp_resident_deep.hip: two or three hidden layers; cvae_resident.hip: the conditional VAE).
 // Split four ways so that the ~130 kernel instantiations compile in parallel.
 #pragma once
@@ -158,7 +158,7 @@ __device__ __forceinline__ void adam_phase(const float *st0, int stg_floats, int
 inline int rc_kit(const KShape &k) { const int ki = (k.d + k.c + 1 + 3) / 4; return ki <= 2 ? 2 : (ki <= 4 ? 4 : 8); }
 // rnvp_resident_deep.hip: nh = 2 or 3
 int launch_deep(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArgs &a);
-// rnvp_resident_ns.hip: nh = 1, batches of at most 32 rows, a wave per (row tile, net)
+// rnvp_resident_ns.hip: nh = 1, batches of at most 64 rows, a wave per (row tile, net)
 bool ns_applies(const KShape &k, int64_t batch);
 int launch_ns(hipStream_t st, const KShape &k, const EpochArgs &a);
 

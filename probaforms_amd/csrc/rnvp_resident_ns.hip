@@ -1,7 +1,7 @@
-// rnvp_resident_ns.hip -- resident fit (rnvp_resident.hip), net-split form for batches of at most 32 rows (the reference's default).
+// rnvp_resident_ns.hip -- resident fit (rnvp_resident.hip), net-split form for batches of at most 64 rows (the reference's default: 32).
 //
 // A resident step is a chain of small dependent GEMMs, and at batch 32 the one-wave-per-tile kernel leaves most of a CU
-// idle.  Here a step is cut along the two lines the algorithm offers (8 waves):
+// idle.  Here a step is cut along the two lines the algorithm offers (8 waves; described for up to two row tiles):
 //   * the two nets of a coupling layer are independent: every 16-row tile gets a PAIR of waves, wave 2t walks the t nets
 //     of tile t, wave 2t+1 its s nets; both keep the tile's x, condition and gradient.  Per layer the pair meets twice
 //     through LDS -- the forward exchanges the nets' outputs (both waves then apply the coupling), the backward the nets'
@@ -13,6 +13,9 @@
 //     waves 4-7 contract them over the rows one layer behind the chain, between the same barriers: each takes one net and
 //     one of its two contractions over BOTH row tiles (summed inside the MFMA accumulators, tile 0 first), so there is one
 //     gradient stage however many tiles a batch has.
+// Batches of 33 to 64 rows (three or four row tiles) use all eight waves for the chain; every wave then takes one
+// weight-gradient job (net, contraction, pair of tiles) behind its own posting, and the two pairs' stages are added in the
+// Adam phase.
 // The Adam scalars of a step (double precision division and square root) are computed by one of those waves while the
 // chain runs its forward; all eight share the Adam phase.  Products with padding (the fourth slot of a hidden tile of at
 // most 12 units, the second k-step of an input of at most 3 columns) are exact zeros and are not issued.
@@ -65,7 +68,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
     const bool h3 = MT == 1 && h <= 12;                    // the fourth slot of the hidden tile (units 12-15) is padding
     float *PAR = lds + pl.oPAR, *MM = lds + pl.oM, *VV = lds + pl.oV, *RED = lds + pl.oRED;
     AdamK *ADK = reinterpret_cast<AdamK *>(lds + pl.oADK);
-    const int ctile = tile < 2 ? tile : 0;                // waves 4-7 never touch the per-tile areas of the chain
+    const int ctile = tile < pl.W ? tile : 0;             // waves without a row tile never touch the per-tile areas of the chain
     float *FWt = lds + pl.oFW + (size_t)ctile * L * FW_LAYER, *BWt = lds + pl.oBW + (size_t)ctile * kNsSlots * BW_SLOT;
     f4 *EX = reinterpret_cast<f4 *>(lds + pl.oEX) + (size_t)ctile * 256;               // [parity][role][lane]
     for (int e = tid; e < pl.total_floats; e += nthreads) lds[e] = 0.f;
@@ -75,7 +78,6 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
         if (pl.mv_lds) { MM[p] = exp_avg[p]; VV[p] = exp_avg_sq[p]; }
     }
     __syncthreads();
-    if (wave < 4) __builtin_amdgcn_s_setprio(3);          // the chain goes first where a helper wave shares its SIMD
     const float prior_c = 0.5f * (float)d * kLog2Pi;
     // perm holds n_epochs permutations of n rows back to back; every epoch is cut into the same batches (the last one ragged).
     // Batch cursors advance by increments: no 64-bit division inside the loop
@@ -167,12 +169,12 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
 
     // weight gradients of one net of one layer, summed over the batch's row tiles inside the MFMA accumulators (tile 0's rows
     // first: a fixed order) and written to the ONE stage: d W2 (+ d b2, the two tiles' DPP row sums added) and / or d W1 (+ d b1)
-    auto wgrad_tiles = [&](int jn, int jl, int sl, auto parts_tag, auto ntiles_tag) {
+    auto wgrad_tiles = [&](int jn, int jl, int sl, int t0, int stage, auto parts_tag, auto ntiles_tag) {
         constexpr int NTL = decltype(ntiles_tag)::value;      // row tiles: all operands are requested before the first product
         constexpr bool do_w2 = (decltype(parts_tag)::value & 1) != 0, do_w1 = (decltype(parts_tag)::value & 2) != 0;
-        float *stg = lds + pl.oSTG + (size_t)(2 * jl + jn) * pl.stg_net;
+        float *stg = lds + pl.oSTG + (size_t)stage * pl.stg_floats + (size_t)(2 * jl + jn) * pl.stg_net;
         if (do_w2 && lane < 16 && lane < d) {      // d b2: the tiles' DPP row sums
-            const float *db = lds + pl.oDB2 + (2 * jl + jn) * 16 + lane;
+            const float *db = lds + pl.oDB2 + ((t0 * 2 * L) + 2 * jl + jn) * 16 + lane;
             stg[b1o + lane] = NTL > 1 ? db[0] + db[2 * 16 * L] : db[0];
         }
 #pragma unroll
@@ -183,8 +185,8 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
             float goT[NTL][4], hT[NTL][4], inT[NTL][NIT][4], gpT[NTL][4];
 #pragma unroll
             for (int jt = 0; jt < NTL; ++jt) {
-                const float *bws = lds + pl.oBW + (size_t)(jt * kNsSlots + sl) * BW_SLOT;
-                const float *fwl = lds + pl.oFW + (size_t)(jt * L + jl) * FW_LAYER;
+                const float *bws = lds + pl.oBW + (size_t)((t0 + jt) * kNsSlots + sl) * BW_SLOT;
+                const float *fwl = lds + pl.oFW + (size_t)((t0 + jt) * L + jl) * FW_LAYER;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     if (do_w2) {
@@ -193,7 +195,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
                     }
                     if (do_w1) {
                         inT[jt][0][ks] = bws[tgI + 4 * ks];
-                        if (NIT > 1) inT[jt][NIT - 1][ks] = lds[pl.oT2 + jt * HT + tgH + 4 * ks];
+                        if (NIT > 1) inT[jt][NIT - 1][ks] = lds[pl.oT2 + (t0 + jt) * HT + tgH + 4 * ks];
                         gpT[jt][ks] = bws[oGP + (jn * MT + m) * HT + tgH + 4 * ks];
                     }
                 }
@@ -218,11 +220,12 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
             }
         }
     };
-    // two row tiles: a helper takes one contraction of a net over both tiles; one tile: both contractions of a net
-    auto wgrad_job = [&](int jn, int jl, int sl, bool second, int ntiles) {
-        if (ntiles == 1) wgrad_tiles(jn, jl, sl, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
-        else if (!second) wgrad_tiles(jn, jl, sl, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
-        else wgrad_tiles(jn, jl, sl, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    // parts: 1 = d W2 (+ d b2), 2 = d W1 (+ d b1), 3 = both; over ntiles (1 or 2) row tiles from tile t0, into stage `stage`
+    auto wgrad_job = [&](int jn, int jl, int sl, int parts, int ntiles, int t0, int stage) {
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if (parts == 3) wgrad_tiles(jn, jl, sl, t0, stage, I3{}, I1{});
+        else if (parts == 1) { if (ntiles > 1) wgrad_tiles(jn, jl, sl, t0, stage, I1{}, I2{}); else wgrad_tiles(jn, jl, sl, t0, stage, I1{}, I1{}); }
+        else { if (ntiles > 1) wgrad_tiles(jn, jl, sl, t0, stage, I2{}, I2{}); else wgrad_tiles(jn, jl, sl, t0, stage, I2{}, I1{}); }
     };
 
     int meetings = 0;                                     // parity of the pair's exchange buffer
@@ -349,12 +352,17 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
         BwdW bw;
         Pre cur;
         if (active) { load_bwd(L - 1, bw); pre(L - 1, cur); }
-        // waves 4-7: the weight gradients of the layer the chain has just left, on the SIMDs the chain leaves idle.  Two row
-        // tiles: wave 4 + j takes net j & 1, d W2 (j < 2) or d W1 (j >= 2) over both tiles; one tile: waves 6 and 7 (next to the
-        // idle waves 2 and 3) take a net each, both contractions
-        const bool helper = wave >= 4 && (nw > 1 || wave >= 6);
-        const int hnet = wave & 1;
-        const bool hsecond = wave >= 6;
+        // The weight gradients of the layer the chain has just left.  Up to two row tiles: on waves 4-7, the SIMDs' second
+        // waves -- two tiles: wave 4 + j takes net j & 1, d W2 (j < 2) or d W1 (j >= 2) over both tiles; one tile: waves 6 and 7
+        // (next to the idle waves 2 and 3) take a net each, both contractions.  Three or four row tiles: all eight waves walk
+        // the chain (waves 4-7: tiles 2 and 3) and every wave takes one job behind its own posting: net, contraction, tile pair
+        // (the pairs' sums go to two stages, added in the Adam phase).
+        const bool wide = nw > 2;
+        const bool has_job = wide || (wave >= 4 && (nw > 1 || wave >= 6));
+        const int jnet = wave & 1;
+        const int jparts = wide ? 1 + ((wave >> 1) & 1) : (nw == 1 ? 3 : (wave >= 6 ? 2 : 1));
+        const int jt0 = wide ? 2 * (wave >> 2) : 0, jstage = wide ? wave >> 2 : 0;
+        const int jtiles = wide ? (nw - jt0 < 2 ? nw - jt0 : 2) : nw;
         int slot = 0, pslot = 0;                          // the record the chain fills / the one the helpers read
         for (int l = L - 1; l >= 0; --l) {
             const uint32_t mb = (uint32_t)(mbits >> (4 * l)) & 15u;
@@ -410,11 +418,8 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
                     }
                 }
                 if (l > 0) { load_bwd(l - 1, bn); pre(l - 1, nxt); }
-            } else if (helper && l < L - 1) {
-#ifndef NS_NOWG
-                wgrad_job(hnet, l + 1, pslot, hsecond, nw);
-#endif
             }
+            if (has_job && l < L - 1) wgrad_job(jnet, l + 1, pslot, jparts, jtiles, jt0, jstage);
             __syncthreads();
             if (active) {
                 const f4 gother = EX[(meetings & 1) * 128 + (1 - role) * 64 + lane];
@@ -430,7 +435,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
             pslot = slot;
             slot = nslot;
         }
-        if (helper) wgrad_job(hnet, 0, pslot, hsecond, nw);
+        if (has_job) wgrad_job(jnet, 0, pslot, jparts, jtiles, jt0, jstage);
         __syncthreads();
 #ifdef RC_STAMP
         __builtin_amdgcn_sched_barrier(0); ts2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
@@ -438,7 +443,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
 #endif
         {
             const AdamK a = *ADK;
-            adam_phase(lds + pl.oSTG, pl.stg_floats, pl.stg_net, npn, P, 1, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
+            adam_phase(lds + pl.oSTG, pl.stg_floats, pl.stg_net, npn, P, wide ? 2 : 1, PAR, MM, VV, pl.mv_lds != 0, exp_avg, exp_avg_sq, a, tid, nthreads);
             if (tid == 0) {
                 float acc = 0.f;
                 for (int w = 0; w < nw; ++w) acc += RED[w];
@@ -461,9 +466,9 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
     }
 }
 
-// plan: two row tiles at most (batch <= 32), one hidden layer; false when the form does not apply or its records do not fit LDS
+// plan: four row tiles at most (batch <= 64), one hidden layer; false when the form does not apply or its records do not fit LDS
 bool make_ns_plan(const KShape &k, int64_t batch, NsPlan *out) {
-    if (k.nh != 1 || batch < 1 || batch > 32) return false;
+    if (k.nh != 1 || batch < 1 || batch > 64) return false;
     if (k.d > 16 || k.d + k.c > 31 || k.L > 16 || k.nout[0] > 32 || (k.nout[0] > 16 && rc_kit(k) > 4)) return false;
     NsPlan p;
     std::memset(&p, 0, sizeof(p));
@@ -478,7 +483,7 @@ bool make_ns_plan(const KShape &k, int64_t batch, NsPlan *out) {
         p.oPAR = f; f += p.P;
         p.oM = f; p.oV = f;
         if (mv) { p.oM = f; f += p.P; p.oV = f; f += p.P; }
-        p.oSTG = f; f += p.stg_floats;                   // ONE stage: the row tiles are summed inside the weight-gradient jobs
+        p.oSTG = f; f += (p.W > 2 ? 2 : 1) * p.stg_floats;      // one stage per PAIR of row tiles: a pair is summed inside the weight-gradient jobs
         p.oDB2 = f; f += p.W * 2 * k.L * 16;             // the chain's d b2 row sums per (tile, net, feature)
         p.oRED = f; f += kMaxWaves;
         p.oADK = f; f += 8;

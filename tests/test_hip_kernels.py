@@ -882,6 +882,8 @@ RESIDENT_CASES = [
     (4, 8, 3, (16,), "relu", 96, 32, 0.1, True),              # net-split form (rnvp_resident_ns.hip): a full hidden tile, 12 input columns
     (3, 4, 2, (12,), "tanh", 60, 17, 0.0, False),             # its second row tile holds one row; the widest trimmed hidden tile
     (8, 2, 1, (32,), "tanh", 64, 32, 0.0, False),             # two hidden tiles on a one-k-step input
+    (4, 3, 1, (10,), "tanh", 100, 40, 0.1, False),            # three row tiles (all eight waves walk the chain), then a two-tile batch
+    (8, 2, 1, (10,), "relu", 200, 64, 0.0, True),             # four row tiles, user masks, a ragged one-tile batch at the end
 ]
 
 
