@@ -955,7 +955,8 @@ def test_resident_fit_epoch_vs_step_loop(L, d, c, hidden, act, n, batch, wd, use
     assert np.abs(pr - p0).max() > 1e-3            # it did train
 
 
-@pytest.mark.parametrize("L,d,c,hidden,batch", [(8, 2, 1, (10,), 32), (4, 5, 3, (10, 12), 25), (2, 16, 4, (128,), 64)])
+@pytest.mark.parametrize("L,d,c,hidden,batch", [(8, 2, 1, (10,), 32), (4, 5, 3, (10, 12), 25), (2, 16, 4, (128,), 64),
+                                                   (4, 2, 1, (10,), 48), (3, 8, 7, (16,), 32)])
 def test_fit_epochs_equals_consecutive_fit_epoch_calls(L, d, c, hidden, batch):
     """rnvp_fit_epochs (several epochs, one library call; one persistent launch where the model is LDS-resident) walks
     exactly the trajectory of one rnvp_fit_epoch call per epoch, bit for bit, on the resident kernels and on the loop"""
