@@ -40,14 +40,16 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     if (s->alt_masks < 0 || s->alt_masks > 2) return RNVP_EINVAL;
     k->alt = s->alt_masks;
     if (s->precision < RNVP_PREC_AUTO || s->precision > RNVP_PREC_BX3) return RNVP_EINVAL;
-    // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) --
-    // measured 1.3-1.4x there; the d <= 16 geometry gains nothing from it and keeps the f32 kernels
+    // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) -- measured
+    // 1.3-1.4x there -- and in the d <= 16 geometry from seven hidden tiles on (hidden > 96: 3-7 % on every operation; at 96 the
+    // flows lose 2 %, at 32 19 %: scripts/bench_kernels.py with PREC=f32 / bx3, profiles/r03_precision_auto.txt)
     if (s->small_calls != RNVP_SMALL_INVARIANT && s->small_calls != RNVP_SMALL_LATENCY) return RNVP_EINVAL;
     k->small_latency = s->small_calls == RNVP_SMALL_LATENCY;
     if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM) return RNVP_EINVAL;
     k->family = s->family;
     k->prec_auto = s->precision == RNVP_PREC_AUTO;
-    k->prec = s->precision == RNVP_PREC_AUTO ? ((s->d > 16 || s->c > 4) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
+    k->prec = s->precision == RNVP_PREC_AUTO ? ((s->d > 16 || s->c > 4 || (s->n_hidden == 1 && s->hidden[0] > 96)) ? RNVP_PREC_BX3 : RNVP_PREC_F32)
+                                              : s->precision;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;
     for (int i = 0; i <= s->n_hidden; ++i) {

@@ -21,7 +21,7 @@ def main():
     which = sys.argv[1:] or list(CONFIGS)
     ops = os.environ.get("OPS", "fwd,inv,train").split(",")
     for name in which:
-        L, d, c, h = CONFIGS[name]
+        L, d, c, h = CONFIGS[name] if name in CONFIGS else tuple(int(v) for v in name.split(","))      # or "L,d,c,h"
         n = int(os.environ.get("N", 1 << 20))
         shape = _hip.RnvpShape.make(L, d, c, (h,), os.environ.get("ACT", "tanh"), alt_masks=1, precision=os.environ.get("PREC") or None,
                                     small_calls=_hip.SMALL_CALLS[os.environ.get("SMALL", "invariant")])
