@@ -98,6 +98,16 @@ def make_data(n, d, c, seed):
     return X.astype(np.float32), C.astype(np.float32)
 
 
+def train_mixed_bound_seconds_per_row(d, c, hidden, L):
+    """roofline time per row of a training step whose FORWARD GEMM1 runs on split-bf16 MFMA (the backward, incl. its GEMM1
+    recompute, and GEMM2 stay on f32 MFMA): the forward GEMM1's useful flops on the six-product bf16 form, the other
+    3 F - that on the f32 peak"""
+    h = hidden[0]
+    g1 = 4 * h * (d / 2 + c) * L
+    rest = 3 * 4 * h * (d + c) * L - g1
+    return g1 / (BX3_EFFECTIVE_TFLOPS * 1e12) + rest / (F32_MFMA_PEAK_TFLOPS * 1e12)
+
+
 def useful_flops_per_row(d, c, hidden, L, passes):
     """F_useful = 4 h (d + c) per row per layer (dead masked lanes removed)"""
     return 4 * hidden[0] * (d + c) * L * passes
@@ -387,7 +397,7 @@ def secondary_c3_c4(dev):
         res = {"workload": "%s: d=%d cond=%d L=%d hidden=%r, one GPU" % (w["label"], d, c, L, hidden)}
         _hip.profile_enable(64)
 
-        def timed(kind, fn, reps, rows, passes, bx3):
+        def timed(kind, fn, reps, rows, passes):
             for _ in range(2):
                 fn()
             torch.cuda.synchronize(dev)
@@ -402,8 +412,11 @@ def secondary_c3_c4(dev):
             r = {"rows": rows, "ms_per_call": e0.elapsed_time(e1) / reps, "kernel_ms": kms,
                  "rows_per_s": rows / (e0.elapsed_time(e1) / reps * 1e-3), "useful_flop_per_row": passes * f1,
                  "roofline_frac_f32_mfma": passes * f1 * rows / (kms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
-            if bx3:
-                r["roofline_frac_mixed_bound"] = mixed_bound_seconds_per_row(d, c, hidden, L, passes) * rows / (kms * 1e-3)
+            r["dispatch"] = _hip.last_dispatch(kind)
+            if r["dispatch"]["gemm1_fwd"] == "bx3":     # priced against the bound of what ran as well
+                bound = (train_mixed_bound_seconds_per_row(d, c, hidden, L) if kind == _hip.PROFILE_TRAIN
+                         else mixed_bound_seconds_per_row(d, c, hidden, L, passes))
+                r["roofline_frac_mixed_bound"] = bound * rows / (kms * 1e-3)
             return r
 
         if w["fit"]:
@@ -411,9 +424,9 @@ def secondary_c3_c4(dev):
             idx = torch.randperm(n, device=dev, generator=gen)[:BATCH].contiguous()
             loss = torch.zeros(1, device=dev)
             res["train_step_65536_rows"] = timed(_hip.PROFILE_TRAIN,
-                                                  lambda: eng.train_step(opt, X, C, idx, BATCH, 1.0 / BATCH, loss), 10, BATCH, 3, False)
-            res["log_prob_1M_rows"] = timed(_hip.PROFILE_FORWARD, lambda: eng.forward(X, C, want_z=False, want_logp=True), 5, n, 1, True)
-        res["sample_%dM_rows" % (n // 1_000_000)] = timed(_hip.PROFILE_INVERSE, lambda: eng.sample(n, C, 77, row_offset=0, out=xs), 5, n, 1, True)
+                                                  lambda: eng.train_step(opt, X, C, idx, BATCH, 1.0 / BATCH, loss), 10, BATCH, 3)
+            res["log_prob_1M_rows"] = timed(_hip.PROFILE_FORWARD, lambda: eng.forward(X, C, want_z=False, want_logp=True), 5, n, 1)
+        res["sample_%dM_rows" % (n // 1_000_000)] = timed(_hip.PROFILE_INVERSE, lambda: eng.sample(n, C, 77, row_offset=0, out=xs), 5, n, 1)
         _hip.profile_enable(0)
         out[key] = res
         del X, C, xs, nf, eng
@@ -575,6 +588,10 @@ def main():
 
     n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
     n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
+    # what the library launched for the timed region's last batch / sampling call (rnvp_last_dispatch: written by the launch
+    # sites themselves): the kernel names, variants and arithmetic below are the library's statement, not a copy of its rules
+    disp_train = _hip.last_dispatch(_hip.PROFILE_TRAIN) if do_fit else None
+    disp_inv = _hip.last_dispatch(_hip.PROFILE_INVERSE) if do_sample else None
     assert n_train == args.steps * nb and n_inv == args.steps * (1 if do_sample else 0), (n_train, n_inv, args.steps)
     final_loss = float(losses[n_steps - 1, nb - 1].item()) if do_fit else None
     assert final_loss is None or np.isfinite(final_loss), "training diverged"
@@ -589,6 +606,7 @@ def main():
             eng.forward(X, C, want_z=False, want_logp=True)
         torch.cuda.synchronize()
         n_fwd, fwd_ms = _hip.profile_read(_hip.PROFILE_FORWARD)
+        disp_fwd = _hip.last_dispatch(_hip.PROFILE_FORWARD)
     _hip.profile_enable(0)
 
     if rank == 0:
@@ -598,23 +616,33 @@ def main():
         inv_tf = f1 * N_ROWS * args.steps / (inv_ms * 1e-3) / 1e12
         fwd_tf = f1 * N_ROWS * n_fwd / (fwd_ms * 1e-3) / 1e12
         path = _hip.kernel_path(eng.shape, eng.masks_host, _hip.OP_TRAIN)
-        kname = "k_mfma_train" if path == _hip.PATH_MFMA else "k_generic_train"
-        flow_bx3 = D > 16 or CDIM > 4                    # precision 'auto': split-bf16 GEMM1 in the forward / inverse kernels
-        flow_kernel = "k_flow_bx3" if flow_bx3 else "k_mfma_flow"
+        kname = disp_train["kernel"] if do_fit else None
+        train_bx3 = do_fit and disp_train["gemm1_fwd"] == "bx3"
+        flow_bx3 = (disp_inv or disp_fwd)["gemm1_fwd"] == "bx3"
+        flow_kernel = (disp_inv or disp_fwd)["kernel"]
+        fwd_bx3, fwd_kernel = disp_fwd["gemm1_fwd"] == "bx3", disp_fwd["kernel"]
         mixed = mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS)
         if do_fit:
             roof = {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": train_tf / F32_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("k_mfma_train<2, 1, 4") if args.workload == "c2" else
-                               (pmc_traffic("k_mfma_train_wide<4, 2", TRAFFIC_FILE_C3C4) if args.workload == "c3" else None),
-                    "kernel": "%s (fused forward+backward): %d launches in the timed region, %.3f ms avg (15 of every 16 "
-                              "on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch"
-                              % (kname, n_train, train_ms / n_train, 3 * f1, N_ROWS)}
+                    "frac_mixed_bound": (train_mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS) * N_ROWS * args.steps / (train_ms * 1e-3)
+                                         if train_bx3 else None),
+                    "traffic": pmc_traffic(kname + "<", TRAFFIC_FILE if args.workload == "c2" else TRAFFIC_FILE_C3C4),
+                    "dispatch": disp_train,
+                    "kernel": "%s (fused forward+backward; variant %s, %d row tiles per wave, %d waves per workgroup; GEMM1 of the "
+                              "forward phase on %s, everything else on f32 MFMA): %d launches in the timed region, %.3f ms avg (15 of "
+                              "every 16 on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch; %d kernel launches per "
+                              "batch; `frac` prices the useful flops against the f32 MFMA peak%s"
+                              % (kname, disp_train["variant"], disp_train["row_tiles"], disp_train["waves"],
+                                 "3-term split-bf16 MFMA (float32-level accuracy)" if train_bx3 else "f32 MFMA", n_train,
+                                 train_ms / n_train, 3 * f1, N_ROWS, disp_train["launches"],
+                                 ", `frac_mixed_bound` against the bound of what runs (forward GEMM1 as six bf16 products per f32 "
+                                 "product on the dense bf16 peak)" if train_bx3 else "")}
         else:           # sampling only (C4): the inverse kernel is the dominant one
             roof = {"bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": inv_tf / F32_MFMA_PEAK_TFLOPS,
                     # the committed PMC profile has this kernel at 1M rows per launch; scaled to this launch's rows
-                    "traffic": (lambda t: None if t is None else t * N_ROWS / 1048576.0)(pmc_traffic("k_flow_bx3<8, 4, 2, true", TRAFFIC_FILE_C3C4)),
+                    "traffic": (lambda t: None if t is None else t * N_ROWS / 1048576.0)(pmc_traffic(flow_kernel + "<", TRAFFIC_FILE_C3C4)),
                     "frac_mixed_bound": mixed * N_ROWS * args.steps / (inv_ms * 1e-3) if flow_bx3 else None,
                     "kernel": "%s inverse with the prior drawn in-kernel: %d launches of %d rows in the timed region, %.3f ms avg, "
                               "%d useful flop/row; `frac` prices it against the f32 MFMA peak, `frac_mixed_bound` against the "
@@ -626,9 +654,17 @@ def main():
         fwd_entry = {"bound": "mfma", "achieved": fwd_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fwd_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": fwd_ms / n_fwd, "rows_per_launch": N_ROWS,
                      "launches": n_fwd, "where": "after the timed region"}
-        if flow_bx3:
+        sample_entry["dispatch"], fwd_entry["dispatch"] = disp_inv, disp_fwd
+        if flow_bx3 and do_sample:
             sample_entry["frac_mixed_bound"] = mixed * N_ROWS * args.steps / (inv_ms * 1e-3)
+        if fwd_bx3:
             fwd_entry["frac_mixed_bound"] = mixed * N_ROWS * n_fwd / (fwd_ms * 1e-3)
+        gemm1_text = "3-term split-bf16 MFMA, float32-level accuracy"
+        dtype = "f32"
+        if train_bx3 or flow_bx3:
+            dtype = "f32 (first Linear of the s/t nets on %s in: %s; everything else f32)" % (
+                gemm1_text, ", ".join(t for t, on in (("the training kernel's forward phase", train_bx3), ("sampling", flow_bx3 and do_sample),
+                                                      ("log-prob", fwd_bx3)) if on))
         step_text = ("one fit epoch over the rank's %d rows (%d batches of %d incl. the ragged one: loss+grad+Adam each) + "
                      % (N_ROWS, nb, BATCH) if do_fit else "") + \
                     "sampling %d rows (counter-based prior draw inside the inverse kernel)" % N_ROWS
@@ -640,7 +676,7 @@ def main():
             "metric": "RealNVP samples/sec (fit+sample)", "value": rows_per_step * args.steps / dt,
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: RealNVP n=%d/GPU d=%d cond=%d L=%d hidden=%r; one step = %s"
                                    % (wl["label"], N_ROWS, D, CDIM, LAYERS, HIDDEN, step_text),
                        "global_batch": BATCH * world if do_fit else None, "parallelism": "dp%d" % world,
@@ -648,7 +684,7 @@ def main():
             "roofline": roof,
             "roofline_kernels": {
                 "sample (%s inverse, prior drawn in-kernel)" % flow_kernel: sample_entry,
-                "log_prob (%s forward)" % flow_kernel: fwd_entry},
+                "log_prob (%s forward)" % fwd_kernel: fwd_entry},
             "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / args.steps * 1e-3),
                                 "note": "sample: kernel time only; fit: ms_per_step minus the sampling kernels' time"},
         }

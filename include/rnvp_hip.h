@@ -100,7 +100,7 @@ typedef struct rnvp_shape {
 #define RNVP_OP_INVERSE  1
 #define RNVP_OP_TRAIN    2
 
-#define RNVP_HIP_VERSION 300     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
+#define RNVP_HIP_VERSION 400     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
                                     binding must refuse a library that reports another number                      */
 int         rnvp_version(void);
 const char *rnvp_status_string(int status);
@@ -333,6 +333,34 @@ int rnvp_fit_epoch_dp(void *stream, void *comm, const rnvp_shape *shape,
 #define RNVP_PROFILE_INVERSE 2
 int rnvp_profile_enable(int capacity);          /* capacity <= 0 disables and frees the events */
 int rnvp_profile_read(int kind, int *n_launches, float *total_ms);
+
+/*
+ * Which kernel the CALLING THREAD's most recent call of a kind (RNVP_PROFILE_TRAIN / _FORWARD / _INVERSE) launched as
+ * its hot kernel: every launch site writes this record itself, next to the launch, so it cannot drift from the
+ * dispatch rules.  Tests assert it (a later change of a threshold cannot silently move a benchmark size onto an
+ * untested kernel) and bench.py labels its JSON line from it.  Thread-local; no equivalent in the reference.
+ */
+#define RNVP_VARIANT_NONE        0
+#define RNVP_VARIANT_ROWPAR      1   /* row-parallel: 4 waves per workgroup, each with both nets of its row tiles          */
+#define RNVP_VARIANT_NETSPLIT    2   /* k_mfma_train<.., NS = 1>: 8 waves, wave pairs share row tiles, one net each        */
+#define RNVP_VARIANT_WIDE        3   /* k_mfma_train_wide: 8 row-owning waves per workgroup (d in (16, 32])                */
+#define RNVP_VARIANT_TILESPLIT   4   /* k_mfma_train_ts / k_mfma_flow_ts: the workgroup's waves split the hidden tiles     */
+#define RNVP_VARIANT_BX3_STAGED  5   /* k_flow_bx3<.., STAGED>: split-bf16 GEMM1, weights staged in LDS by LDS-DMA         */
+#define RNVP_VARIANT_BX3_DIRECT  6   /* k_flow_bx3, barrier-free form (d <= 16)                                           */
+#define RNVP_VARIANT_LMM         7   /* any-shape MFMA kernels, LDS-resident activations                                  */
+#define RNVP_VARIANT_VALU        8   /* one thread per row                                                                */
+#define RNVP_VARIANT_RESIDENT    9   /* persistent one-workgroup epoch (rnvp_resident*.hip)                               */
+typedef struct rnvp_dispatch {
+    int32_t variant;      /* RNVP_VARIANT_*                                                              */
+    int32_t row_tiles;    /* 16-row tiles per wave                                                       */
+    int32_t waves;        /* waves per workgroup                                                         */
+    int32_t grid;         /* workgroups                                                                  */
+    int32_t gemm1_fwd;    /* RNVP_PREC_F32 / RNVP_PREC_BX3: arithmetic the first Linear ran in (forward phase) */
+    int32_t launches;     /* kernel launches the whole call enqueued (pack, hot kernel, follow-ups)      */
+    int64_t rows;         /* rows of the hot launch                                                      */
+    char    kernel[48];   /* name of the hot kernel as rocprofv3 lists it (without template arguments)   */
+} rnvp_dispatch;
+int rnvp_last_dispatch(int kind, rnvp_dispatch *out);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import threading
 import torch
 
 MAX_HIDDEN = 8
-ABI_VERSION = 300          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
+ABI_VERSION = 400          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA, PATH_LMM = 0, 1, 2
@@ -76,6 +76,16 @@ class RnvpShape(C.Structure):
 
     def key(self):
         return (self.L, self.d, self.c, tuple(self.hidden[:self.n_hidden]), self.act)
+
+
+VARIANTS = {0: "none", 1: "rowpar", 2: "netsplit", 3: "wide", 4: "tilesplit", 5: "bx3_staged", 6: "bx3_direct", 7: "lmm",
+            8: "valu", 9: "resident"}
+
+
+class RnvpDispatch(C.Structure):
+    """mirror of `rnvp_dispatch` (include/rnvp_hip.h): what the calling thread's last call of a kind launched"""
+    _fields_ = [("variant", C.c_int32), ("row_tiles", C.c_int32), ("waves", C.c_int32), ("grid", C.c_int32),
+                ("gemm1_fwd", C.c_int32), ("launches", C.c_int32), ("rows", C.c_int64), ("kernel", C.c_char * 48)]
 
 
 class CvaeShape(C.Structure):
@@ -149,6 +159,7 @@ _SIGNATURES = {
     "cvae_encode": (C.c_int, [_VP, C.POINTER(CvaeShape), _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
     "rnvp_profile_enable": (C.c_int, [C.c_int]),
     "rnvp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "rnvp_last_dispatch": (C.c_int, [C.c_int, C.POINTER(RnvpDispatch)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -221,6 +232,14 @@ def profile_read(kind=PROFILE_TRAIN):
     n, ms = C.c_int(0), C.c_float(0.0)
     check(lib().rnvp_profile_read(int(kind), C.byref(n), C.byref(ms)), "rnvp_profile_read")
     return n.value, ms.value
+
+
+def last_dispatch(kind=PROFILE_TRAIN):
+    """-> dict(kernel, variant, row_tiles, waves, grid, gemm1_fwd, launches, rows) of this thread's last call of `kind`"""
+    d = RnvpDispatch()
+    check(lib().rnvp_last_dispatch(int(kind), C.byref(d)), "rnvp_last_dispatch")
+    return dict(kernel=d.kernel.decode(), variant=VARIANTS.get(d.variant, str(d.variant)), row_tiles=d.row_tiles, waves=d.waves,
+                grid=d.grid, gemm1_fwd={1: "f32", 2: "bx3"}.get(d.gemm1_fwd, "?"), launches=d.launches, rows=d.rows)
 
 
 def param_count(shape):

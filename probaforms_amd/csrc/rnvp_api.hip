@@ -50,9 +50,30 @@ KernelEvents::KernelEvents(int kind) {
         ++g_ev_used[kind];
     }
 }
+
+namespace {
+thread_local rnvp_dispatch g_last[kKinds];
+}
+void note_dispatch(int kind, const char *kernel, int variant, int row_tiles, int waves, int grid, int gemm1_fwd, int64_t rows) {
+    if (kind < 0 || kind >= kKinds) return;
+    rnvp_dispatch &d = g_last[kind];
+    d.variant = variant; d.row_tiles = row_tiles; d.waves = waves; d.grid = grid; d.gemm1_fwd = gemm1_fwd;
+    d.launches = 0; d.rows = rows;
+    std::strncpy(d.kernel, kernel, sizeof(d.kernel) - 1);
+    d.kernel[sizeof(d.kernel) - 1] = 0;
+}
+void note_launches(int kind, int launches) {
+    if (kind >= 0 && kind < kKinds) g_last[kind].launches = launches;
+}
 }  // namespace rnvp
 
 extern "C" {
+
+int rnvp_last_dispatch(int kind, rnvp_dispatch *out) {
+    if (kind < 0 || kind >= rnvp::kKinds || !out) return RNVP_EINVAL;
+    *out = rnvp::g_last[kind];
+    return RNVP_OK;
+}
 
 int rnvp_profile_enable(int capacity) {
     std::lock_guard<std::mutex> lk(rnvp::g_ev_mu);

@@ -500,6 +500,8 @@ int launch(hipStream_t st, const KShape &k, const Geo3 &g, const uint32_t *packe
     const int grid = (int)(ngroups < maxgrid ? ngroups : maxgrid);
     if (grid_out) *grid_out = grid;
     if (waves_out) *waves_out = WAVES;
+    note_dispatch(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD, "k_flow_bx3", DIRECT ? RNVP_VARIANT_BX3_DIRECT : RNVP_VARIANT_BX3_STAGED,
+                  R, WAVES, grid, RNVP_PREC_BX3, n);
     {
         const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt,

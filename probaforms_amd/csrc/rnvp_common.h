@@ -178,6 +178,10 @@ struct KernelEvents {
     explicit KernelEvents(int kind);
 };
 
+// rnvp_last_dispatch (rnvp_api.hip): every launch site of a hot kernel notes what it launched, per thread and kind
+void note_dispatch(int kind, const char *kernel, int variant, int row_tiles, int waves, int grid, int gemm1_fwd, int64_t rows);
+void note_launches(int kind, int launches);       // launches of the whole call, once known
+
 #define RNVP_HIP_TRY(expr)                         \
     do {                                           \
         hipError_t e__ = (expr);                   \

@@ -339,6 +339,7 @@ int generic_forward(hipStream_t st, const KShape &k, const float *params, const 
     int rc = allow_lds(k_generic_forward, tl.lds, g_lds_fwd);
     if (rc) return rc;
     const int G = grid_for(n, tl.TB, kMaxGrid);
+    note_dispatch(RNVP_PROFILE_FORWARD, "k_generic_forward", RNVP_VARIANT_VALU, 0, tl.threads / 64, G, RNVP_PREC_F32, n);
     hipLaunchKernelGGL(k_generic_forward, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,
                        row_index, n, z_out, logdet_out, logp_out, part, tl.TB, tl.TBP);
     RNVP_HIP_TRY(hipGetLastError());
@@ -356,6 +357,7 @@ int generic_inverse(hipStream_t st, const KShape &k, const float *params, const 
     int rc = allow_lds(k_generic_inverse, tl.lds, g_lds_inv);
     if (rc) return rc;
     const int G = grid_for(n, tl.TB, kMaxGrid);
+    note_dispatch(RNVP_PROFILE_INVERSE, "k_generic_inverse", RNVP_VARIANT_VALU, 0, tl.threads / 64, G, RNVP_PREC_F32, n);
     hipLaunchKernelGGL(k_generic_inverse, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, z, c, n,
                        x_out, tl.TB, tl.TBP);
     RNVP_HIP_TRY(hipGetLastError());
@@ -378,6 +380,7 @@ int generic_loss_grad(hipStream_t st, const KShape &k, const float *params, cons
     float *xsave = reinterpret_cast<float *>(w);
     int rc = allow_lds(k_generic_train, tl.lds, g_lds_train);
     if (rc) return rc;
+    note_dispatch(RNVP_PROFILE_TRAIN, "k_generic_train", RNVP_VARIANT_VALU, 0, tl.threads / 64, G, RNVP_PREC_F32, n);
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);      // rnvp_profile_*: brackets exactly this launch when enabled
         hipLaunchKernelGGL(k_generic_train, dim3(G), dim3(tl.threads), tl.lds, st, k, params, masks, x, c,

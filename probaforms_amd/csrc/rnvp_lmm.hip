@@ -720,6 +720,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const uint8_t 
     rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_flow<false>), 160 * 1024, g_attr_fwd);
     if (rc) return rc;
     const int G = grid_for((n + 15) / 16);
+    note_dispatch(RNVP_PROFILE_FORWARD, "k_lmm_flow", RNVP_VARIANT_LMM, 1, kW, G, RNVP_PREC_F32, n);
     hipLaunchKernelGGL(k_lmm_flow<false>, dim3(G), dim3(64 * kW), g.lds_flow, st, k, g, packed, params, masks, x, c, row_index, n,
                        z_out, logdet_out, logp_out, part);
     RNVP_HIP_TRY(hipGetLastError());
@@ -736,6 +737,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
     if (rc) return rc;
     rc = allow_big_lds(reinterpret_cast<const void *>(k_lmm_flow<true>), 160 * 1024, g_attr_inv);
     if (rc) return rc;
+    note_dispatch(RNVP_PROFILE_INVERSE, "k_lmm_flow", RNVP_VARIANT_LMM, 1, kW, grid_for((n + 15) / 16), RNVP_PREC_F32, n);
     hipLaunchKernelGGL(k_lmm_flow<true>, dim3(grid_for((n + 15) / 16)), dim3(64 * kW), g.lds_flow, st, k, g, packed, params, masks, z,
                        c, nullptr, n, x_out, nullptr, nullptr, nullptr);
     RNVP_HIP_TRY(hipGetLastError());
@@ -768,6 +770,7 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_
         const bool first = r0 == 0;
         const float *xc = row_index ? x : x + r0 * k.d;
         const float *cc = (row_index || !c) ? c : c + r0 * k.c;
+        note_dispatch(RNVP_PROFILE_TRAIN, "k_lmm_train", RNVP_VARIANT_LMM, 1, kW, G, RNVP_PREC_F32, rows);
         {
             KernelTimer timer(st, RNVP_PROFILE_TRAIN);
             hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64 * kW), g.lds_train, st, k, g, packed, params, masks, xc, cc,

@@ -353,6 +353,8 @@ int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pack
             const int grid = (int)((n + 15) / 16);
             *grid_out = grid;
             const size_t lds_bytes = (size_t)2 * kTsWaves * NF * 64 * sizeof(float);
+            note_dispatch(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD, "k_mfma_flow_ts", RNVP_VARIANT_TILESPLIT, 1, kTsWaves,
+                          grid, RNVP_PREC_F32, n);
             const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
             hipExtLaunchKernelGGL((k_mfma_flow_ts<NF, CQ, INVERSE, ACT>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start,
                                   ev.stop, 0, packed, g, k.L, k.alt, x, c, row_index, n, out_x, logdet_out, logp_out, part, seed,
@@ -373,6 +375,8 @@ int launch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pack
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const int grid = (int)(ngroups < kMaxGrid ? ngroups : kMaxGrid);
     *grid_out = grid;
+    note_dispatch(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD, "k_mfma_flow", RNVP_VARIANT_ROWPAR, R, kWaves, grid,
+                  RNVP_PREC_F32, n);
     {
         const KernelEvents ev(INVERSE ? RNVP_PROFILE_INVERSE : RNVP_PROFILE_FORWARD);
         hipExtLaunchKernelGGL((k_mfma_flow<NF, CQ, R, INVERSE, ACT>), dim3(grid), dim3(kWaves * 64), 0, st, ev.start, ev.stop, 0,

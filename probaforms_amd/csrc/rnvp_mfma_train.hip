@@ -1093,6 +1093,8 @@ int launch_train_act(hipStream_t st, const KShape &k, const Geo &g, const TrainP
     static std::atomic<uint64_t> attr_done{0};          // per kernel instance; one bit per device
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
     if (arc) return arc;
+    note_dispatch(RNVP_PROFILE_TRAIN, "k_mfma_train", NS ? RNVP_VARIANT_NETSPLIT : RNVP_VARIANT_ROWPAR, R, kWaves * (1 + NS), grid,
+                  BXF ? RNVP_PREC_BX3 : RNVP_PREC_F32, n);
     {
         const KernelEvents ev(RNVP_PROFILE_TRAIN);      // rnvp_profile_*: this launch's own start / stop stamps when enabled
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64 * (1 + NS)), lds_bytes, st, ev.start, ev.stop, 0, packed, g,
@@ -1115,6 +1117,7 @@ int launch_train_wide(hipStream_t st, const KShape &k, const Geo &g, const Train
     static std::atomic<uint64_t> attr_done{0};
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
     if (arc) return arc;
+    note_dispatch(RNVP_PROFILE_TRAIN, "k_mfma_train_wide", RNVP_VARIANT_WIDE, R, kWideWaves, grid, BXF ? RNVP_PREC_BX3 : RNVP_PREC_F32, n);
     {
         const KernelEvents ev(RNVP_PROFILE_TRAIN);
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWideWaves * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt,
@@ -1156,6 +1159,7 @@ int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
                         ? allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<NF, CQ, R, 0>), 160 * 1024, attr_done[0])
                         : allow_big_lds(reinterpret_cast<const void *>(k_mfma_train_ts<NF, CQ, R, 1>), 160 * 1024, attr_done[1]);
     if (arc) return arc;
+    note_dispatch(RNVP_PROFILE_TRAIN, "k_mfma_train_ts", RNVP_VARIANT_TILESPLIT, R, kTsWaves, grid, RNVP_PREC_F32, n);
     const KernelEvents ev(RNVP_PROFILE_TRAIN);
     if (k.act == RNVP_ACT_TANH)
         hipExtLaunchKernelGGL((k_mfma_train_ts<NF, CQ, R, 0>), dim3(grid), dim3(kTsWaves * 64), lds_bytes, st, ev.start, ev.stop, 0,
@@ -1178,6 +1182,7 @@ int launch_train_bx(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
     static std::atomic<uint64_t> attr_done{0};
     const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
     if (arc) return arc;
+    note_dispatch(RNVP_PROFILE_TRAIN, "k_mfma_train_bx", RNVP_VARIANT_ROWPAR, R, kWaves, grid, RNVP_PREC_BX3, n);
     {
         const KernelEvents ev(RNVP_PROFILE_TRAIN);
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt, x,
@@ -1357,6 +1362,7 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, lay.glayer_floats, lay.w2c, seg, S, losspart,
                        grid, inv_B, grad_out, loss_out, adam_p, adam_m, adam_v, adam);
     RNVP_HIP_TRY(hipGetLastError());
+    note_launches(RNVP_PROFILE_TRAIN, grid > kSeg ? 4 : 3);       // pack, hot kernel, (segment sums,) scatter (+ Adam)
     return RNVP_OK;
 }
 

@@ -501,6 +501,8 @@ int launch_rc_s(hipStream_t st, const KShape &k, const RcPlan &p, const EpochArg
     static std::atomic<uint64_t> attr_done{0};
     const int rc = allow_big_lds(reinterpret_cast<const void *>(kern), (int)kLdsMax, attr_done);
     if (rc) return rc;
+    note_dispatch(RNVP_PROFILE_TRAIN, "k_fit_resident_rc", RNVP_VARIANT_RESIDENT, 1, rc_threads<MT, KIT, WMAX, SAVE>() / 64, 1, RNVP_PREC_F32, a.n);
+    note_launches(RNVP_PROFILE_TRAIN, 1);
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);
         hipLaunchKernelGGL(kern, dim3(1), dim3(rc_threads<MT, KIT, WMAX, SAVE>()), (size_t)p.total_floats * sizeof(float), st, k, p, a.params, a.masks, a.x, a.c,
