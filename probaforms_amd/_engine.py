@@ -102,19 +102,21 @@ if hasattr(os, "register_at_fork"):
     os.register_at_fork(after_in_child=_reset_perm_pool_after_fork)
 
 
+_PERM_POOL_WORKERS = 12          # the most any caller asks for (PermutationPrefetcher: min(12, cpus // 2); CVAE's draw worker: 2)
+
+
 def _perm_pool(workers):
     """One process-wide pool for the permutation workers: starting a thread costs ~3 ms on the MI355X hosts (measured:
     12 threads = 39 ms, a quarter of a 32-epoch fit at n = 1M), so the threads are started once and kept.  Called from
-    the fitting thread and from CVAE's draw worker: creation is serialised, a pool that has to grow replaces the old one
-    (which finishes what it holds and is shut down without waiting)."""
+    the fitting thread and from CVAE's draw worker, which keep the returned executor for a whole fit: the pool is
+    therefore created ONCE at the largest size any caller needs and never replaced or shut down (ThreadPoolExecutor starts
+    its threads lazily, so a caller that needs two pays for two)."""
     global _PERM_POOL
     with _PERM_POOL_LOCK:
-        if _PERM_POOL is None or _PERM_POOL[1] < workers:
+        if _PERM_POOL is None:
             from concurrent.futures import ThreadPoolExecutor
-            old = _PERM_POOL
-            _PERM_POOL = (ThreadPoolExecutor(max_workers=workers, thread_name_prefix="rnvp-perm"), workers)
-            if old is not None:
-                old[0].shutdown(wait=False)
+            size = max(_PERM_POOL_WORKERS, int(workers))
+            _PERM_POOL = (ThreadPoolExecutor(max_workers=size, thread_name_prefix="rnvp-perm"), size)
         return _PERM_POOL[0]
 
 
@@ -219,6 +221,24 @@ def is_flat(params, flat):
             return False
         off += p.numel() * 4
     return True
+
+
+# Writes the LIBRARY makes to parameter storage go through raw pointers and leave torch's version counters untouched; they are
+# counted here per storage (keyed by its base address), so that an autograd node recorded on a flow OR on one of its layers
+# alone (whose parameters are views of the flow's buffer) can tell that its parameters changed since the forward.
+_STORAGE_WRITES = {}
+
+
+def note_param_write(t):
+    k = t.untyped_storage().data_ptr()
+    _STORAGE_WRITES[k] = _STORAGE_WRITES.get(k, 0) + 1
+
+
+def param_state(param_list):
+    """what FlowFunction compares between forward and backward: torch's version counters see in-place edits made through
+    tensors (a torch.optim step, `p.add_()`, load_state_dict -- every nn.Parameter keeps its own counter), the per-storage
+    write count the library's own updates (Adam, train_step, fit_epoch*), the data pointers a re-allocation"""
+    return tuple((p.data_ptr(), p._version, _STORAGE_WRITES.get(p.untyped_storage().data_ptr(), 0)) for p in param_list)
 
 
 class FlatAdam:
@@ -418,6 +438,7 @@ class FlowEngine:
         return g
 
     def adam(self, opt):
+        note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         opt.step_count += 1
         g = self.ensure_gbuf()
@@ -426,6 +447,7 @@ class FlowEngine:
 
     def finish_dp_step(self, opt, loss_out):
         """data parallel, after the all-reduce of gbuf[:P+1]: batch loss -> loss_out[0:1] and Adam, one launch"""
+        note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         opt.step_count += 1
         g = self.ensure_gbuf()
@@ -434,6 +456,7 @@ class FlowEngine:
 
     def fit_epoch(self, opt, x, c, perm, batch_size, losses):
         """single-GPU: all batches of one epoch in ONE library call (rnvp_fit_epoch)"""
+        note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         n = perm.numel()
         g = self.ensure_gbuf()
@@ -445,6 +468,7 @@ class FlowEngine:
     def fit_epochs(self, opt, x, c, perms, batch_size, losses):
         """single-GPU: every batch of SEVERAL epochs in one library call (rnvp_fit_epochs): perms [n_epochs, n], losses
         [n_epochs, batches per epoch].  For a model that fits one CU's LDS that is ONE launch for the whole fit."""
+        note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         n_epochs, n = perms.shape
         g = self.ensure_gbuf()
@@ -457,6 +481,7 @@ class FlowEngine:
         """data parallel: all batches of one epoch in ONE library call on ONE stream (rnvp_fit_epoch_dp): per batch this
         rank's loss + gradient, the all-reduce of [gradient | loss] on the library's RCCL communicator, loss read-out +
         Adam.  comm None: the same loop for a single rank without any exchange."""
+        note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         n = perm.numel()
         g = self.ensure_gbuf()
@@ -467,6 +492,7 @@ class FlowEngine:
 
     def train_step(self, opt, x, c, rows, n_rows, inv_B, loss_out):
         """single-GPU fused step: loss+grad, Adam; the batch loss lands in loss_out[0:1]."""
+        note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         opt.step_count += 1
         g = self.ensure_gbuf()
@@ -496,7 +522,7 @@ class FlowFunction(torch.autograd.Function):
         ctx.engine, ctx.n = engine, n
         ctx.save_for_backward(x, c if c is not None else x.new_empty(0))
         ctx.has_c = c is not None
-        ctx.version = engine.flat._version
+        ctx.version = param_state(engine.param_list)
         return z, ld
 
     @staticmethod
@@ -504,7 +530,7 @@ class FlowFunction(torch.autograd.Function):
         eng, n = ctx.engine, ctx.n
         x, c = ctx.saved_tensors
         c = c if ctx.has_c else None
-        if eng.flat._version != ctx.version:
+        if param_state(eng.param_list) != ctx.version:
             raise RuntimeError("the flow's parameters were modified in place between forward and backward "
                                "(one of the variables needed for gradient computation has been modified)")
         dev = x.device
@@ -560,12 +586,23 @@ def dp_communicator(device):
     if world == 1 or dist.get_backend() != "nccl":
         return None
     key = (world, rank, torch.device(device).index)
-    if key not in _DP_COMM:
+    pg = dist.distributed_c10d._get_default_group()
+    cached = _DP_COMM.get(key)
+    if cached is not None and cached[0] is not pg:
+        # the default process group was destroyed and re-created since: the old communicator's peers are gone
+        try:
+            _hip.dp_destroy(cached[1])
+        except Exception:
+            pass
+        cached = None
+    if cached is None:
         # Whether the communicator exists must be the SAME answer on every rank (it selects which collectives the fit
         # issues): each step is followed by an agreement over torch.distributed, and one rank's failure sends all of them
         # to the per-batch loop (with a warning -- slower, not wrong).
+        dev = torch.device(device)
+
         def agree(ok):
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
         uid, comm, err = None, None, None
@@ -573,12 +610,19 @@ def dp_communicator(device):
             uid = _hip.dp_unique_id() if rank == 0 else None
         except Exception as e:          # librccl missing / not loadable
             err = e
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)
-        if agree(box[0] is not None):
+        # the 128 id bytes + a validity flag travel as ONE uint8 tensor on the engine's device (a pickled object list would be
+        # staged on torch.cuda.current_device(), which need not be this rank's engine device)
+        box = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0 and uid is not None:
+            box[:128] = torch.frombuffer(bytearray(uid), dtype=torch.uint8).to(dev)
+            box[128] = 1
+        dist.broadcast(box, src=0)
+        host = box.cpu()
+        have_id = bool(host[128].item())
+        if agree(have_id):
             try:
-                with torch.cuda.device(device):
-                    comm = _hip.dp_init(box[0], rank, world)
+                with torch.cuda.device(dev):
+                    comm = _hip.dp_init(bytes(host[:128].numpy().tobytes()), rank, world)
             except Exception as e:
                 err = e
             if not agree(comm is not None):
@@ -588,8 +632,8 @@ def dp_communicator(device):
             import warnings
             warnings.warn("probaforms_amd: no RCCL communicator for the in-library data-parallel loop (%r); "
                           "falling back to the per-batch loop over torch.distributed" % (err,))
-        _DP_COMM[key] = comm
-    return _DP_COMM[key]
+        cached = _DP_COMM[key] = (pg, comm)
+    return cached[1]
 
 
 def run_epoch(engine, opt, comm, X, C, perm, bounds, batch_size, rank, world, losses, prior=None):
@@ -641,6 +685,7 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     engine.sync_params()
     if world > 1:
         broadcast_(engine.flat, src=0)
+        note_param_write(engine.flat)
     if perms is None:
         perms = PermutationPrefetcher(n, n_epochs)
     try:

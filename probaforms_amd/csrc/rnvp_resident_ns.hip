@@ -101,7 +101,7 @@ k_fit_resident_ns(KShape s, NsPlan pl, float *__restrict__ params, const uint8_t
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = 4 * e + q;
-            const bool mk = masks ? masks[l * d + j] != 0 : (((j + l + (s.alt == 2 ? 1 : 0)) & 1) != 0);
+            const bool mk = masks ? (j < d && masks[l * d + j] != 0) : (((j + l + (s.alt == 2 ? 1 : 0)) & 1) != 0);   // (no read past the [L, d] table)
             if (j >= d || mk) mbits |= 1ull << (4 * l + e);
         }
     bool xok[4];

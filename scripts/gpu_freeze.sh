@@ -6,7 +6,7 @@
 TAG=${1:-r03}
 cd /root/repo; mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt; cat gpurun_out/${TAG}_gpu_tests.txt
-bash scripts/gpu_micro.sh $TAG > /dev/null 2>&1; tail -3 gpurun_out/${TAG}_micro_overlap.txt
+bash scripts/gpu_micro.sh $TAG > gpurun_out/${TAG}_micro.log 2>&1 || echo "gpu_micro.sh FAILED (see gpurun_out/${TAG}_micro.log)"; tail -3 gpurun_out/${TAG}_micro_overlap.txt
 bash scripts/gpu_profiles.sh $TAG > gpurun_out/${TAG}_profiles.log 2>&1; tail -25 gpurun_out/${TAG}_profiles.log
 NT=65536 N=1048576 bash scripts/gpu_pmc.sh ${TAG}train c2 train > gpurun_out/${TAG}_train_pmc.log 2>&1
 python scripts/make_train_pmc.py $TAG

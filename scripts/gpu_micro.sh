@@ -1,10 +1,17 @@
 # usage (GPU box, via gpurun): bash scripts/gpu_micro.sh <tag>  -- the microbenchmarks DESIGN.md leans on, output under gpurun_out/
-TAG=${1:-r03}
+# Each scripts/micro/*.hip is built here (hipcc, gfx950) before it runs; a failed build or run fails the script loudly.
+TAG=${1:-r04}
 cd /root/repo; mkdir -p gpurun_out
-{
-  echo "== scripts/micro/bf16_overlap (MI355X) =="; timeout 300 scripts/micro/bf16_overlap
-  echo; echo "== scripts/micro/mfma_valu_overlap =="; timeout 300 scripts/micro/mfma_valu_overlap
-  echo; echo "== scripts/micro/mfma4x4 =="; timeout 300 scripts/micro/mfma4x4
-  echo; echo "== scripts/micro/unit_mix =="; timeout 300 scripts/micro/unit_mix
-} > gpurun_out/${TAG}_micro_overlap.txt 2>&1
-cat gpurun_out/${TAG}_micro_overlap.txt
+OUT=gpurun_out/${TAG}_micro_overlap.txt
+: > $OUT
+rc=0
+for b in bf16_overlap mfma_valu_overlap mfma4x4 unit_mix; do
+  if ! /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o scripts/micro/$b scripts/micro/$b.hip >> $OUT 2>&1; then
+    echo "BUILD FAILED: scripts/micro/$b.hip" | tee -a $OUT; rc=1; continue
+  fi
+  echo "== scripts/micro/$b (MI355X) ==" >> $OUT
+  if ! timeout 300 scripts/micro/$b >> $OUT 2>&1; then echo "RUN FAILED: scripts/micro/$b" | tee -a $OUT; rc=1; fi
+  echo >> $OUT
+done
+cat $OUT
+exit $rc

@@ -382,6 +382,45 @@ def test_backward_through_log_prob_fills_param_grads_like_the_reference(name):
     assert not v.requires_grad and abs(float(v) + float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
 
 
+@pytest.mark.parametrize("how", ["torch_optim", "inplace", "library_fit", "library_adam", "layer_then_fit", "none"])
+def test_backward_refuses_parameters_changed_since_the_forward(how):
+    """rnvp_backward recomputes the forward from the CURRENT parameters: if they changed between `nf.log_prob()` and
+    `.backward()` the gradients would silently belong to another point.  The reference raises in that case (autograd's
+    version check); so does the build -- for edits through tensors (every nn.Parameter has its own version counter: a
+    torch.optim step, p.add_()) and for the library's own raw-pointer writes (RealNVP.fit, the fused Adam)."""
+    from probaforms_amd.models import RealNVP
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(64, 4)).astype(np.float32); C = rng.normal(size=(64, 2)).astype(np.float32)
+    torch.manual_seed(0)
+    m = RealNVP(n_layers=3, hidden=(8,), batch_size=32, n_epochs=1, lr=1e-3)
+    m.fit(X, C)
+    nf = m.nf
+    Xt, Ct = torch.from_numpy(X), torch.from_numpy(C)
+    if how == "layer_then_fit":                      # a graph recorded on ONE layer (its parameters are views of the flow's buffer)
+        y, ld = nf.layers[1].f(Xt, Ct)
+        loss = y.sum() + ld.sum()
+        m.fit(X, C)
+    else:
+        loss = -nf.log_prob(Xt, Ct)
+    if how == "torch_optim":
+        opt = torch.optim.SGD(nf.parameters(), lr=0.1)
+        (-nf.log_prob(Xt, Ct)).backward()
+        opt.step()                                   # in-place update of every parameter
+    elif how == "inplace":
+        with torch.no_grad():
+            next(iter(nf.parameters())).add_(1e-3)
+    elif how == "library_fit":
+        m.fit(X, C)                                  # warm start (realnvp.py:189-193): the fused kernels write the flat buffer
+    elif how == "library_adam":
+        eng = nf.engine(); eng.ensure_gbuf().zero_(); eng.adam(m.opt)
+    if how == "none":
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in nf.parameters())
+    else:
+        with pytest.raises(RuntimeError, match="modified in place"):
+            loss.backward()
+
+
 def test_input_gradient_and_per_row_seeds_vs_torch_autograd(oracle64):
     """d loss / d x and per-row d loss / d logdet (log_prob_samples with a non-uniform weighting; RealNVPLayer.f alone)
     against torch autograd over an eager restatement of realnvp.py:91-100 on the same weights"""
