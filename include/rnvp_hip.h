@@ -319,6 +319,22 @@ int rnvp_fit_epoch_dp(void *stream, void *comm, const rnvp_shape *shape,
                       int64_t first_step, void *workspace, size_t workspace_bytes);
 
 /*
+ * The same loop with the exchange supplied by the CALLER: `all_reduce(ctx, stream, buf, count)` must leave, on every rank,
+ * the element-wise SUM over ranks of buf[0 .. count) in buf, ordered after the work already enqueued on `stream` and before
+ * whatever is enqueued on it afterwards (an RCCL / MPI call on that stream, or a host-synchronous exchange); non-zero return =
+ * failure, handed back to the caller.  `rank` / `world` place this process in the job.  rnvp_fit_epoch_dp is this call with
+ * the library's RCCL communicator as the exchange.  Lets an embedding that owns its own communicator (torch.distributed
+ * process groups, MPI) run the in-library batch loop, and lets the shard arithmetic be tested with two ranks on one GPU.
+ */
+typedef int (*rnvp_all_reduce_fn)(void *ctx, void *stream, float *buf, int64_t count);
+int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world,
+                         const rnvp_shape *shape, float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                         float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                         double lr, double beta1, double beta2, double eps, double weight_decay,
+                         int64_t first_step, void *workspace, size_t workspace_bytes);
+
+/*
  * Measurement aid (bench.py): while enabled, the hot kernel of each call -- the fused forward+backward
  * kernel of rnvp_loss_grad / rnvp_train_step (RNVP_PROFILE_TRAIN), the stack kernel of
  * rnvp_forward_logprob (RNVP_PROFILE_FORWARD) and of rnvp_inverse / rnvp_sample (RNVP_PROFILE_INVERSE) --

@@ -477,17 +477,23 @@ class FlowEngine:
                         opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
         opt.step_count += n_epochs * len(batch_bounds(n, batch_size))
 
-    def fit_epoch_dp(self, opt, comm, x, c, perm, batch_size, losses):
-        """data parallel: all batches of one epoch in ONE library call on ONE stream (rnvp_fit_epoch_dp): per batch this
-        rank's loss + gradient, the all-reduce of [gradient | loss] on the library's RCCL communicator, loss read-out +
-        Adam.  comm None: the same loop for a single rank without any exchange."""
+    def fit_epoch_dp(self, opt, comm, x, c, perm, batch_size, losses, exchange=None, rank=0, world=1):
+        """data parallel: all batches of one epoch in ONE library call on ONE stream: per batch this rank's loss + gradient, the
+        all-reduce of [gradient | loss], loss read-out + Adam.  comm: the library's RCCL communicator (rnvp_fit_epoch_dp);
+        exchange: a callable(tensor, count) summing in place over the ranks -- process groups that are not RCCL, e.g. gloo
+        (rnvp_fit_epoch_dp_cb; rank / world place this process); neither: the same loop for a single rank."""
         note_param_write(self.flat)
         lr, b1, b2, eps, wd = opt.hyper
         n = perm.numel()
         g = self.ensure_gbuf()
         ws = self.workspace(_hip.OP_TRAIN, min(n, batch_size))
-        _hip.fit_epoch_dp(comm, self.shape, self.params, self.masks, x, c, perm, n, batch_size, g[:self.P + 1], losses,
-                          opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
+        if exchange is not None:
+            _hip.fit_epoch_dp_cb(exchange, rank, world, self.shape, self.params, self.masks, x, c, perm, n, batch_size,
+                                 g[:self.P + 1], losses, opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd,
+                                 opt.step_count + 1, ws)
+        else:
+            _hip.fit_epoch_dp(comm, self.shape, self.params, self.masks, x, c, perm, n, batch_size, g[:self.P + 1], losses,
+                              opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
         opt.step_count += len(batch_bounds(n, batch_size))
 
     def train_step(self, opt, x, c, rows, n_rows, inv_B, loss_out):
@@ -640,13 +646,19 @@ def run_epoch(engine, opt, comm, X, C, perm, bounds, batch_size, rank, world, lo
     """every batch of one epoch (realnvp.py:237-254), enqueued without waiting for the GPU:
     one GPU            -> rnvp_fit_epoch (a fused loss + gradient + Adam step per batch, looped in the library);
     N ranks over RCCL  -> rnvp_fit_epoch_dp (per batch: this rank's share, all-reduce on the same stream, Adam);
-    otherwise (gloo process groups, a user-assigned prior) batch by batch from here with torch.distributed.
+    N ranks, another process group (gloo) -> rnvp_fit_epoch_dp_cb: the same in-library loop, torch.distributed's all_reduce as the exchange;
+    a user-assigned prior -> batch by batch from here with torch.distributed.
     bench.py times exactly this function."""
     if world == 1 and prior is None and comm is None:
         engine.fit_epoch(opt, X, C, perm, batch_size, losses)
         return
     if prior is None and (comm is not None or world == 1):
         engine.fit_epoch_dp(opt, comm, X, C, perm, batch_size, losses)
+        return
+    if prior is None:
+        # a process group that is not RCCL (gloo: CPU test jobs, several ranks on one GPU): the same in-library loop, the exchange
+        # handed in as a callback over torch.distributed -- one code path for the shard arithmetic whatever carries the sum
+        engine.fit_epoch_dp(opt, None, X, C, perm, batch_size, losses, exchange=lambda t, count: all_reduce_sum(t), rank=rank, world=world)
         return
     for k, (s, e) in enumerate(bounds):
         lo, hi = shard_bounds(s, e, rank, world)
@@ -671,7 +683,8 @@ def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook
     flat [gradient | loss] buffer is all-reduced (SUM) before an identical Adam step on every
     rank -- gradients are scaled by 1/B_global inside the kernel, so the sum is the batch mean.  Over RCCL (one rank per
     GPU) that loop, too, is one library call per epoch on one stream (rnvp_fit_epoch_dp on the library's own communicator);
-    other process groups (gloo) and user-assigned priors run it batch by batch from here.
+    other process groups (gloo) run the same library loop with torch.distributed's all_reduce handed in as the exchange
+    (rnvp_fit_epoch_dp_cb); only user-assigned priors run batch by batch from here.
     Losses stay on the device; one copy per epoch feeds loss_history (one entry per batch, as
     realnvp.py:254)."""
     rank, world = dist_info()

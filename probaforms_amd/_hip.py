@@ -146,6 +146,8 @@ _SIGNATURES = {
     "rnvp_dp_all_reduce": (C.c_int, [_VP, _VP, _VP, _I64]),
     "rnvp_fit_epoch_dp": (C.c_int, [_VP, _VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
                                     _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "rnvp_fit_epoch_dp_cb": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
+                                       _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
     "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
@@ -392,6 +394,40 @@ def fit_epoch_dp(comm, shape, params, masks, x, c, perm, n, batch_size, grad_los
           int(batch_size), _ptr(grad_loss, torch.float32, "grad_loss"), _ptr(loss_hist, torch.float32, "loss_hist"),
           _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
           float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn))
+
+
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)      # rnvp_all_reduce_fn
+
+
+def fit_epoch_dp_cb(all_reduce, rank, world, shape, params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, exp_avg,
+                    exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step, ws):
+    """rnvp_fit_epoch_dp with the exchange supplied by the caller: `all_reduce(buf_tensor_view, count)` must sum
+    grad_loss[:count] over the ranks in place, ordered with the current stream (a torch.distributed all_reduce on the tensor
+    is).  The library hands back raw pointers; the wrapper checks that they are the ones of `grad_loss` and passes that tensor."""
+    wp, wn = _ws(ws)
+    base = grad_loss.data_ptr()
+    failure = []
+
+    def _cb(_ctx, _stream, buf, count):
+        try:
+            if buf != base or count > grad_loss.numel():
+                raise RuntimeError("rnvp_fit_epoch_dp_cb handed the exchange a buffer that is not grad_loss")
+            all_reduce(grad_loss[:count], int(count))
+            return 0
+        except BaseException as e:          # an exception must not unwind through the C frames
+            failure.append(e)
+            return 1
+
+    cb = ALL_REDUCE_FN(_cb)
+    st = lib().rnvp_fit_epoch_dp_cb(_stream(), C.cast(cb, C.c_void_p), None, int(rank), int(world), C.byref(shape),
+          _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+          _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), int(n),
+          int(batch_size), _ptr(grad_loss, torch.float32, "grad_loss"), _ptr(loss_hist, torch.float32, "loss_hist"),
+          _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"), float(lr),
+          float(beta1), float(beta2), float(eps), float(weight_decay), int(first_step), wp, wn)
+    if failure:
+        raise failure[0]
+    check(st, "rnvp_fit_epoch_dp_cb")
 
 
 # ---- CVAE (include/cvae_hip.h) ----------------------------------------------------------------

@@ -340,13 +340,28 @@ int rnvp_fit_epochs(void *stream, const rnvp_shape *shape, float *params, const 
         return resident::fit_epoch(static_cast<hipStream_t>(stream), ks, params, masks, x, c, perms, n, batch_size, n_epochs, loss_hist,
                                    exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step);
     }
+    // the register-chained kernels keep their packed weight fragments in the workspace: packed once at the head of this call,
+    // then re-packed by each step's finish kernel (two launches per batch: training kernel + finish)
+    const bool chained = n > 0 && mfma::train_supported(ks);
+    if (chained && (bad_ptrs(ks, params, masks, x, c) || !grad_buf || !exp_avg || !exp_avg_sq)) return RNVP_EINVAL;
+    bool packed_valid = false;
     for (int64_t e = 0; e < n_epochs; ++e) {
         int64_t k = 0;
         for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
             const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
-            const int rc = rnvp_train_step(stream, shape, params, masks, x, c, perms + e * n + s0, rows, 1.0f / (float)rows,
-                                           grad_buf, loss_hist + e * nb + k, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
-                                           weight_decay, first_step + e * nb + k, workspace, workspace_bytes);
+            const bool last = e + 1 == n_epochs && s0 + rows >= n;
+            int rc;
+            if (chained) {
+                rc = mfma::train_step(static_cast<hipStream_t>(stream), ks, params, x, c, perms + e * n + s0, rows, 1.0f / (float)rows,
+                                      grad_buf, loss_hist + e * nb + k, exp_avg, exp_avg_sq,
+                                      make_adam(lr, beta1, beta2, eps, weight_decay, first_step + e * nb + k), workspace,
+                                      workspace_bytes, packed_valid, !last);
+                packed_valid = true;
+            } else {
+                rc = rnvp_train_step(stream, shape, params, masks, x, c, perms + e * n + s0, rows, 1.0f / (float)rows,
+                                     grad_buf, loss_hist + e * nb + k, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+                                     weight_decay, first_step + e * nb + k, workspace, workspace_bytes);
+            }
             if (rc) return rc;
         }
     }

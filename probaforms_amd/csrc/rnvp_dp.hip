@@ -15,6 +15,7 @@
 #include <mutex>
 
 #include "rnvp_common.h"
+#include "rnvp_mfma.h"
 
 namespace {
 
@@ -102,17 +103,40 @@ int rnvp_dp_all_reduce(void *stream, void *comm, float *buf, int64_t count) {
     return RNVP_OK;
 }
 
+static int rccl_all_reduce_cb(void *ctx, void *stream, float *buf, int64_t count) {
+    return rnvp_dp_all_reduce(stream, ctx, buf, count);
+}
+
 int rnvp_fit_epoch_dp(void *stream, void *comm, const rnvp_shape *shape, float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
                       float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
                       double lr, double beta1, double beta2, double eps, double weight_decay,
                       int64_t first_step, void *workspace, size_t workspace_bytes) {
-    if (n < 0 || batch_size < 1 || !perm || !loss_hist || !grad_loss || first_step < 1) return RNVP_EINVAL;
-    // comm == NULL: one rank, no exchange (the same three-launch step, for tests of the loop itself)
+    // comm == NULL: one rank, no exchange (the same step sequence, for tests of the loop itself)
     const DpComm *dc = static_cast<const DpComm *>(comm);
-    const int rank = dc ? dc->rank : 0, world = dc ? dc->world : 1;
+    return rnvp_fit_epoch_dp_cb(stream, dc ? rccl_all_reduce_cb : nullptr, comm, dc ? dc->rank : 0, dc ? dc->world : 1, shape,
+                                params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, exp_avg, exp_avg_sq, lr, beta1,
+                                beta2, eps, weight_decay, first_step, workspace, workspace_bytes);
+}
+
+int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world,
+                         const rnvp_shape *shape, float *params, const uint8_t *masks,
+                         const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                         float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                         double lr, double beta1, double beta2, double eps, double weight_decay,
+                         int64_t first_step, void *workspace, size_t workspace_bytes) {
+    if (n < 0 || batch_size < 1 || !perm || !loss_hist || !grad_loss || first_step < 1) return RNVP_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !all_reduce)) return RNVP_EINVAL;
+    rnvp::KShape ks;
+    int rc = rnvp::make_kshape(shape, &ks);
+    if (rc) return rc;
     const int64_t P = (int64_t)rnvp_param_count(shape);
     if (P <= 0) return RNVP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // register-chained kernels: the packed weight fragments live in the workspace for the whole call -- packed by the first
+    // batch's rnvp_loss_grad, then re-packed by every batch's Adam launch (rnvp::mfma::adam_pack)
+    const bool chained = rnvp::mfma::train_supported(ks);
+    bool packed_valid = false;
     int64_t k = 0;
     for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
         const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
@@ -121,15 +145,28 @@ int rnvp_fit_epoch_dp(void *stream, void *comm, const rnvp_shape *shape, float *
         const int64_t base = rows / world, rem = rows % world;
         const int64_t lo = s0 + rank * base + (rank < rem ? rank : rem);
         const int64_t mine = base + (rank < rem ? 1 : 0);
-        int rc = rnvp_loss_grad(stream, shape, params, masks, x, c, perm + lo, mine, 1.0f / (float)rows, grad_loss,
+        if (chained && mine > 0) {
+            if (!params || (!masks && !ks.alt) || !x || (ks.c > 0 && !c)) return RNVP_EINVAL;
+            rc = rnvp::mfma::loss_grad(st, ks, params, x, c, perm + lo, mine, 1.0f / (float)rows, grad_loss, grad_loss + P, workspace,
+                                       workspace_bytes, rnvp::Seeds{}, packed_valid);
+        } else {
+            rc = rnvp_loss_grad(stream, shape, params, masks, x, c, perm + lo, mine, 1.0f / (float)rows, grad_loss,
                                 grad_loss + P, workspace, workspace_bytes);
+        }
         if (rc) return rc;
-        if (dc) {
-            rc = rnvp_dp_all_reduce(stream, comm, grad_loss, P + 1);
+        if (all_reduce) {               // (a one-rank communicator still runs its trivial exchange: the call sequence of N ranks)
+            rc = all_reduce(ctx, stream, grad_loss, P + 1);
             if (rc) return rc;
         }
-        rc = rnvp_dp_finish_step(stream, params, grad_loss, exp_avg, exp_avg_sq, P, lr, beta1, beta2, eps, weight_decay,
-                                 first_step + k, loss_hist + k);
+        if (chained) {
+            if (!exp_avg || !exp_avg_sq) return RNVP_EINVAL;
+            rc = rnvp::mfma::adam_pack(st, ks, params, grad_loss, grad_loss + P, loss_hist + k, exp_avg, exp_avg_sq,
+                                       rnvp::make_adam(lr, beta1, beta2, eps, weight_decay, first_step + k), workspace, workspace_bytes);
+            packed_valid = true;
+        } else {
+            rc = rnvp_dp_finish_step(stream, params, grad_loss, exp_avg, exp_avg_sq, P, lr, beta1, beta2, eps, weight_decay,
+                                     first_step + k, loss_hist + k);
+        }
         if (rc) return rc;
     }
     return RNVP_OK;

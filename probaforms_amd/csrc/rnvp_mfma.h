@@ -106,11 +106,17 @@ int sample(hipStream_t st, const KShape &k, const float *params, const float *c,
            int64_t row0, float *x_out, void *ws, size_t ws_bytes);
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes, Seeds sd = Seeds{});
+              void *ws, size_t ws_bytes, Seeds sd = Seeds{}, bool packed_valid = false);
 
+// packed_valid: the workspace already holds the packed fragments of `params` (an earlier step of the same rnvp_fit_epoch*
+// call left them there): no pack launch.  pack_next: the step's finish kernel re-packs the parameters it updates.
 int train_step(hipStream_t st, const KShape &k, float *params, const float *x, const float *c,
                const int64_t *row_index, int64_t n, float inv_B, float *grad_buf, float *loss_out,
-               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes);
+               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes, bool packed_valid = false,
+               bool pack_next = false);
+// data parallel, after the all-reduce: loss read-out + Adam from the flat gradient + re-pack, one launch
+int adam_pack(hipStream_t st, const KShape &k, float *params, float *grad, const float *loss_in, float *loss_out,
+              float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes);
 
 }  // namespace mfma
 }  // namespace rnvp

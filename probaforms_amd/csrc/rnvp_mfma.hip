@@ -5,6 +5,7 @@
 // geometry), one hidden layer, tanh, and the reference's alternating masks.
 #include "rnvp_bx3.h"
 #include "rnvp_mfma_layer.h"
+#include "rnvp_mfma_pack.h"
 #include "rnvp_prior.h"
 
 // amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE): with at most 256 registers per wave hipcc keeps MFMA
@@ -22,127 +23,10 @@ constexpr int kWaves = 4;                // waves per workgroup (one per SIMD)
 constexpr int kMaxGrid = 2048;
 
 // ---- weight packing ----------------------------------------------------------------------------
-// One thread per float of the packed block; reads the flat reference-order parameters
-// (include/rnvp_hip.h "params").  Runs at the head of every call so the packed copy always
-// reflects the caller's current parameters (76 k .. 450 k floats: a few microseconds).
-__device__ float pack_value(const KShape &k, const Geo &g, int l, int idx, const float *__restrict__ params) {
-    const int pc = (l + k.alt) & 1;
-    const int nin = k.d + k.c, h = k.nout[0];                 // REAL sizes: flat indexing; padded slots -> 0
-    const float *pl = params + (size_t)l * 2 * k.npn;
-#define RNVP_W1(net, hid, col) (((hid) < h && (col) >= 0) ? pl[(net) * k.npn + k.woff[0] + (hid) * nin + (col)] : 0.f)
-#define RNVP_W2(net, feat, hid) (((hid) < h && (feat) < k.d) ? pl[(net) * k.npn + k.woff[1] + (feat) * h + (hid)] : 0.f)
-    // real input column of a padded feature / condition slot, or -1
-    auto xcol = [&](int feat) { return feat < k.d ? feat : -1; };
-    auto ccol = [&](int ci) { return ci < k.c ? k.d + ci : -1; };
-    if (idx < g.oB1) {                                     // A1 [tile][k4][lane][4]
-        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
-        const int k4 = rest % g.K4, tile = rest / g.K4;
-        const int kk = 4 * k4 + e, q = lane >> 4, i = lane & 15;
-        const int net = tile / g.HT, hid = 16 * (tile % g.HT) + i;
-        int col;
-        if (kk < g.NF) col = xcol(feat_cond(g.NF, q, kk, pc));
-        else if (kk < g.KS1) col = ccol(q * g.CQ + (kk - g.NF));
-        else return 0.f;
-        return (k.act == RNVP_ACT_TANH ? kTanhScale : 1.0f) * RNVP_W1(net, hid, col);   // tanh: pre-scaled, see tanh4
-    }
-    if (idx < g.oA2) {                                     // bias1 [tile][q][4]
-        const int j = idx - g.oB1;
-        const int e = j & 3, q = (j >> 2) & 3, tile = j >> 4;
-        const int net = tile / g.HT, hid = 16 * (tile % g.HT) + 4 * q + e;
-        return hid < h ? (k.act == RNVP_ACT_TANH ? kTanhScale : 1.0f) * pl[net * k.npn + k.boff[0] + hid] : 0.f;
-    }
-    if (idx < g.oB2) {                                     // A2 [tile][otl][lane][4 rho]
-        const int j = idx - g.oA2;
-        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int otl = rest % g.OTL, tile = rest / g.OTL;
-        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
-        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
-        const int qo = i >> 2, ro = i & 3;
-        int f, net_out;
-        if (g.NF >= 4) { f = 4 * otl + ro; net_out = net; }
-        else { f = ro & 1; net_out = ro >> 1; }
-        if (net_out != net) return 0.f;
-        return RNVP_W2(net, feat_trans(g.NF, qo, f, pc), hid);
-    }
-    if (idx < g.oA2T) {                                    // bias2 [ot][q][4]
-        const int j = idx - g.oB2;
-        const int ro = j & 3, qo = (j >> 2) & 3, ot = j >> 4;
-        int f, net;
-        if (g.NF >= 4) { net = ot / g.OTL; f = 4 * (ot % g.OTL) + ro; }
-        else { net = ro >> 1; f = ro & 1; }
-        const int feat = feat_trans(g.NF, qo, f, pc);
-        return feat < k.d ? pl[net * k.npn + k.boff[1] + feat] : 0.f;
-    }
-    if (idx >= g.oA2TS) {                                  // A2TS [tile][NI2][lane][4 dwords]: W2^T of ONE net, split bf16
-        // lane (q, i): hidden unit 16t + i; the lane's slot list holds the NF transformed features of lane group q
-        const int j = idx - g.oA2TS;
-        const int e = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int ni = rest % g.NI2, tile = rest / g.NI2;
-        const int D = 4 * ni + e, v = D / 3, p = D % 3;
-        if (v >= g.NF) return 0.f;
-        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
-        const int hid = 16 * (tile % g.HT) + i;
-        return __uint_as_float(split::a_dword(RNVP_W2(net, feat_trans(g.NF, q, v, pc), hid), p));
-    }
-    if (idx >= g.oA1S) {                                   // A1S [tile][NI1][lane][4 dwords]: A1 split bf16 (same k order)
-        const int j = idx - g.oA1S;
-        const int e = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int ni = rest % g.NI1, tile = rest / g.NI1;
-        const int D = 4 * ni + e, kk = D / 3, p = D % 3;
-        const int q = lane >> 4, i = lane & 15;
-        const int net = tile / g.HT, hid = 16 * (tile % g.HT) + i;
-        int col;
-        if (kk < g.NF) col = xcol(feat_cond(g.NF, q, kk, pc));
-        else if (kk < g.KS1) col = ccol(q * g.CQ + (kk - g.NF));
-        else return 0.f;
-        return __uint_as_float(split::a_dword((k.act == RNVP_ACT_TANH ? kTanhScale : 1.0f) * RNVP_W1(net, hid, col), p));
-    }
-    if (idx < g.oA1T) {                                    // A2T [tile][otl][lane][4 rho]
-        const int j = idx - g.oA2T;
-        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int otl = rest % g.OTL, tile = rest / g.OTL;
-        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
-        const int hid = 16 * (tile % g.HT) + i;
-        int f, net_out;
-        if (g.NF >= 4) { f = 4 * otl + rho; net_out = net; }
-        else { f = rho & 1; net_out = rho >> 1; }
-        if (net_out != net) return 0.f;
-        return RNVP_W2(net, feat_trans(g.NF, q, f, pc), hid);
-    }
-    if (idx >= g.oA1X) {                                   // A1X [tile][og][lane][4 rho]  (d == 16)
-        // 4x4x1 blocks: lane (q, r), i = r & 3 supplies W1[hid 16t+4q+rho][conditioning feature (og, i)],
-        // feature owner q_f = 2*og + (i >> 1), slot f = i & 1
-        const int j = idx - g.oA1X;
-        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int og = rest & 1, tile = rest >> 1;
-        const int q = lane >> 4, i = lane & 3, net = tile / g.HT;
-        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
-        return RNVP_W1(net, hid, xcol(feat_cond(g.NF, 2 * og + (i >> 1), i & 1, pc)));
-    }
-    if (idx >= g.oA2X) {                                   // A2X [tile][og][lane][4 rho]  (d == 16)
-        const int j = idx - g.oA2X;
-        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int og = rest & 1, tile = rest >> 1;
-        const int q = lane >> 4, i = lane & 3, net = tile / g.HT;
-        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
-        return RNVP_W2(net, feat_trans(g.NF, 2 * og + (i >> 1), i & 1, pc), hid);
-    }
-    {                                                      // A1T [tile][mt][lane][4 rho]
-        const int j = idx - g.oA1T;
-        const int rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
-        const int mt = rest % g.MTI, tile = rest / g.MTI;
-        const int q = lane >> 4, i = lane & 15, net = tile / g.HT;
-        const int hid = 16 * (tile % g.HT) + 4 * q + rho;
-        const int qi = i >> 2, ri = i & 3;
-        int f;
-        if (g.NF >= 4) f = 4 * mt + ri;
-        else { if (ri >= 2) return 0.f; f = ri; }
-        return RNVP_W1(net, hid, xcol(feat_cond(g.NF, qi, f, pc)));
-    }
-#undef RNVP_W1
-#undef RNVP_W2
-}
-
+// One thread per float of the packed block (slot values: rnvp_mfma_pack.h); reads the flat reference-order parameters
+// (include/rnvp_hip.h "params").  Runs at the head of every call so the packed copy always reflects the caller's current
+// parameters (76 k .. 450 k floats: a few microseconds); inside rnvp_fit_epoch* only once per call -- from then on the
+// training step's finish kernel re-packs what it updates.
 __global__ void __launch_bounds__(256)
 k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restrict__ packed) {
     const int per = g.layer_floats;
@@ -150,7 +34,7 @@ k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restr
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int l = (int)(t / per), idx = (int)(t - (int64_t)l * per);
-        packed[t] = pack_value(k, g, l, idx, params);
+        packed[t] = pack_value(k, g, l, idx, FlatParams(k, params, l));
     }
 }
 

@@ -4,6 +4,7 @@
 // reference-order gradient (+ Adam).  Replaces `loss = -nf.log_prob(X, C); loss.backward()` and `opt.step()`
 // (/root/reference/probaforms/models/realnvp.py:246-251).
 #include "rnvp_mfma_train_dev.h"
+#include "rnvp_mfma_pack.h"
 
 namespace rnvp {
 namespace mfma {
@@ -17,32 +18,11 @@ RNVP_LAUNCH_DECL(2, 1) RNVP_LAUNCH_DECL(2, 0) RNVP_LAUNCH_DECL(4, 2) RNVP_LAUNCH
 
 namespace {
 
-// ---- stage 2: segment sums -> flat reference-order gradient -----------------------------------------
-// One thread per flat parameter; finds where the packed gradient keeps it (or that the masks make
-// it dead: exactly zero, as in the reference) and sums the workgroup partials in index order.
-__global__ void __launch_bounds__(256)
-k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, int w2c, const float *__restrict__ seg, int S,
-              const float *__restrict__ losspart, int G, float inv_B, float *__restrict__ grad, float *loss,
-              float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
-    // w2c: the launch wrote the compact dW2 records of Dims::w2c (128 floats per hidden tile after the dW1 tiles)
-    const size_t P = (size_t)2 * k.npn * k.L;
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) {
-        // the last block's first wave reduces the per-wave loss partials (fixed order: deterministic)
-        if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
-            const int lane = threadIdx.x - 192;
-            float a = 0.f;
-            for (int i = lane; i < G * kWaves; i += 64) a += losspart[i];
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-            if (lane == 0) loss[0] = -a * inv_B;
-        }
-        return;
-    }
-    const int l = (int)(p / (2 * (size_t)k.npn));
-    int idx = (int)(p - (size_t)l * 2 * k.npn);
-    const int net = idx >= k.npn;
-    idx -= net * k.npn;
-    const int pc = (l + k.alt) & 1;
+// ---- stage 2: per-workgroup partial gradients -> flat reference-order gradient (+ Adam, + next step's fragments) --------
+// Where the packed gradient of one layer keeps parameter `idx` of net `net` (float offset inside the layer's record), or -1
+// when the masks make it dead (exactly zero, as in the reference).  pc = (l + alt) & 1; w2c: the launch wrote the compact
+// dW2 records of Dims::w2c (128 floats per hidden tile after the dW1 tiles).
+__device__ __forceinline__ int grad_loc(const KShape &k, const Geo &g, int NTI, int w2c, int pc, int net, int idx) {
     const int NF = g.NF, CQ = g.CQ, HT = g.HT, OTL = g.OTL, h = k.nout[0], nin = k.d + k.c;
     const int KSP = 4 * NTI;
     const int tblk = w2c ? NTI * 256 + 128 : (NTI + OTL) * 256;      // floats of one hidden tile's record
@@ -92,22 +72,165 @@ k_mfma_reduce(KShape k, Geo g, int NTI, int glayer_floats, int w2c, const float 
             loc = 2 * netblock + (ot * 4 + qo) * 4 + reg;
         }
     }
-    float a = 0.f;
-    if (loc >= 0) {
-        const float *src = seg + (size_t)l * glayer_floats + loc;
-        const size_t stride = (size_t)glayer_floats * k.L;
-        if (S == kSeg) {            // the usual case: all sixteen loads in flight, then added in segment order
-            float v[kSeg];
+    return loc;
+}
+
+// parameter source of pack_value for ONE hidden tile of one net, from the workgroup's LDS copy of the freshly updated
+// values: [16 hidden units][nin] of W1, 16 of b1, [d][16 hidden units] of W2 (k_train_finish)
+struct TileParams {
+    const float *pw;
+    int nin, ht;
+    __device__ float w1(int, int hid, int col) const { return pw[(hid - 16 * ht) * nin + col]; }
+    __device__ float b1(int, int hid) const { return pw[16 * nin + hid - 16 * ht]; }
+    __device__ float w2(int, int feat, int hid) const { return pw[16 * nin + 16 + feat * 16 + hid - 16 * ht]; }
+    __device__ float b2(int, int) const { return 0.f; }
+};
+// ... and for the second-Linear biases of a layer: [2 nets][d]
+struct Bias2Params {
+    const float *pw;
+    int d;
+    __device__ float w1(int, int, int) const { return 0.f; }
+    __device__ float b1(int, int) const { return 0.f; }
+    __device__ float w2(int, int, int) const { return 0.f; }
+    __device__ float b2(int net, int feat) const { return pw[net * d + feat]; }
+};
+
+// ONE launch behind the training kernel (round 3 ran three: segment sums, scatter + Adam, and the next step's re-pack).
+// Workgroup b < 2 L HT owns the gradient record of (layer, net, hidden tile) = b -- the rows 16 ht .. 16 ht + 15 of W1 and b1
+// and the matching columns of W2 of that net; workgroups 2 L HT .. 2 L HT + L - 1 own the second-Linear biases of one layer
+// each; the last one adds the loss partials.  Stages, each optional (`mode`):
+//   kFinSum : add the record over the G per-workgroup partials of the training launch -- threads split into sub-groups, sub-group
+//             s adds partials s, s + nsub, ... in index order (eight loads in flight), the sub-sums are added in s order: a fixed
+//             order for a given launch geometry, no float atomics -- and scatter it into the flat gradient;
+//             without it the flat gradient is an INPUT (data parallel: the all-reduced message);
+//   kFinAdam: torch.optim.Adam on the record's parameters (realnvp.py:251);
+//   kFinPack: rewrite the packed fragments of exactly this hidden tile from the updated values (kept in LDS), so that the
+//             next batch's training kernel can start without a pack launch.
+constexpr int kFinSum = 1, kFinAdam = 2, kFinPack = 4;
+constexpr int kFinThreads = 512;
+constexpr int kFinRecMax = 1536;                  // floats of the largest record: (NTI 4 + OTL 2) x 256 (d = 64)
+constexpr int kFinParMax = 16 * 80 + 16 + 64 * 16;  // LDS copy of a tile's parameters: d <= 64, cdim <= 16
+
+__global__ void __launch_bounds__(kFinThreads)
+k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, const float *__restrict__ gpart, int G,
+               const float *__restrict__ losspart, int n_loss, float inv_B, const float *loss_in, float *loss_out,
+               float *grad, float *params, float *adam_m, float *adam_v, AdamK adam, float *packed) {
+    __shared__ __attribute__((aligned(16))) float rec[kFinRecMax];
+    __shared__ f4 red[kFinThreads];
+    __shared__ float pw[kFinParMax];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int HT = g.HT, nrec = k.L * 2 * HT;
+    if (b == nrec + k.L) {                  // the loss: partials added in a fixed order (one wave), or read out of the message
+        if (t < 64 && loss_out) {
+            if (mode & kFinSum) {
+                float a = 0.f;
+                for (int i = t; i < n_loss; i += 64) a += losspart[i];
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (t == 0) loss_out[0] = -a * inv_B;
+            } else if (t == 0 && loss_in) {
+                loss_out[0] = loss_in[0];
+            }
+        }
+        return;
+    }
+    const bool bias2 = b >= nrec;
+    const int l = bias2 ? b - nrec : b / (2 * HT);
+    const int net = bias2 ? 0 : (b / HT) & 1, ht = bias2 ? 0 : b % HT;
+    const int tblk = w2c ? NTI * 256 + 128 : (NTI + g.OTL) * 256, netblock = HT * tblk;
+    const int rec_off = bias2 ? 2 * netblock : net * netblock + ht * tblk;      // floats inside the layer's record
+    const int rec_n = bias2 ? g.NT2 * 16 : tblk;
+    const int pc = (l + k.alt) & 1;
+    const int h = k.nout[0], nin = k.d + k.c, d = k.d;
+    if (mode & kFinSum) {
+        const int nf4 = rec_n / 4;
+        const size_t stride4 = (size_t)glayer_floats * k.L / 4;
+        for (int c0 = 0; c0 < nf4; c0 += kFinThreads) {
+            const int cols = nf4 - c0 < kFinThreads ? nf4 - c0 : kFinThreads;
+            const int nsub = kFinThreads / cols;
+            const int col = t % cols, sub = t / cols;
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            if (sub < nsub) {
+                const f4 *src = reinterpret_cast<const f4 *>(gpart + (size_t)l * glayer_floats + rec_off) + c0 + col;
+                int bb = sub;
+                for (; bb + 7 * nsub < G; bb += 8 * nsub) {
+                    f4 v[8];
 #pragma unroll
-            for (int b = 0; b < kSeg; ++b) v[b] = __builtin_nontemporal_load(src + (size_t)b * stride);
+                    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(bb + u * nsub) * stride4);
 #pragma unroll
-            for (int b = 0; b < kSeg; ++b) a += v[b];
-        } else {
-            for (int b = 0; b < S; ++b) a += src[(size_t)b * stride];      // segment order: deterministic
+                    for (int u = 0; u < 8; ++u) acc += v[u];
+                }
+                for (; bb < G; bb += nsub) acc += __builtin_nontemporal_load(src + (size_t)bb * stride4);
+            }
+            red[t] = acc;
+            __syncthreads();
+            if (t < cols) {
+                f4 a = red[t];
+                for (int s2 = 1; s2 < nsub; ++s2) a += red[s2 * cols + t];
+                *reinterpret_cast<f4 *>(rec + 4 * (c0 + t)) = a;
+            }
+            __syncthreads();
         }
     }
-    grad[p] = a;
-    if (adam_p) adam_one(adam_p[p], a, adam_m[p], adam_v[p], adam);  // fused optimizer (rnvp_train_step)
+    // the record's parameters: gradient out of the record (or in from the all-reduced message), Adam, LDS copy for the re-pack
+    const int npar = bias2 ? 2 * d : 16 * (nin + 1 + d);
+    for (int e = t; e < npar; e += kFinThreads) {
+        int pnet = net, idx, hid = 0;
+        if (bias2) {
+            pnet = e / d;
+            idx = k.boff[1] + (e - pnet * d);
+        } else if (e < 16 * nin) {
+            const int i = e / nin;
+            hid = 16 * ht + i;
+            idx = k.woff[0] + hid * nin + (e - i * nin);
+        } else if (e < 16 * nin + 16) {
+            hid = 16 * ht + (e - 16 * nin);
+            idx = k.boff[0] + hid;
+        } else {
+            const int ee = e - 16 * nin - 16, j = ee >> 4;
+            hid = 16 * ht + (ee & 15);
+            idx = k.woff[1] + j * h + hid;
+        }
+        float val = 0.f;
+        if (hid < h) {
+            const size_t p = ((size_t)l * 2 + pnet) * k.npn + idx;
+            float a;
+            if (mode & kFinSum) {
+                const int loc = grad_loc(k, g, NTI, w2c, pc, pnet, idx);
+                a = loc >= 0 ? rec[loc - rec_off] : 0.f;
+                grad[p] = a;
+            } else {
+                a = grad[p];
+            }
+            if (mode & kFinAdam) {
+                float pv = params[p], mm = adam_m[p], vv = adam_v[p];
+                adam_one(pv, a, mm, vv, adam);
+                params[p] = pv; adam_m[p] = mm; adam_v[p] = vv;
+                val = pv;
+            } else if (mode & kFinPack) {
+                val = params[p];
+            }
+        }
+        pw[e] = val;
+    }
+    if (!(mode & kFinPack)) return;
+    __syncthreads();
+    float *pk = packed + (size_t)l * g.layer_floats;
+    if (bias2) {
+        const Bias2Params src{pw, d};
+        for (int s2 = t; s2 < g.NT2 * 16; s2 += kFinThreads) pk[g.oB2 + s2] = pack_value(k, g, l, g.oB2 + s2, src);
+        return;
+    }
+    const TileParams src{pw, nin, ht};
+    const int T = net * HT + ht;
+    // every packed array is indexed [tile][...]: the slots of tile T, array by array
+    const int offs[9] = {g.oA1, g.oB1, g.oA2, g.oA2T, g.oA1T, g.oA2X, g.oA1X, g.oA1S, g.oA2TS};
+    const int pers[9] = {g.K4 * 256, 16, g.OTL * 256, g.OTL * 256, g.MTI * 256, g.NF == 2 ? 512 : 0, g.NF == 2 ? 512 : 0,
+                         g.NI1 * 256, g.NI2 * 256};
+#pragma unroll
+    for (int arr = 0; arr < 9; ++arr) {
+        const int base = offs[arr] + T * pers[arr];
+        for (int s2 = t; s2 < pers[arr]; s2 += kFinThreads) pk[base + s2] = pack_value(k, g, l, base + s2, src);
+    }
 }
 
 template <int NF, int CQ>
@@ -156,16 +279,30 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
     if (!plan_for(g, k.L, &pl)) return 0;
     size_t b = align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);                    // packed weights
     b += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);          // partials
-    b += align_up((size_t)kSeg * pl.glayer_floats * k.L * sizeof(float), 256);                   // segment sums
     b += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);                          // loss partials
     b += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);    // saved activations
     return b;
 }
 
-static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
-                          const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-                          void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam,
-                          Seeds sd = Seeds{}) {
+static int launch_finish(hipStream_t st, const KShape &k, const Geo &g, int glayer_floats, int w2c, int mode, const float *gpart,
+                         int G, const float *losspart, float inv_B, const float *loss_in, float *loss_out, float *grad,
+                         float *params, float *adam_m, float *adam_v, const AdamK &adam, float *packed) {
+    const int NTI = (g.KS1 + 1 + 3) / 4;
+    const unsigned blocks = (unsigned)(k.L * 2 * g.HT + k.L + 1);
+    hipLaunchKernelGGL(k_train_finish, dim3(blocks), dim3(kFinThreads), 0, st, k, g, NTI, glayer_floats, w2c, mode, gpart, G, losspart,
+                       G * kWaves, inv_B, loss_in, loss_out, grad, params, adam_m, adam_v, adam, packed);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}
+
+// One training step on the register-chained kernels: [pack the fragments] -> fused forward + backward (per-workgroup partial
+// gradients) -> k_train_finish (sum, scatter to flat order [, Adam [, re-pack for the next step]]).
+//   packed_valid: the workspace already holds the fragments of `params` (the previous step of the same rnvp_fit_epoch* call
+//                 re-packed them): no pack launch;   pack_next: this step's finish kernel re-packs what Adam updates.
+static int step_impl(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
+                     const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
+                     void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam, Seeds sd,
+                     bool packed_valid, bool pack_next) {
     if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     if ((sd.gld || sd.gx) && n > ts_max_rows(g)) return RNVP_EUNSUPPORTED;       // see backward_rows_ok
@@ -176,12 +313,10 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     w += align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);
     float *gpart = reinterpret_cast<float *>(w);
     w += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);
-    float *seg = reinterpret_cast<float *>(w);
-    w += align_up((size_t)kSeg * pl.glayer_floats * k.L * sizeof(float), 256);
     float *losspart = reinterpret_cast<float *>(w);
     w += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);
     float *scratch = reinterpret_cast<float *>(w);
-    int rc = pack_weights(st, k, g, params, packed);
+    int rc = packed_valid ? RNVP_OK : pack_weights(st, k, g, params, packed);
     if (rc) return rc;
     int grid = 0;
     PartialLayout lay{pl.glayer_floats, 0};
@@ -191,40 +326,42 @@ static int loss_grad_impl(hipStream_t st, const KShape &k, const float *params, 
     else if (g.NF == 8 && g.CQ == 4) rc = launch_train_8_4(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, sd, &lay);
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
-    const size_t P = (size_t)2 * k.npn * k.L;
-    const unsigned blocks = (unsigned)(P / 256 + 2);     // last block's last wave is always past P: it sums the loss
-    int NTI = (g.KS1 + 1 + 3) / 4;
-    const size_t n4 = (size_t)lay.glayer_floats * k.L / 4;
-    // second level (<= kSeg segment sums per parameter) is folded into the scatter to flat order; up to kSeg
-    // workgroups ARE the segments (small batches: one launch fewer per step)
-    const int S = grid < kSeg ? grid : kSeg;
-    if (grid > kSeg) {
-        hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), kSeg), dim3(256), 0, st, gpart, grid, n4, seg);
-        RNVP_HIP_TRY(hipGetLastError());
-    } else {
-        seg = gpart;
-    }
-    hipLaunchKernelGGL(k_mfma_reduce, dim3(blocks), dim3(256), 0, st, k, g, NTI, lay.glayer_floats, lay.w2c, seg, S, losspart,
-                       grid, inv_B, grad_out, loss_out, adam_p, adam_m, adam_v, adam);
-    RNVP_HIP_TRY(hipGetLastError());
-    note_launches(RNVP_PROFILE_TRAIN, grid > kSeg ? 4 : 3);       // pack, hot kernel, (segment sums,) scatter (+ Adam)
+    const int mode = kFinSum | (adam_p ? kFinAdam : 0) | (adam_p && pack_next ? kFinPack : 0);
+    rc = launch_finish(st, k, g, lay.glayer_floats, lay.w2c, mode, gpart, grid, losspart, inv_B, nullptr, loss_out, grad_out, adam_p,
+                       adam_m, adam_v, adam, packed);
+    if (rc) return rc;
+    note_launches(RNVP_PROFILE_TRAIN, packed_valid ? 2 : 3);       // [pack,] hot kernel, finish
     return RNVP_OK;
 }
 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
-              void *ws, size_t ws_bytes, Seeds sd) {
-    return loss_grad_impl(st, k, params, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, nullptr,
-                          nullptr, nullptr, AdamK{}, sd);
+              void *ws, size_t ws_bytes, Seeds sd, bool packed_valid) {
+    return step_impl(st, k, params, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, nullptr, nullptr, nullptr,
+                     AdamK{}, sd, packed_valid, false);
 }
 
-// loss + gradient + Adam with the optimizer fused into the final scatter kernel (one launch and one
-// round trip of the gradient fewer than rnvp_loss_grad + rnvp_adam_step; same arithmetic, bit for bit)
+// loss + gradient + Adam with the optimizer (and the next step's re-pack) fused into the finish kernel: same arithmetic as
+// rnvp_loss_grad + rnvp_adam_step, bit for bit
 int train_step(hipStream_t st, const KShape &k, float *params, const float *x, const float *c,
                const int64_t *row_index, int64_t n, float inv_B, float *grad_buf, float *loss_out,
-               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes) {
-    return loss_grad_impl(st, k, params, x, c, row_index, n, inv_B, grad_buf, loss_out, ws, ws_bytes, params, exp_avg,
-                          exp_avg_sq, adam);
+               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes, bool packed_valid,
+               bool pack_next) {
+    return step_impl(st, k, params, x, c, row_index, n, inv_B, grad_buf, loss_out, ws, ws_bytes, params, exp_avg,
+                     exp_avg_sq, adam, Seeds{}, packed_valid, pack_next);
+}
+
+// second half of a DATA-PARALLEL step (after the all-reduce of [gradient | loss]): the batch loss out of the message, Adam
+// from the all-reduced flat gradient, and the re-pack for the next batch -- one launch (what rnvp_dp_finish_step + the next
+// step's pack launch did)
+int adam_pack(hipStream_t st, const KShape &k, float *params, float *grad, const float *loss_in, float *loss_out,
+              float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < train_workspace_bytes(k, 1)) return RNVP_EWORKSPACE;
+    const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
+    TrainPlan pl;
+    if (!plan_for(g, k.L, &pl)) return RNVP_EUNSUPPORTED;
+    return launch_finish(st, k, g, pl.glayer_floats, 0, kFinAdam | kFinPack, nullptr, 0, nullptr, 0.f, loss_in, loss_out, grad, params,
+                         exp_avg, exp_avg_sq, adam, static_cast<float *>(ws));
 }
 
 }  // namespace mfma

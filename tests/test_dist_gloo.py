@@ -68,6 +68,22 @@ def _install_oracle_backend():
         loss_out[0] = float(grad_loss[n])
         adam_step(params, grad_loss[:n], m, v, n, lr, b1, b2, eps, wd, step)
 
+    def fit_epoch_dp_cb(all_reduce, rank, world, shape, params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, m, v,
+                        lr, b1, b2, eps, wd, first_step, ws):
+        """stand-in for rnvp_fit_epoch_dp_cb (csrc/rnvp_dp.hip), the loop RealNVP.fit runs under a gloo process group: per
+        global batch this rank's contiguous share (remainder rows to the low ranks), gradients scaled by 1 / B_global, ONE
+        exchange of [gradient | loss], loss read-out + the identical Adam step.  (The C loop itself runs with two ranks in
+        tests/test_dist_gpu.py.)"""
+        P = params.numel()
+        for k, s0 in enumerate(range(0, n, batch_size)):
+            rows = min(batch_size, n - s0)
+            base, rem = divmod(rows, world)
+            lo = s0 + rank * base + min(rank, rem)
+            mine = base + (1 if rank < rem else 0)
+            loss_grad(shape, params, masks, x, c, perm[lo:lo + mine], mine, 1.0 / rows, grad_loss[:P], grad_loss[P:P + 1], ws)
+            all_reduce(grad_loss[:P + 1], P + 1)
+            dp_finish_step(params, grad_loss, m, v, P, lr, b1, b2, eps, wd, first_step + k, loss_hist[k:k + 1])
+
     def prior_normal(seed, row_offset, n_rows, d, z_out):
         z_out.copy_(torch.from_numpy(o.prior_normal(seed, row_offset, n_rows, d)))
 
@@ -78,6 +94,7 @@ def _install_oracle_backend():
 
     _hip.loss_grad, _hip.adam_step, _hip.train_step, _hip.inverse = loss_grad, adam_step, train_step, inverse
     _hip.fit_epoch, _hip.dp_finish_step, _hip.prior_normal, _hip.sample = fit_epoch, dp_finish_step, prior_normal, sample
+    _hip.fit_epoch_dp_cb = fit_epoch_dp_cb
     _hip.workspace_bytes = lambda shape, op, rows: 16
     for mod in (_engine, nflow, realnvp):
         mod.require_hip = lambda device: None
