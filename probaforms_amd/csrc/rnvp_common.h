@@ -20,7 +20,8 @@ constexpr float kLog2Pi = 1.8378770664093453f;   // ln(2*pi)
 struct KShape {
     int L, d, c, nh, act;
     int alt;                           // rnvp_shape::alt_masks (0 arbitrary, 1/2 alternating)
-    int prec;                          // rnvp_shape::precision (RNVP_PREC_*), RNVP_PREC_AUTO resolved
+    int prec;                          // rnvp_shape::precision (RNVP_PREC_*) for the FORWARD PHASE OF THE TRAINING kernels, RNVP_PREC_AUTO resolved
+    int prec_flow;                     // ... for the forward / inverse / sampling kernels, RNVP_PREC_AUTO resolved
     int prec_auto;                     // the caller left the choice to the library (RNVP_PREC_AUTO)
     int small_latency;                 // rnvp_shape::small_calls == RNVP_SMALL_LATENCY
     int family;                        // rnvp_shape::family (RNVP_FAMILY_*)
@@ -40,16 +41,21 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     if (s->alt_masks < 0 || s->alt_masks > 2) return RNVP_EINVAL;
     k->alt = s->alt_masks;
     if (s->precision < RNVP_PREC_AUTO || s->precision > RNVP_PREC_BX3) return RNVP_EINVAL;
-    // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) -- measured
-    // 1.3-1.4x there -- and in the d <= 16 geometry from seven hidden tiles on (hidden > 96: 3-7 % on every operation; at 96 the
-    // flows lose 2 %, at 32 19 %: scripts/bench_kernels.py with PREC=f32 / bx3, profiles/r03_precision_auto.txt)
     if (s->small_calls != RNVP_SMALL_INVARIANT && s->small_calls != RNVP_SMALL_LATENCY) return RNVP_EINVAL;
     k->small_latency = s->small_calls == RNVP_SMALL_LATENCY;
     if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM) return RNVP_EINVAL;
     k->family = s->family;
     k->prec_auto = s->precision == RNVP_PREC_AUTO;
-    k->prec = s->precision == RNVP_PREC_AUTO ? ((s->d > 16 || s->c > 4 || (s->n_hidden == 1 && s->hidden[0] > 96)) ? RNVP_PREC_BX3 : RNVP_PREC_F32)
-                                              : s->precision;
+    // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) -- measured
+    // 1.3-1.4x on every operation there.  In the d <= 16 geometry the split inputs cost 36 registers the f32 form does not need:
+    //   * the training kernel's forward phase takes them from seven hidden tiles on (hidden > 96: C2 step -1.5 .. -4.8 %,
+    //     profiles/r03_precision_auto.txt) -- its spills are cold (none inside a tile loop: profiles/r04_scratch_isa.txt);
+    //   * the flow kernels do NOT: at three row tiles per wave they spill 42-46 registers and move 3.5x the algorithmic bytes
+    //     (295 vs 88 MB per 1M rows) for 1-3 %, at two row tiles (no spill) they are 4 % slower than f32
+    //     (profiles/r04_flow_bx3_rows.txt): d <= 16 flows stay on the f32 kernels.
+    const bool wide = s->d > 16 || s->c > 4;
+    k->prec = s->precision == RNVP_PREC_AUTO ? ((wide || (s->n_hidden == 1 && s->hidden[0] > 96)) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
+    k->prec_flow = s->precision == RNVP_PREC_AUTO ? (wide ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;
     for (int i = 0; i <= s->n_hidden; ++i) {

@@ -319,7 +319,7 @@ size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
 // rnvp_shape.small_calls = RNVP_SMALL_LATENCY: short calls run the tile-split f32 kernel whatever `auto` would pick for
 // long ones (the bx3 kernels need whole stages per workgroup; an explicit precision = bx3 is honoured)
 static bool ts_flow(const KShape &k, const Geo &g, int64_t n) {
-    return RNVP_TILE_SPLIT && k.small_latency && n <= kTsFlowMaxRows && g.HT >= 3 && (k.prec != RNVP_PREC_BX3 || k.prec_auto);
+    return RNVP_TILE_SPLIT && k.small_latency && n <= kTsFlowMaxRows && g.HT >= 3 && (k.prec_flow != RNVP_PREC_BX3 || k.prec_auto);
 }
 
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
@@ -330,7 +330,7 @@ int forward(hipStream_t st, const KShape &k, const float *params, const float *x
     float *packed = static_cast<float *>(ws);
     float *part = reinterpret_cast<float *>(static_cast<char *>(ws) + flow_packed_bytes(k));
     int grid = 0, waves = kWaves, rc;
-    if (k.prec == RNVP_PREC_BX3 && !ts_flow(k, g, n)) {
+    if (k.prec_flow == RNVP_PREC_BX3 && !ts_flow(k, g, n)) {
         rc = bx3::forward(st, k, params, x, c, row_index, n, z_out, logdet_out, logp_out, logp_sum ? part : nullptr, &grid,
                           &waves, ws);
     } else {
@@ -351,7 +351,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const float *z
             int64_t n, float *x_out, void *ws, size_t ws_bytes) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
-    if (k.prec == RNVP_PREC_BX3 && !ts_flow(k, g, n)) return bx3::inverse(st, k, params, z, c, n, x_out, 0, 0, ws);
+    if (k.prec_flow == RNVP_PREC_BX3 && !ts_flow(k, g, n)) return bx3::inverse(st, k, params, z, c, n, x_out, 0, 0, ws);
     float *packed = static_cast<float *>(ws);
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;
@@ -364,7 +364,7 @@ int sample(hipStream_t st, const KShape &k, const float *params, const float *c,
            int64_t row0, float *x_out, void *ws, size_t ws_bytes) {
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_INVERSE, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0]);
-    if (k.prec == RNVP_PREC_BX3 && !ts_flow(k, g, n)) return bx3::inverse(st, k, params, nullptr, c, n, x_out, seed, row0, ws);
+    if (k.prec_flow == RNVP_PREC_BX3 && !ts_flow(k, g, n)) return bx3::inverse(st, k, params, nullptr, c, n, x_out, seed, row0, ws);
     float *packed = static_cast<float *>(ws);
     int rc = pack_weights(st, k, g, params, packed);
     if (rc) return rc;

@@ -19,97 +19,73 @@ RNVP_LAUNCH_DECL(2, 1) RNVP_LAUNCH_DECL(2, 0) RNVP_LAUNCH_DECL(4, 2) RNVP_LAUNCH
 namespace {
 
 // ---- stage 2: per-workgroup partial gradients -> flat reference-order gradient (+ Adam, + next step's fragments) --------
-// Where the packed gradient of one layer keeps parameter `idx` of net `net` (float offset inside the layer's record), or -1
-// when the masks make it dead (exactly zero, as in the reference).  pc = (l + alt) & 1; w2c: the launch wrote the compact
-// dW2 records of Dims::w2c (128 floats per hidden tile after the dW1 tiles).
-__device__ __forceinline__ int grad_loc(const KShape &k, const Geo &g, int NTI, int w2c, int pc, int net, int idx) {
-    const int NF = g.NF, CQ = g.CQ, HT = g.HT, OTL = g.OTL, h = k.nout[0], nin = k.d + k.c;
-    const int KSP = 4 * NTI;
-    const int tblk = w2c ? NTI * 256 + 128 : (NTI + OTL) * 256;      // floats of one hidden tile's record
-    const int netblock = HT * tblk;
-    int loc = -1;
-    if (idx < k.boff[0]) {                                     // W1 [h][d + c]
-        const int hid = idx / nin, col = idx - hid * nin;
-        int jn = -1;                                           // (k.d, k.c, h are the REAL sizes; NF, CQ the padded tiles)
-        if (col < k.d) {
-            const int qq = col / (2 * NF), e = col % (2 * NF);
-            if ((e & 1) == pc) jn = qq * KSP + (e >> 1);
-        } else if (CQ > 0) {
-            const int ci = col - k.d;
-            jn = (ci / CQ) * KSP + NF + (ci % CQ);
+// Where the gradient record of one hidden tile (layer of parity pc, net `net`) keeps a parameter: float offset inside the
+// tile's record, or -1 when the masks make it dead (exactly zero, as in the reference).  i: hidden unit inside the tile.
+// The record: NTI tiles of 256 (dW1 | db1: lane (q', jn & 15) x 4 hidden units), then dW2 -- OTL tiles of 256, or the compact
+// 128 floats of Dims::w2c.  NF and CQ are powers of two: shifts, no divisions.
+struct RecMap {
+    int NF, CQ, OTL, NTI, KSP, sh2, shc, w2c, d, c;
+    __device__ RecMap(const KShape &k, const Geo &g, int NTI_, int w2c_)
+        : NF(g.NF), CQ(g.CQ), OTL(g.OTL), NTI(NTI_), KSP(4 * NTI_), sh2(31 - __clz(2 * g.NF)), shc(g.CQ > 0 ? 31 - __clz(g.CQ) : 0),
+          w2c(w2c_), d(k.d), c(k.c) {}
+    __device__ int slot1(int i, int jn) const { return (jn >> 4) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3); }
+    __device__ int w1(int pc, int i, int col) const {              // W1[16 ht + i][col]
+        if (col < d) {
+            const int qq = col >> sh2, e = col & (2 * NF - 1);
+            return (e & 1) == pc ? slot1(i, qq * KSP + (e >> 1)) : -1;
         }
-        if (jn >= 0) {
-            const int i = hid & 15;
-            loc = net * netblock + (hid >> 4) * tblk + (jn >> 4) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
-        }
-    } else if (idx < k.woff[1]) {                              // b1 [h]: the ones column
-        const int hid = idx - k.boff[0], i = hid & 15, jn = NF + CQ;
-        loc = net * netblock + (hid >> 4) * tblk + (jn >> 4) * 256 + (16 * (i >> 2) + (jn & 15)) * 4 + (i & 3);
-    } else if (idx < k.boff[1]) {                              // W2 [d][h]
-        const int j = (idx - k.woff[1]) / h, hid = (idx - k.woff[1]) - j * h;
-        const int qo = j / (2 * NF), e = j % (2 * NF);
-        if ((e & 1) == 1 - pc) {
-            const int f = e >> 1;
-            int otl, io;
-            if (NF >= 4) { otl = f >> 2; io = 4 * qo + (f & 3); }
-            else { otl = 0; io = 4 * qo + 2 * net + f; }
-            const int i = hid & 15;
-            if (w2c) {      // column 2 qo + f of this net: block cb = col >> 2, kept by lane group 2 cb + (i >> 1) & 1 (layer_bwd)
-                const int col = 2 * qo + f, lane = 16 * (2 * (col >> 2) + ((i >> 1) & 1)) + 4 * (i >> 2) + (col & 3);
-                loc = net * netblock + (hid >> 4) * tblk + NTI * 256 + lane * 2 + (i & 1);
-            } else {
-                loc = net * netblock + (hid >> 4) * tblk + (NTI + otl) * 256 + (16 * (i >> 2) + io) * 4 + (i & 3);
-            }
-        }
-    } else {                                                   // b2 [d]
-        const int j = idx - k.boff[1];
-        const int qo = j / (2 * NF), e = j % (2 * NF);
-        if ((e & 1) == 1 - pc) {
-            const int f = e >> 1;
-            int ot, reg;
-            if (NF >= 4) { ot = net * OTL + (f >> 2); reg = f & 3; }
-            else { ot = 0; reg = 2 * net + f; }
-            loc = 2 * netblock + (ot * 4 + qo) * 4 + reg;
-        }
+        if (CQ == 0) return -1;
+        const int ci = col - d;
+        return slot1(i, (ci >> shc) * KSP + NF + (ci & (CQ - 1)));
     }
-    return loc;
-}
+    __device__ int b1(int i) const { return slot1(i, NF + CQ); }        // the ones column
+    __device__ int w2(int pc, int net, int i, int j) const {       // W2[j][16 ht + i]
+        const int qo = j >> sh2, e = j & (2 * NF - 1);
+        if ((e & 1) != 1 - pc) return -1;
+        const int f = e >> 1;
+        if (w2c) {      // column 2 qo + f of this net: block cb = col >> 2, kept by lane group 2 cb + (i >> 1) & 1 (layer_bwd)
+            const int col = 2 * qo + f, lane = 16 * (2 * (col >> 2) + ((i >> 1) & 1)) + 4 * (i >> 2) + (col & 3);
+            return NTI * 256 + lane * 2 + (i & 1);
+        }
+        const int otl = NF >= 4 ? f >> 2 : 0, io = NF >= 4 ? 4 * qo + (f & 3) : 4 * qo + 2 * net + f;
+        return (NTI + otl) * 256 + (16 * (i >> 2) + io) * 4 + (i & 3);
+    }
+    __device__ int b2(int pc, int net, int j) const {              // offset inside the layer's db2 record [ot][q][4]
+        const int qo = j >> sh2, e = j & (2 * NF - 1);
+        if ((e & 1) != 1 - pc) return -1;
+        const int f = e >> 1;
+        const int ot = NF >= 4 ? net * OTL + (f >> 2) : 0, reg = NF >= 4 ? f & 3 : 2 * net + f;
+        return (ot * 4 + qo) * 4 + reg;
+    }
+};
 
-// parameter source of pack_value for ONE hidden tile of one net, from the workgroup's LDS copy of the freshly updated
-// values: [16 hidden units][nin] of W1, 16 of b1, [d][16 hidden units] of W2 (k_train_finish)
+// parameter source of pack_slot for ONE hidden tile of one net, from the workgroup's LDS copy of the freshly updated
+// values: W1 half [16 hidden units][nin] then 16 of b1; W2 half [d][16 hidden units]; bias-2 workgroups [2 nets][d]
 struct TileParams {
     const float *pw;
-    int nin, ht;
+    int nin, ht, d;
     __device__ float w1(int, int hid, int col) const { return pw[(hid - 16 * ht) * nin + col]; }
     __device__ float b1(int, int hid) const { return pw[16 * nin + hid - 16 * ht]; }
-    __device__ float w2(int, int feat, int hid) const { return pw[16 * nin + 16 + feat * 16 + hid - 16 * ht]; }
-    __device__ float b2(int, int) const { return 0.f; }
-};
-// ... and for the second-Linear biases of a layer: [2 nets][d]
-struct Bias2Params {
-    const float *pw;
-    int d;
-    __device__ float w1(int, int, int) const { return 0.f; }
-    __device__ float b1(int, int) const { return 0.f; }
-    __device__ float w2(int, int, int) const { return 0.f; }
+    __device__ float w2(int, int feat, int hid) const { return pw[feat * 16 + hid - 16 * ht]; }
     __device__ float b2(int net, int feat) const { return pw[net * d + feat]; }
 };
 
 // ONE launch behind the training kernel (round 3 ran three: segment sums, scatter + Adam, and the next step's re-pack).
-// Workgroup b < 2 L HT owns the gradient record of (layer, net, hidden tile) = b -- the rows 16 ht .. 16 ht + 15 of W1 and b1
-// and the matching columns of W2 of that net; workgroups 2 L HT .. 2 L HT + L - 1 own the second-Linear biases of one layer
-// each; the last one adds the loss partials.  Stages, each optional (`mode`):
-//   kFinSum : add the record over the G per-workgroup partials of the training launch -- threads split into sub-groups, sub-group
-//             s adds partials s, s + nsub, ... in index order (eight loads in flight), the sub-sums are added in s order: a fixed
-//             order for a given launch geometry, no float atomics -- and scatter it into the flat gradient;
+// Every gradient record (layer, net, hidden tile) is served by TWO workgroups: half 0 owns rows 16 ht .. 16 ht + 15 of W1 and b1
+// (the record's dW1 | db1 tiles), half 1 the matching columns of W2 (its dW2 part); L more workgroups own the second-Linear biases
+// of one layer each; the last one adds the loss partials.  Stages, each optional (`mode`):
+//   kFinSum : add the workgroup's part of the record over the G per-workgroup partials of the training launch -- threads split into
+//             sub-groups, sub-group s adds partials s, s + nsub, ... in index order (eight loads in flight), the sub-sums are added
+//             in s order: a fixed order for a given launch geometry, no float atomics -- and scatter it into the flat gradient;
 //             without it the flat gradient is an INPUT (data parallel: the all-reduced message);
-//   kFinAdam: torch.optim.Adam on the record's parameters (realnvp.py:251);
-//   kFinPack: rewrite the packed fragments of exactly this hidden tile from the updated values (kept in LDS), so that the
-//             next batch's training kernel can start without a pack launch.
+//   kFinAdam: torch.optim.Adam on the workgroup's parameters (realnvp.py:251);
+//   kFinPack: rewrite the packed fragments that hold exactly these parameters from the updated values (kept in LDS), so that the
+//             next batch's training kernel starts without a pack launch.
 constexpr int kFinSum = 1, kFinAdam = 2, kFinPack = 4;
 constexpr int kFinThreads = 512;
-constexpr int kFinRecMax = 1536;                  // floats of the largest record: (NTI 4 + OTL 2) x 256 (d = 64)
-constexpr int kFinParMax = 16 * 80 + 16 + 64 * 16;  // LDS copy of a tile's parameters: d <= 64, cdim <= 16
+constexpr int kFinRecMax = 1024;                  // floats of the largest half record: NTI 4 x 256 (d = 64, cdim = 16)
+constexpr int kFinParMax = 16 * 81;               // LDS copy of a workgroup's parameters: 16 x (d + cdim + 1) <= 16 x 81, d x 16 <= 1024
+constexpr int kFinPer = 3;                        // parameters per thread: ceil(16 x 81 / 512)
 
 __global__ void __launch_bounds__(kFinThreads)
 k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, const float *__restrict__ gpart, int G,
@@ -120,7 +96,7 @@ k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, c
     __shared__ float pw[kFinParMax];
     const int t = threadIdx.x, b = blockIdx.x;
     const int HT = g.HT, nrec = k.L * 2 * HT;
-    if (b == nrec + k.L) {                  // the loss: partials added in a fixed order (one wave), or read out of the message
+    if (b == 2 * nrec + k.L) {              // the loss: partials added in a fixed order (one wave), or read out of the message
         if (t < 64 && loss_out) {
             if (mode & kFinSum) {
                 float a = 0.f;
@@ -133,103 +109,122 @@ k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, c
         }
         return;
     }
-    const bool bias2 = b >= nrec;
-    const int l = bias2 ? b - nrec : b / (2 * HT);
-    const int net = bias2 ? 0 : (b / HT) & 1, ht = bias2 ? 0 : b % HT;
+    const bool bias2 = b >= 2 * nrec;
+    const int r = b >> 1, half = bias2 ? 2 : b & 1;           // 0: W1 | b1, 1: W2, 2: the layer's b2
+    const int l = bias2 ? b - 2 * nrec : r / (2 * HT);
+    const int net = bias2 ? 0 : (r / HT) & 1, ht = bias2 ? 0 : r % HT;
     const int tblk = w2c ? NTI * 256 + 128 : (NTI + g.OTL) * 256, netblock = HT * tblk;
-    const int rec_off = bias2 ? 2 * netblock : net * netblock + ht * tblk;      // floats inside the layer's record
-    const int rec_n = bias2 ? g.NT2 * 16 : tblk;
+    // this workgroup's floats inside the layer's record
+    const int rec_off = bias2 ? 2 * netblock : net * netblock + ht * tblk + (half ? NTI * 256 : 0);
+    const int rec_n = bias2 ? g.NT2 * 16 : (half ? tblk - NTI * 256 : NTI * 256);
     const int pc = (l + k.alt) & 1;
     const int h = k.nout[0], nin = k.d + k.c, d = k.d;
-    if (mode & kFinSum) {
-        const int nf4 = rec_n / 4;
-        const size_t stride4 = (size_t)glayer_floats * k.L / 4;
-        for (int c0 = 0; c0 < nf4; c0 += kFinThreads) {
-            const int cols = nf4 - c0 < kFinThreads ? nf4 - c0 : kFinThreads;
-            const int nsub = kFinThreads / cols;
-            const int col = t % cols, sub = t / cols;
-            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-            if (sub < nsub) {
-                const f4 *src = reinterpret_cast<const f4 *>(gpart + (size_t)l * glayer_floats + rec_off) + c0 + col;
-                int bb = sub;
-                for (; bb + 7 * nsub < G; bb += 8 * nsub) {
-                    f4 v[8];
+    // the workgroup's parameters: gradient out of the record (or in from the all-reduced message), Adam, LDS copy for the re-pack.
+    // Up to kFinPer per thread; their loads (parameter, both moments) are issued BEFORE the partial sums are read, so that the
+    // two memory latencies of a small step overlap.
+    const RecMap map(k, g, NTI, w2c);
+    const int npar = half == 2 ? 2 * d : (half == 1 ? 16 * d : 16 * (nin + 1));
+    const int base_in_rec = half == 1 ? NTI * 256 : 0;      // rec[] starts at this workgroup's part
+    size_t pidx[kFinPer];
+    float ga[kFinPer], pv[kFinPer], mm[kFinPer], vv[kFinPer];
+    int locs[kFinPer];
+    bool live[kFinPer];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(bb + u * nsub) * stride4);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += v[u];
-                }
-                for (; bb < G; bb += nsub) acc += __builtin_nontemporal_load(src + (size_t)bb * stride4);
-            }
-            red[t] = acc;
-            __syncthreads();
-            if (t < cols) {
-                f4 a = red[t];
-                for (int s2 = 1; s2 < nsub; ++s2) a += red[s2 * cols + t];
-                *reinterpret_cast<f4 *>(rec + 4 * (c0 + t)) = a;
-            }
-            __syncthreads();
-        }
-    }
-    // the record's parameters: gradient out of the record (or in from the all-reduced message), Adam, LDS copy for the re-pack
-    const int npar = bias2 ? 2 * d : 16 * (nin + 1 + d);
-    for (int e = t; e < npar; e += kFinThreads) {
-        int pnet = net, idx, hid = 0;
-        if (bias2) {
-            pnet = e / d;
-            idx = k.boff[1] + (e - pnet * d);
+    for (int u = 0; u < kFinPer; ++u) {
+        const int e = t + u * kFinThreads;
+        live[u] = false; ga[u] = 0.f; pv[u] = 0.f; mm[u] = 0.f; vv[u] = 0.f; pidx[u] = 0; locs[u] = -1;
+        if (e >= npar) continue;
+        int pnet = net, idx, i = 0, loc;
+        if (half == 2) {
+            pnet = e >= d;
+            const int j = e - pnet * d;
+            idx = k.boff[1] + j;
+            loc = map.b2(pc, pnet, j);
+        } else if (half == 1) {
+            const int j = e >> 4;
+            i = e & 15;
+            idx = k.woff[1] + j * h + 16 * ht + i;
+            loc = map.w2(pc, net, i, j);
         } else if (e < 16 * nin) {
-            const int i = e / nin;
-            hid = 16 * ht + i;
-            idx = k.woff[0] + hid * nin + (e - i * nin);
-        } else if (e < 16 * nin + 16) {
-            hid = 16 * ht + (e - 16 * nin);
-            idx = k.boff[0] + hid;
+            i = e / nin;
+            const int col = e - i * nin;
+            idx = k.woff[0] + (16 * ht + i) * nin + col;
+            loc = map.w1(pc, i, col);
         } else {
-            const int ee = e - 16 * nin - 16, j = ee >> 4;
-            hid = 16 * ht + (ee & 15);
-            idx = k.woff[1] + j * h + hid;
+            i = e - 16 * nin;
+            idx = k.boff[0] + 16 * ht + i;
+            loc = map.b1(i);
         }
-        float val = 0.f;
-        if (hid < h) {
-            const size_t p = ((size_t)l * 2 + pnet) * k.npn + idx;
-            float a;
-            if (mode & kFinSum) {
-                const int loc = grad_loc(k, g, NTI, w2c, pc, pnet, idx);
-                a = loc >= 0 ? rec[loc - rec_off] : 0.f;
-                grad[p] = a;
-            } else {
-                a = grad[p];
+        if (16 * ht + i >= h) continue;                     // a padded hidden unit: no parameter behind it
+        live[u] = true;
+        pidx[u] = ((size_t)l * 2 + pnet) * k.npn + idx;
+        locs[u] = loc;
+        if (!(mode & kFinSum)) ga[u] = grad[pidx[u]];
+        if (mode & (kFinAdam | kFinPack)) pv[u] = params[pidx[u]];
+        if (mode & kFinAdam) { mm[u] = adam_m[pidx[u]]; vv[u] = adam_v[pidx[u]]; }
+    }
+    if (mode & kFinSum) {
+        const int nf4 = rec_n / 4;                          // <= 256
+        const size_t stride4 = (size_t)glayer_floats * k.L / 4;
+        const int nsub = kFinThreads / nf4;
+        const int col = t % nf4, sub = t / nf4;
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        if (sub < nsub) {
+            const f4 *src = reinterpret_cast<const f4 *>(gpart + (size_t)l * glayer_floats + rec_off) + col;
+            int bb = sub;
+            for (; bb + 7 * nsub < G; bb += 8 * nsub) {
+                f4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(bb + u * nsub) * stride4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
             }
+            for (; bb < G; bb += nsub) acc += __builtin_nontemporal_load(src + (size_t)bb * stride4);
+        }
+        red[t] = acc;
+        __syncthreads();
+        if (t < nf4) {
+            f4 a = red[t];
+            for (int s2 = 1; s2 < nsub; ++s2) a += red[s2 * nf4 + t];
+            *reinterpret_cast<f4 *>(rec + 4 * t) = a;
+        }
+        __syncthreads();
+    }
+    if (mode & kFinSum) {
+#pragma unroll
+        for (int u = 0; u < kFinPer; ++u) ga[u] = (live[u] && locs[u] >= 0) ? rec[locs[u] - base_in_rec] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kFinPer; ++u) {
+        const int e = t + u * kFinThreads;
+        if (e >= npar) continue;
+        if (live[u]) {
+            if (mode & kFinSum) grad[pidx[u]] = ga[u];
             if (mode & kFinAdam) {
-                float pv = params[p], mm = adam_m[p], vv = adam_v[p];
-                adam_one(pv, a, mm, vv, adam);
-                params[p] = pv; adam_m[p] = mm; adam_v[p] = vv;
-                val = pv;
-            } else if (mode & kFinPack) {
-                val = params[p];
+                adam_one(pv[u], ga[u], mm[u], vv[u], adam);
+                params[pidx[u]] = pv[u]; adam_m[pidx[u]] = mm[u]; adam_v[pidx[u]] = vv[u];
             }
         }
-        pw[e] = val;
+        pw[e] = pv[u];
     }
     if (!(mode & kFinPack)) return;
     __syncthreads();
     float *pk = packed + (size_t)l * g.layer_floats;
-    if (bias2) {
-        const Bias2Params src{pw, d};
-        for (int s2 = t; s2 < g.NT2 * 16; s2 += kFinThreads) pk[g.oB2 + s2] = pack_value(k, g, l, g.oB2 + s2, src);
+    const TileParams src{pw, nin, ht, d};
+    if (half == 2) {
+        for (int s2 = t; s2 < g.NT2 * 16; s2 += kFinThreads) pk[g.oB2 + s2] = pack_slot(k, g, pc, kPkB2, 0, 0, s2, src);
         return;
     }
-    const TileParams src{pw, nin, ht};
     const int T = net * HT + ht;
-    // every packed array is indexed [tile][...]: the slots of tile T, array by array
-    const int offs[9] = {g.oA1, g.oB1, g.oA2, g.oA2T, g.oA1T, g.oA2X, g.oA1X, g.oA1S, g.oA2TS};
-    const int pers[9] = {g.K4 * 256, 16, g.OTL * 256, g.OTL * 256, g.MTI * 256, g.NF == 2 ? 512 : 0, g.NF == 2 ? 512 : 0,
-                         g.NI1 * 256, g.NI2 * 256};
+    // the packed arrays that hold this workgroup's parameters, the slots of tile T of each
+    const int arrs[2][5] = {{kPkA1, kPkB1, kPkA1T, kPkA1X, kPkA1S}, {kPkA2, kPkA2T, kPkA2X, kPkA2TS, -1}};
 #pragma unroll
-    for (int arr = 0; arr < 9; ++arr) {
-        const int base = offs[arr] + T * pers[arr];
-        for (int s2 = t; s2 < pers[arr]; s2 += kFinThreads) pk[base + s2] = pack_value(k, g, l, base + s2, src);
+    for (int a = 0; a < 5; ++a) {
+        const int arr = arrs[half][a];
+        if (arr < 0) continue;
+        const int per = pack_per_tile(g, arr);
+        float *dst = pk + pack_offset(g, arr) + T * per;
+        for (int s2 = t; s2 < per; s2 += kFinThreads) dst[s2] = pack_slot(k, g, pc, arr, net, ht, s2, src);
     }
 }
 
@@ -288,7 +283,7 @@ static int launch_finish(hipStream_t st, const KShape &k, const Geo &g, int glay
                          int G, const float *losspart, float inv_B, const float *loss_in, float *loss_out, float *grad,
                          float *params, float *adam_m, float *adam_v, const AdamK &adam, float *packed) {
     const int NTI = (g.KS1 + 1 + 3) / 4;
-    const unsigned blocks = (unsigned)(k.L * 2 * g.HT + k.L + 1);
+    const unsigned blocks = (unsigned)(2 * k.L * 2 * g.HT + k.L + 1);       // two per gradient record, one per layer (b2), the loss
     hipLaunchKernelGGL(k_train_finish, dim3(blocks), dim3(kFinThreads), 0, st, k, g, NTI, glayer_floats, w2c, mode, gpart, G, losspart,
                        G * kWaves, inv_B, loss_in, loss_out, grad, params, adam_m, adam_v, adam, packed);
     RNVP_HIP_TRY(hipGetLastError());
