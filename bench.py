@@ -238,26 +238,25 @@ def secondary_configs(Xh, Ch, dev):
     m = CVAE(latent_dim=2, hidden=HIDDEN, batch_size=BATCH, n_epochs=1, lr=1e-3, noise_rng="device")
     m.fit(Xh[:BATCH], Ch[:BATCH])
     core = m._core
-    eps = torch.randn(BATCH, 2, device=dev); idx = torch.randperm(N_ROWS, device=dev)[:BATCH].contiguous()
+    K = 15                                                   # full batches per call
+    eps = torch.randn(K * BATCH, 2, device=dev); idx = torch.randperm(N_ROWS, device=dev)[:K * BATCH].contiguous()
     g = core.grads(); ws = core.workspace(BATCH)
-    def cvae_step(t):        # what CVAE.fit issues per batch on one GPU: loss + gradient + Adam, one library call
-        _hip.cvae_train_step(core.shape, core.sync(), X, C, idx, eps, BATCH, 1.0 / BATCH, 0.001, g[:core.P], g[core.P:core.P + 1],
-                             m.opt.exp_avg[:core.P], m.opt.exp_avg_sq[:core.P], 1e-3, 0.9, 0.999, 1e-8, 0.0, t, ws)
-    for t in range(3):
-        cvae_step(t + 1)
+    lossK = torch.zeros(K, device=dev)
+    def cvae_epoch(t):       # what CVAE.fit issues per epoch on one GPU: cvae_fit_epoch -- per batch the step kernel + one finish launch
+        _hip.cvae_fit_epoch(core.shape, core.sync(), X, C, idx, eps, K * BATCH, BATCH, 0.001, g[:core.P], lossK,
+                            m.opt.exp_avg[:core.P], m.opt.exp_avg_sq[:core.P], 1e-3, 0.9, 0.999, 1e-8, 0.0, t, ws)
+    cvae_epoch(1)
     torch.cuda.synchronize(dev)
     _hip.profile_enable(64)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    K = 20
     e0.record()
-    for t in range(K):
-        cvae_step(t + 4)
+    cvae_epoch(1 + K)
     e1.record(); torch.cuda.synchronize(dev)
     n_k, k_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
     _hip.profile_enable(0)
     flop_row = 3 * 2 * ((D + CDIM) * HIDDEN[0] + HIDDEN[0] * 4 + (2 + CDIM) * HIDDEN[0] + HIDDEN[0] * D)
     step_ms = e0.elapsed_time(e1) / K
-    out["cvae_c5"] = {"workload": "CVAE latent 2, hidden (128,), d=16 cond=4: loss+grad+Adam on 65536 rows, device resident",
+    out["cvae_c5"] = {"workload": "CVAE latent 2, hidden (128,), d=16 cond=4: loss+grad+Adam per 65536-row batch, 15 batches in one cvae_fit_epoch call (the call CVAE.fit makes), device resident",
                       "ms_per_step": step_ms, "rows_per_s": BATCH / (step_ms * 1e-3),
                       "kernel_ms": k_ms / max(n_k, 1), "useful_flop_per_row": flop_row,
                       "roofline_frac_f32_mfma": flop_row * BATCH / (k_ms / max(n_k, 1) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
@@ -586,6 +585,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # N > 1 self-check, after the clock stopped: every rank applied the identical Adam update to the identical all-reduced
+    # gradient, so the replicas must still hold the same bits -- a checksum of the flat parameter buffer (and the last batch
+    # loss) gathered over the ranks; the first multi-GPU run validates its own exchange this way
+    replicas_identical, rccl_ranks = None, 0
+    if dp:
+        chk = torch.stack([eng.flat.double().sum(), eng.flat.double().abs().sum(),
+                           (losses[n_steps - 1, nb - 1].double() if do_fit else torch.zeros((), dtype=torch.float64, device=dev))])
+        allchk = [torch.zeros_like(chk) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allchk, chk)
+        else:
+            allchk = [chk]
+        replicas_identical = bool(all(torch.equal(a, allchk[0]) for a in allchk))
+        rccl_ranks = world if comm is not None else 0
     n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
     n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
     # what the library launched for the timed region's last batch / sampling call (rnvp_last_dispatch: written by the launch
@@ -680,6 +693,7 @@ def main():
             "config": {"workload": "%s: RealNVP n=%d/GPU d=%d cond=%d L=%d hidden=%r; one step = %s"
                                    % (wl["label"], N_ROWS, D, CDIM, LAYERS, HIDDEN, step_text),
                        "global_batch": BATCH * world if do_fit else None, "parallelism": "dp%d" % world,
+                       "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
             "roofline": roof,
             "roofline_kernels": {

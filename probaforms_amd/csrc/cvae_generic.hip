@@ -296,12 +296,26 @@ int cvae_fit_epoch(void *stream, const cvae_shape *shape, float *params, const f
     if (resident::cvae_fits(k, shape->family, batch_size))
         return resident::cvae_fit_epoch(static_cast<hipStream_t>(stream), k, params, x, c, perm, eps, n, batch_size, kl_weight,
                                         loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, weight_decay, first_step);
+    // register-chained step kernel: the packed fragments live in the workspace for the whole call (packed before the first batch,
+    // re-packed by every step's finish kernel)
+    const bool chained = use_mfma(shape);
+    if (chained && (!workspace || workspace_bytes < cvae_workspace_bytes(shape, batch_size < n ? batch_size : n))) return RNVP_EWORKSPACE;
+    if (chained && !grad_buf) return RNVP_EINVAL;
+    bool packed_valid = false;
     int64_t kb = 0;
     for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++kb) {
         const int64_t rows = (n - s0 < batch_size) ? n - s0 : batch_size;
-        rc = cvae_train_step(stream, shape, params, x, c, perm + s0, eps + s0 * k.lat, rows, 1.0f / (float)rows, kl_weight, grad_buf,
-                             loss_hist + kb, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, weight_decay, first_step + kb, workspace,
-                             workspace_bytes);
+        if (chained) {
+            rc = cvae_mfma::train_step(static_cast<hipStream_t>(stream), shape, params, x, c, perm + s0, eps + s0 * k.lat, rows,
+                                       1.0f / (float)rows, kl_weight, grad_buf, loss_hist + kb, exp_avg, exp_avg_sq,
+                                       make_adam(lr, beta1, beta2, adam_eps, weight_decay, first_step + kb), workspace, workspace_bytes,
+                                       packed_valid, s0 + rows < n);
+            packed_valid = true;
+        } else {
+            rc = cvae_train_step(stream, shape, params, x, c, perm + s0, eps + s0 * k.lat, rows, 1.0f / (float)rows, kl_weight, grad_buf,
+                                 loss_hist + kb, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, weight_decay, first_step + kb, workspace,
+                                 workspace_bytes);
+        }
         if (rc) return rc;
     }
     return RNVP_OK;

@@ -38,8 +38,6 @@ using mfma::transpose16;
 using mfma::wave_lds_fence;
 using mfma::kTS;
 using mfma::kTanhScale;
-using mfma::kSeg;
-using mfma::k_sum_segments;
 
 #ifndef CVAE_R
 #define CVAE_R 4
@@ -91,14 +89,27 @@ CG make_cg(const cvae_shape *s) {
 }
 
 // ---- packing ----------------------------------------------------------------------------------------
-__device__ float pack_value(const CG &g, int idx, const float *__restrict__ p) {
-    const int ne = g.d + g.c, nd = g.lat + g.c, h = g.h;
-    auto W1e = [&](int hid, int col) { return (hid < h && col >= 0) ? p[g.fW1e + hid * ne + col] : 0.f; };
-    auto W1d = [&](int hid, int col) { return (hid < h && col >= 0) ? p[g.fW1d + hid * nd + col] : 0.f; };
-    auto Whead = [&](int og, int i, int hid) {
-        return (hid < h && i < g.lat) ? p[(og == 0 ? g.fWmu : g.fWls) + i * h + hid] : 0.f;
-    };
-    auto W2d = [&](int out, int hid) { return (hid < h && out < g.d) ? p[g.fW2d + out * h + hid] : 0.f; };
+// parameter source: the flat reference-order buffer (k_pack) ...
+struct FlatCvae {
+    const float *p;
+    const CG &g;
+    __device__ float w1e(int hid, int col) const { return p[g.fW1e + hid * (g.d + g.c) + col]; }
+    __device__ float b1e(int hid) const { return p[g.fb1e + hid]; }
+    __device__ float whead(int og, int i, int hid) const { return p[(og == 0 ? g.fWmu : g.fWls) + i * g.h + hid]; }
+    __device__ float bhead(int og, int i) const { return p[(og == 0 ? g.fbmu : g.fbls) + i]; }
+    __device__ float w1d(int hid, int col) const { return p[g.fW1d + hid * (g.lat + g.c) + col]; }
+    __device__ float b1d(int hid) const { return p[g.fb1d + hid]; }
+    __device__ float w2d(int out, int hid) const { return p[g.fW2d + out * g.h + hid]; }
+    __device__ float b2d(int j) const { return p[g.fb2d + j]; }
+};
+
+template <class Src>
+__device__ float pack_value(const CG &g, int idx, const Src &src) {
+    const int h = g.h;
+    auto W1e = [&](int hid, int col) { return (hid < h && col >= 0) ? src.w1e(hid, col) : 0.f; };
+    auto W1d = [&](int hid, int col) { return (hid < h && col >= 0) ? src.w1d(hid, col) : 0.f; };
+    auto Whead = [&](int og, int i, int hid) { return (hid < h && i < g.lat) ? src.whead(og, i, hid) : 0.f; };
+    auto W2d = [&](int out, int hid) { return (hid < h && out < g.d) ? src.w2d(out, hid) : 0.f; };
     if (idx < g.oB1E) {                                        // A1E [t][2][lane][4]: k-steps 0-3 x, 4 c
         const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8, k4 = rest & 1, t = rest >> 1;
         const int kk = 4 * k4 + e, q = lane >> 4, i = lane & 15, hid = 16 * t + i;
@@ -109,7 +120,7 @@ __device__ float pack_value(const CG &g, int idx, const float *__restrict__ p) {
     }
     if (idx < g.oA2E) {                                        // B1E [t][q][4]
         const int j = idx - g.oB1E, hid = 16 * (j >> 4) + (j & 15);
-        return hid < h ? kTanhScale * p[g.fb1e + hid] : 0.f;
+        return hid < h ? kTanhScale * src.b1e(hid) : 0.f;
     }
     if (idx < g.oA2ET) {                                       // A2E [t][og][lane][4 rho]  (4x4x1 heads)
         const int j = idx - g.oA2E, rho = j & 3, lane = (j >> 2) & 63, rest = j >> 8, og = rest & 1, t = rest >> 1;
@@ -128,7 +139,7 @@ __device__ float pack_value(const CG &g, int idx, const float *__restrict__ p) {
     }
     if (idx < g.oA2D) {                                        // B1D [t][q][4]
         const int j = idx - g.oB1D, hid = 16 * (j >> 4) + (j & 15);
-        return hid < h ? kTanhScale * p[g.fb1d + hid] : 0.f;
+        return hid < h ? kTanhScale * src.b1d(hid) : 0.f;
     }
     if (idx < g.oA2DT) {                                       // A2D [t][lane][4 rho]: A[i = out][k = q <-> hid 16t+4q+rho]
         const int j = idx - g.oA2D, rho = j & 3, lane = (j >> 2) & 63, t = j >> 8;
@@ -145,17 +156,17 @@ __device__ float pack_value(const CG &g, int idx, const float *__restrict__ p) {
     if (idx < g.oB2D) {                                        // BH [q][4]: b_mu[q], b_ls[q]
         const int j = idx - g.oBH, e = j & 3, q = j >> 2;
         if (q >= g.lat || e > 1) return 0.f;
-        return p[(e == 0 ? g.fbmu : g.fbls) + q];
+        return src.bhead(e, q);
     }
     {                                                          // B2D [q][4]
         const int j = idx - g.oB2D;
-        return j < g.d ? p[g.fb2d + j] : 0.f;
+        return j < g.d ? src.b2d(j) : 0.f;
     }
 }
 
 __global__ void __launch_bounds__(256) k_pack(CG g, const float *__restrict__ params, float *__restrict__ packed) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.packed_floats; t += gridDim.x * blockDim.x)
-        packed[t] = pack_value(g, t, params);
+        packed[t] = pack_value(g, t, FlatCvae{params, g});
 }
 
 // lane group q keeps element q of a 4-vector whose partial sums are spread over the 4 lane groups
@@ -584,53 +595,131 @@ k_cvae_mfma_mlp(CG g, const float *__restrict__ wp, const float *__restrict__ in
 // D-layout location of (row i of the 16-row M tile = hid & 15, column j) inside a 256-float block
 __device__ __forceinline__ int dloc(int hid, int col) { const int i = hid & 15; return (16 * (i >> 2) + col) * 4 + (i & 3); }
 
-__global__ void __launch_bounds__(256)
-k_unpack(CG g, const float *__restrict__ seg, int S, const float *__restrict__ losspart, int nloss, float inv_B,
-         float *__restrict__ grad, float *loss, float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= g.P) {
-        if (loss && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
-            const int lane = threadIdx.x - 192;
+// ---- stage 2: ONE launch behind the step kernel (round 3 ran three: segment sums, scatter + Adam, the next step's pack) ----
+// Workgroup t * 5 + kind owns one 256-float block of hidden tile t's gradient record -- kind 0: W1e, x columns; 1: W1e, condition
+// columns + b1e; 2: the two heads' weights; 3: W1d + b1d; 4: W2d -- workgroup 5 HT the head and output biases, the last one the
+// loss.  Stages as k_train_finish (rnvp_mfma_train.hip): sum the block over the G per-workgroup partials in a fixed order
+// (kFinSum), scatter into the flat gradient, Adam on exactly those parameters (kFinAdam), and re-pack the fragment slots that
+// hold them from the updated values kept in LDS (kFinPack), so that the next batch's step kernel needs no pack launch.
+constexpr int kFinSum = 1, kFinAdam = 2, kFinPack = 4;
+constexpr int kFinThreads = 512;
+
+// pack_value's parameter source for one workgroup's LDS copy (layouts: the `e` order of k_cvae_finish)
+struct BlockCvae {
+    const float *pw;
+    int t, d, c, lat;
+    __device__ float w1e(int hid, int col) const { return col < d ? pw[(hid - 16 * t) * d + col] : pw[(hid - 16 * t) * (c + 1) + col - d]; }
+    __device__ float b1e(int hid) const { return pw[(hid - 16 * t) * (c + 1) + c]; }
+    __device__ float whead(int og, int i, int hid) const { return pw[(og * lat + i) * 16 + hid - 16 * t]; }
+    __device__ float bhead(int og, int i) const { return pw[og * lat + i]; }
+    __device__ float w1d(int hid, int col) const { return pw[(hid - 16 * t) * (lat + c + 1) + col]; }
+    __device__ float b1d(int hid) const { return pw[(hid - 16 * t) * (lat + c + 1) + lat + c]; }
+    __device__ float w2d(int out, int hid) const { return pw[out * 16 + hid - 16 * t]; }
+    __device__ float b2d(int j) const { return pw[2 * lat + j]; }
+};
+
+__global__ void __launch_bounds__(kFinThreads)
+k_cvae_finish(CG g, int mode, const float *__restrict__ gpart, int G, const float *__restrict__ losspart, int nloss, float inv_B,
+              float *loss, float *grad, float *params, float *adam_m, float *adam_v, AdamK adam, float *packed) {
+    __shared__ __attribute__((aligned(16))) float rec[256];
+    __shared__ f4 red[kFinThreads];
+    __shared__ float pw[16 * 21];                 // the widest block: 16 hidden units x (d <= 16 | lat + c + 1 <= 9 | ...)
+    const int tix = threadIdx.x, b = blockIdx.x, HT = g.HT;
+    if (b == 5 * HT + 1) {
+        if (loss && tix < 64) {
             float a = 0.f;
-            for (int i = lane; i < nloss; i += 64) a += losspart[i];
+            for (int i = tix; i < nloss; i += 64) a += losspart[i];
             for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-            if (lane == 0) loss[0] = a * inv_B;
+            if (tix == 0) loss[0] = a * inv_B;
         }
         return;
     }
-    if (!grad) return;
-    const int h = g.h, ne = g.d + g.c, nd = g.lat + g.c;
-    int loc;
-    if (p < g.fb1e) {                                          // W1e [h][d + c]
-        const int hid = p / ne, col = p - hid * ne;
-        const int nt = col < g.d ? 0 : 1, cj = col < g.d ? col : 4 * (col - g.d);
-        loc = g.gEnc + ((hid >> 4) * 3 + nt) * 256 + dloc(hid, cj);
-    } else if (p < g.fWmu) {                                   // b1e: the ones column (tile 1, column 1)
-        const int hid = p - g.fb1e;
-        loc = g.gEnc + ((hid >> 4) * 3 + 1) * 256 + dloc(hid, 1);
-    } else if (p < g.fbmu) {                                   // W_mu / W_ls [lat][h]
-        const int j = p - g.fWmu, og = j >= g.lat * h, jj = j - og * g.lat * h, i = jj / h, hid = jj - i * h;
-        loc = g.gEnc + ((hid >> 4) * 3 + 2) * 256 + dloc(hid, 4 * i + og);
-    } else if (p < g.fW1d) {                                   // b_mu, b_ls
-        const int j = p - g.fbmu, og = j >= g.lat, i = j - og * g.lat;
-        loc = g.gBH + i * 4 + og;
-    } else if (p < g.fb1d) {                                   // W1d [h][lat + c]
-        const int j = p - g.fW1d, hid = j / nd, col = j - hid * nd;
-        const int cj = col < g.lat ? 4 * col : 4 * (col - g.lat) + 1;
-        loc = g.gDec + ((hid >> 4) * 2) * 256 + dloc(hid, cj);
-    } else if (p < g.fW2d) {                                   // b1d: ones column 2
-        const int hid = p - g.fb1d;
-        loc = g.gDec + ((hid >> 4) * 2) * 256 + dloc(hid, 2);
-    } else if (p < g.fb2d) {                                   // W2d [d][h]
-        const int j = p - g.fW2d, out = j / h, hid = j - out * h;
-        loc = g.gDec + ((hid >> 4) * 2 + 1) * 256 + dloc(hid, out);
-    } else {                                                   // b2d
-        loc = g.gB2D + (p - g.fb2d);
+    if (!(mode & kFinSum)) return;                // (cvae_loss_grad without gradients: only the loss block has work)
+    const bool misc = b == 5 * HT;
+    const int t = misc ? 0 : b / 5, kind = misc ? 5 : b - 5 * t;
+    const int rec_off = misc ? g.gBH : (kind < 3 ? g.gEnc + (t * 3 + kind) * 256 : g.gDec + (t * 2 + kind - 3) * 256);
+    const int rec_n = misc ? 32 : 256;
+    const int d = g.d, c = g.c, lat = g.lat, h = g.h, ne = d + c, nd = lat + c;
+    // this workgroup's parameters (at most one per thread): flat index, location inside the block; loads issued ahead of the sums
+    const int npar = kind == 0 ? 16 * d : kind == 1 ? 16 * (c + 1) : kind == 2 ? 2 * lat * 16 : kind == 3 ? 16 * (nd + 1)
+                     : kind == 4 ? d * 16 : 2 * lat + d;
+    int p = -1, loc = 0;
+    if (tix < npar) {
+        const int e = tix;
+        int hid = 0;
+        if (kind == 0) { const int i = e / d, col = e - i * d; hid = 16 * t + i; p = g.fW1e + hid * ne + col; loc = dloc(i, col); }
+        else if (kind == 1) {
+            const int i = e / (c + 1), cc = e - i * (c + 1); hid = 16 * t + i;
+            if (cc < c) { p = g.fW1e + hid * ne + d + cc; loc = dloc(i, 4 * cc); } else { p = g.fb1e + hid; loc = dloc(i, 1); }
+        } else if (kind == 2) {
+            const int og = e / (lat * 16), rem = e - og * lat * 16, li = rem >> 4, i = rem & 15; hid = 16 * t + i;
+            p = (og ? g.fWls : g.fWmu) + li * h + hid; loc = dloc(i, 4 * li + og);
+        } else if (kind == 3) {
+            const int i = e / (nd + 1), col = e - i * (nd + 1); hid = 16 * t + i;
+            if (col < nd) { p = g.fW1d + hid * nd + col; loc = dloc(i, col < lat ? 4 * col : 4 * (col - lat) + 1); }
+            else { p = g.fb1d + hid; loc = dloc(i, 2); }
+        } else if (kind == 4) {
+            const int out = e >> 4, i = e & 15; hid = 16 * t + i;
+            p = g.fW2d + out * h + hid; loc = dloc(i, out);
+        } else if (e < 2 * lat) {
+            const int og = e / lat, li = e - og * lat;
+            p = (og ? g.fbls : g.fbmu) + li; loc = li * 4 + og;
+        } else {
+            p = g.fb2d + e - 2 * lat; loc = 16 + e - 2 * lat;
+        }
+        if (hid >= h) p = -1;
     }
-    float a = 0.f;
-    for (int b = 0; b < S; ++b) a += seg[(size_t)b * g.gfloats + loc];
-    grad[p] = a;
-    if (adam_p) adam_one(adam_p[p], a, adam_m[p], adam_v[p], adam);       // fused optimizer (cvae_train_step)
+    float pv = 0.f, mm = 0.f, vv = 0.f;
+    if (p >= 0 && (mode & kFinAdam)) { pv = params[p]; mm = adam_m[p]; vv = adam_v[p]; }
+    {
+        const int nf4 = rec_n / 4, nsub = kFinThreads / nf4;
+        const int col = tix % nf4, sub = tix / nf4;
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        const f4 *src = reinterpret_cast<const f4 *>(gpart + rec_off) + col;
+        const size_t stride4 = (size_t)g.gfloats / 4;
+        int bb = sub;
+        for (; bb + 7 * nsub < G; bb += 8 * nsub) {
+            f4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(bb + u * nsub) * stride4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; bb < G; bb += nsub) acc += __builtin_nontemporal_load(src + (size_t)bb * stride4);
+        red[tix] = acc;
+        __syncthreads();
+        if (tix < nf4) {
+            f4 a = red[tix];
+            for (int s2 = 1; s2 < nsub; ++s2) a += red[s2 * nf4 + tix];
+            *reinterpret_cast<f4 *>(rec + 4 * tix) = a;
+        }
+        __syncthreads();
+    }
+    if (tix < npar) {
+        if (p >= 0) {
+            const float a = rec[loc];
+            grad[p] = a;
+            if (mode & kFinAdam) {
+                adam_one(pv, a, mm, vv, adam);
+                params[p] = pv; adam_m[p] = mm; adam_v[p] = vv;
+            }
+        }
+        pw[tix] = pv;
+    }
+    if (!(mode & kFinPack)) return;
+    __syncthreads();
+    const BlockCvae src{pw, t, d, c, lat};
+    // the packed arrays whose slots of tile t hold exactly this workgroup's parameters: (offset, floats) pairs
+    int off[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+    if (kind == 0) { off[0] = g.oA1E + (t * 2) * 256; cnt[0] = 256; }
+    else if (kind == 1) { off[0] = g.oA1E + (t * 2 + 1) * 256; cnt[0] = 256; off[1] = g.oB1E + t * 16; cnt[1] = 16; }
+    else if (kind == 2) { off[0] = g.oA2E + t * 512; cnt[0] = 512; off[1] = g.oA2ET + t * 256; cnt[1] = 256; }
+    else if (kind == 3) { off[0] = g.oA1D + t * 256; cnt[0] = 256; off[1] = g.oB1D + t * 16; cnt[1] = 16; off[2] = g.oA1DX + t * 256; cnt[2] = 256; }
+    else if (kind == 4) { off[0] = g.oA2D + t * 256; cnt[0] = 256; off[1] = g.oA2DT + t * 256; cnt[1] = 256; }
+    else { off[0] = g.oBH; cnt[0] = 32; }         // BH and B2D are adjacent
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int s2 = tix; s2 < cnt[a]; s2 += kFinThreads) packed[off[a] + s2] = pack_value(g, off[a] + s2, src);
 }
 
 size_t lds_bytes() { return ((size_t)kWaves * (kFT * 3 * 256 + 32) + (size_t)kWaves * 7 * 16 * kTS) * sizeof(float); }
@@ -645,21 +734,24 @@ bool supported(const cvae_shape *s) {
 size_t workspace_bytes(const cvae_shape *s) {
     const CG g = make_cg(s);
     return align_up((size_t)g.packed_floats * 4, 256) + align_up((size_t)kMaxGrid * g.gfloats * 4, 256) +
-           align_up((size_t)kSeg * g.gfloats * 4, 256) + align_up((size_t)kMaxGrid * kWaves * 4, 256);
+           align_up((size_t)kMaxGrid * kWaves * 4, 256);
 }
 
+// [pack] -> step kernel (per-workgroup partial gradients) -> k_cvae_finish (sum, scatter [, Adam [, re-pack]])
 static int loss_grad_impl(hipStream_t st, const cvae_shape *s, const float *params, const float *x, const float *c,
                           const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
-                          float *loss_out, void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam) {
+                          float *loss_out, void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam,
+                          bool packed_valid, bool pack_next) {
     if (!ws || ws_bytes < workspace_bytes(s)) return RNVP_EWORKSPACE;
     const CG g = make_cg(s);
     char *w = static_cast<char *>(ws);
     float *packed = reinterpret_cast<float *>(w); w += align_up((size_t)g.packed_floats * 4, 256);
     float *gpart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * g.gfloats * 4, 256);
-    float *seg = reinterpret_cast<float *>(w); w += align_up((size_t)kSeg * g.gfloats * 4, 256);
     float *losspart = reinterpret_cast<float *>(w);
-    hipLaunchKernelGGL(k_pack, dim3((g.packed_floats + 255) / 256), dim3(256), 0, st, g, params, packed);
-    RNVP_HIP_TRY(hipGetLastError());
+    if (!packed_valid) {
+        hipLaunchKernelGGL(k_pack, dim3((g.packed_floats + 255) / 256), dim3(256), 0, st, g, params, packed);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
     static std::atomic<uint64_t> attr{0};
     {
         const int arc = allow_big_lds(reinterpret_cast<const void *>(k_cvae_mfma), 160 * 1024, attr);
@@ -673,19 +765,9 @@ static int loss_grad_impl(hipStream_t st, const cvae_shape *s, const float *para
                            inv_B, klw, gpart, losspart, grad_out ? 1 : 0);
     }
     RNVP_HIP_TRY(hipGetLastError());
-    int S = 0;
-    if (grad_out) {
-        const size_t n4 = (size_t)g.gfloats / 4;
-        S = grid < kSeg ? grid : kSeg;
-        if (grid > kSeg) {
-            hipLaunchKernelGGL(k_sum_segments, dim3((unsigned)((n4 + 255) / 256), S), dim3(256), 0, st, gpart, grid, n4, seg);
-            RNVP_HIP_TRY(hipGetLastError());
-        } else {
-            seg = gpart;                          // up to kSeg workgroups ARE the segments
-        }
-    }
-    hipLaunchKernelGGL(k_unpack, dim3(g.P / 256 + 2), dim3(256), 0, st, g, seg, S, losspart, grid * kWaves, inv_B, grad_out,
-                       loss_out, adam_p, adam_m, adam_v, adam);
+    const int mode = grad_out ? (kFinSum | (adam_p ? kFinAdam : 0) | (adam_p && pack_next ? kFinPack : 0)) : 0;
+    hipLaunchKernelGGL(k_cvae_finish, dim3(5 * g.HT + 2), dim3(kFinThreads), 0, st, g, mode, gpart, grid, losspart, grid * kWaves, inv_B,
+                       loss_out, grad_out, adam_p, adam_m, adam_v, adam, packed);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }
@@ -694,16 +776,16 @@ int loss_grad(hipStream_t st, const cvae_shape *s, const float *params, const fl
               const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
               float *loss_out, void *ws, size_t ws_bytes) {
     return loss_grad_impl(st, s, params, x, c, row_index, eps, n, inv_B, klw, grad_out, loss_out, ws, ws_bytes, nullptr, nullptr,
-                          nullptr, AdamK{});
+                          nullptr, AdamK{}, false, false);
 }
 
-// loss + gradient + Adam with the optimizer fused into the final scatter kernel (one launch fewer than cvae_loss_grad +
-// rnvp_adam_step; the same arithmetic, bit for bit)
+// loss + gradient + Adam (+ the next step's re-pack) with the optimizer fused into the finish kernel: the same arithmetic as
+// cvae_loss_grad + rnvp_adam_step, bit for bit.  packed_valid / pack_next: as rnvp::mfma::train_step (cvae_fit_epoch's loop)
 int train_step(hipStream_t st, const cvae_shape *s, float *params, const float *x, const float *c, const int64_t *row_index,
                const float *eps, int64_t n, float inv_B, float klw, float *grad_buf, float *loss_out, float *exp_avg,
-               float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes) {
+               float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes, bool packed_valid, bool pack_next) {
     return loss_grad_impl(st, s, params, x, c, row_index, eps, n, inv_B, klw, grad_buf, loss_out, ws, ws_bytes, params, exp_avg,
-                          exp_avg_sq, adam);
+                          exp_avg_sq, adam, packed_valid, pack_next);
 }
 
 // encoder (mu, log_sigma) or decoder (x_rec) alone on the MFMA blocks; the packed weights go to the caller's workspace

@@ -157,7 +157,8 @@ AdamK make_adam(double lr, double beta1, double beta2, double eps, double wd, in
 namespace cvae_mfma {
 int train_step(hipStream_t st, const ::cvae_shape *s, float *params, const float *x, const float *c,
                const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_buf,
-               float *loss_out, float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes);
+               float *loss_out, float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes,
+               bool packed_valid = false, bool pack_next = false);
 }  // namespace cvae_mfma
 
 // ---- optimizer: rnvp_adam.hip -----------------------------------------------------------
