@@ -156,6 +156,19 @@ int rnvp_prior_normal(void *stream, uint64_t seed, int64_t row_offset, int64_t n
                       float *z_out);
 
 /*
+ * The REFERENCE's prior stream drawn on the device: exactly the values `torch.randn(count)` produces from a CPU generator
+ * whose Mersenne-Twister state is `mt_state` (nflow.py:141: prior.sample = randn on the global CPU generator).  mt_state
+ * [625] (device): the generator's 624 state words + the position of the next unread word (624 = block used up); advanced in
+ * place as the host draw would advance it, so the caller can hand it back to its generator.  z_out [count], count >= 16
+ * (torch draws smaller tensors another way: RNVP_EUNSUPPORTED); tail16 [16]: device scratch.  Restates torch's CPU kernel for
+ * contiguous float tensors (mt19937, 24-bit uniforms, 16-element Box-Muller blocks on the cephes polynomials of avx_mathfun.h
+ * with the multiply-adds torch's build contracts); the Python host checks it against torch.randn itself once per process and
+ * keeps the host draw if another torch build disagrees.  One workgroup walks the twister's 624-word blocks (the recurrence is
+ * serial between blocks), a second kernel applies the Box-Muller blocks.
+ */
+int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count, float *z_out, float *tail16);
+
+/*
  * rnvp_prior_normal fused into rnvp_inverse: x_out = g(z(seed, row_offset + r, .), c[r]) for the n_rows
  * rows of this call; on the MFMA path z is drawn in registers and never written to memory.
  * Replaces nflow.py:141-143 as a whole.  Same workspace as RNVP_OP_INVERSE.

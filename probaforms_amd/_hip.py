@@ -128,6 +128,7 @@ _SIGNATURES = {
     "rnvp_forward_logprob": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_inverse": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "rnvp_prior_normal": (C.c_int, [_VP, _U64, _I64, _I64, C.c_int32, _VP]),
+    "rnvp_prior_normal_torch_cpu": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "rnvp_sample": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _I64, _U64, _I64, _VP, _VP, _SZ]),
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
     "rnvp_loss_grad_zseed": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP, _SZ]),
@@ -276,6 +277,13 @@ def prior_normal(seed, row_offset, n_rows, d, z_out):
     """z_out[r][j] = N(0,1)(seed, row_offset + r, j): the counter-based 'device' prior (rnvp_prior_normal)"""
     _call("rnvp_prior_normal", (int(seed) & 0xFFFFFFFFFFFFFFFF, int(row_offset), int(n_rows), int(d),
                                 _ptr(z_out, torch.float32, "z_out")))
+
+
+def prior_normal_torch_cpu(mt_state, count, z_out, tail16):
+    """z_out[:count] = torch.randn(count) of the CPU generator whose twister state is mt_state ([625] int32 on the device:
+    624 words + position), advanced in place (rnvp_prior_normal_torch_cpu)"""
+    _call("rnvp_prior_normal_torch_cpu", (_ptr(mt_state, torch.int32, "mt_state"), int(count), _ptr(z_out, torch.float32, "z_out"),
+                                          _ptr(tail16, torch.float32, "tail16")))
 
 
 def sample(shape, params, masks, c, n_rows, seed, row_offset, x_out, ws):

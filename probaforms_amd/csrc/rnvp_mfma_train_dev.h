@@ -92,6 +92,10 @@ constexpr bool kW2cNoNs = RNVP_W2C_NO_NS != 0;
 #ifndef RNVP_TRAIN_WIDE
 #define RNVP_TRAIN_WIDE 1
 #endif
+// RNVP_TRAIN_WIDE8: the wide form for d in (32, 64] as well
+#ifndef RNVP_TRAIN_WIDE8
+#define RNVP_TRAIN_WIDE8 0
+#endif
 constexpr bool kTrainWide = RNVP_TRAIN_WIDE != 0;
 #ifndef RNVP_TRAIN_BXF
 #define RNVP_TRAIN_BXF 1
@@ -533,23 +537,37 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             if (r == 0) slot[FT * TBLK + (ot * 4 + q) * 4 + u] = v;
                         }
                 }
+                // A workgroup's second and later row groups ADD to its partial: the old values are requested here, ahead of the
+                // barrier, so that their memory latency (an L2 miss: the partials of all workgroups exceed the L2) overlaps the wait
+                // for the slowest wave instead of following it -- C4 spent 17 % of the kernel in this read-modify-write
+                // (profiles/r04_stamp_c4.txt)
+                constexpr int FTH = NS ? 256 : WV * 64;                  // threads that add one net's slots
+                constexpr int KIT = (FT * TBLK / 4 + FTH - 1) / FTH;
+                const int fl_t0 = (ht / FT) * FT, fl_n4 = (ht + 1 - fl_t0) * TBLK / 4;
+                const int fl_i0 = NS ? (tid & 255) : tid;
+                f4 *fl_dst = reinterpret_cast<f4 *>(gp_layer + (size_t)(NS ? (tid >> 8) : net) * netblock + (size_t)fl_t0 * TBLK);
+                f4 oldv[KIT];
+#pragma unroll
+                for (int u = 0; u < KIT; ++u) {
+                    oldv[u] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (!first && fl_i0 + u * FTH < fl_n4) oldv[u] = fl_dst[fl_i0 + u * FTH];
+                }
                 __syncthreads();
                 STAMP_ADD(stp.fb1, t0);
                 if constexpr (NS) {
                     // both nets flush together: threads 0..255 add the slots of waves 0..3 (t net), threads
                     // 256..511 those of waves 4..7 (s net), each in wave order
-                    const int t0 = (ht / FT) * FT, ntile = ht + 1 - t0;
-                    const int nfl4 = ntile * TBLK / 4;
-                    const int fr = tid >> 8, ft = tid & 255;
-                    f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)fr * netblock + (size_t)t0 * TBLK);
+                    const int fr = tid >> 8;
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)fr * WV * SLOT);
-                    for (int i = ft; i < nfl4; i += 256) {
-                        f4 old = f4{0.f, 0.f, 0.f, 0.f};
-                        if (!first) old = dst[i];           // in flight while the slots are read
-                        f4 v = s0[i];
 #pragma unroll
-                        for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];
-                        dst[i] = first ? v : v + old;
+                    for (int u = 0; u < KIT; ++u) {
+                        const int i = fl_i0 + u * FTH;
+                        if (i < fl_n4) {
+                            f4 v = s0[i];
+#pragma unroll
+                            for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];
+                            fl_dst[i] = first ? v : v + oldv[u];
+                        }
                     }
                     if (last_tile && tid < NT2 * 16) {
                         const int i = WV * SLOT + FT * TBLK + tid;                  // db2 lives in the s waves' slots
@@ -561,17 +579,16 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     }
                 } else
                 {   // slot0 + slot1 + slot2 + slot3 (wave order) -> the workgroup's partial in global memory
-                    const int t0 = (ht / FT) * FT, ntile = ht + 1 - t0;
-                    const int nfl4 = ntile * TBLK / 4;
-                    f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)net * netblock + (size_t)t0 * TBLK);
                     const f4 *s0 = reinterpret_cast<const f4 *>(lds);
-                    for (int i = tid; i < nfl4; i += WV * 64) {
-                        f4 old = f4{0.f, 0.f, 0.f, 0.f};
-                        if (!first) old = dst[i];           // in flight while the slots are read
-                        f4 v = s0[i];
 #pragma unroll
-                        for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
-                        dst[i] = first ? v : v + old;
+                    for (int u = 0; u < KIT; ++u) {
+                        const int i = fl_i0 + u * FTH;
+                        if (i < fl_n4) {
+                            f4 v = s0[i];
+#pragma unroll
+                            for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
+                            fl_dst[i] = first ? v : v + oldv[u];
+                        }
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
                         const int i = FT * TBLK + tid;
@@ -1127,7 +1144,7 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     }
     lay->w2c = DM::template w2c<0>() ? 1 : 0;
     lay->glayer_floats = p0.glayer_floats;
-    if constexpr (kTrainWide && NF == 4) {       // d in (16, 32]: two 4-wave workgroups per CU become one 8-wave workgroup
+    if constexpr (kTrainWide && (NF == 4 || (NF == 8 && RNVP_TRAIN_WIDE8))) {       // d > 16: two 4-wave workgroups per CU become one 8-wave workgroup
         const size_t lds_wide = kWideWaves * per_wave * sizeof(float);
         if (ngroups > 256 && lds_wide <= 160 * 1024) {
             const int64_t rows_wide = (int64_t)kWideWaves * R * 16;

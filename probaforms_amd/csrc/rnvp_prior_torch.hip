@@ -1,0 +1,183 @@
+// rnvp_prior_torch.hip -- the REFERENCE's prior stream on the device: `torch.randn(count)` of a CPU generator
+// (/root/reference/probaforms/models/nflow.py:141 `X = self.prior.sample((n,))`: MultivariateNormal(0, I).sample = randn on the
+// global CPU generator), bit for bit, without the host's serial 2 ns per number.
+//
+// What torch's CPU kernel does for a contiguous float tensor of at least 16 elements (ATen native/cpu/DistributionTemplates.h
+// normal_fill_AVX2: the path taken on AVX2 and AVX-512 hosts alike):
+//   1. data[i] = (mt19937() & 0xFFFFFF) * 2^-24 for every i                        -- one 32-bit draw per element;
+//   2. per block of 16: u1 = 1 - data[j], u2 = data[j + 8] (j < 8);  radius = sqrt(-2 log256_ps(u1)),
+//      theta = float(2 pi) u2;  (sin, cos) = sincos256_ps(theta);  data[j] = radius cos,  data[j + 8] = radius sin;
+//   3. a count that is not a multiple of 16 redraws the LAST 16 elements from 16 fresh draws.
+// log256_ps / sincos256_ps (avx_mathfun.h) are float32 polynomials: restated below operation by operation, with the multiply-adds
+// torch's build contracts, they give the host's bits (pinned on the CPU side by oracle/prior_torch_oracle.c against torch.randn,
+// on the device by tests/test_prior_torch.py against torch.randn).  The Mersenne Twister itself is serial between its 624-word
+// blocks; inside a block the recurrence x[k + 624] = x[k + 397] ^ twist(x[k], x[k + 1]) has three phases of up to 227 independent
+// words: one workgroup, state double buffered in LDS, three barriers per block.
+// The Python host (probaforms_amd/models/nflow.py HostStreamOnDevice) validates this path against torch.randn on a scratch
+// generator once per process and keeps the host draw when they differ (another torch build).
+#include "rnvp_common.h"
+
+namespace rnvp {
+namespace {
+
+constexpr int kN = 624, kM = 397;
+constexpr int kMtThreads = 256;
+
+__device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v, uint32_t far) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// state [625]: 624 words + the position of the next unread word (624: the block is used up).  Writes `count` uniforms to
+// out and `tail` more (0 or 16) to tail_out; leaves the advanced state behind.
+__global__ void __launch_bounds__(kMtThreads)
+k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *__restrict__ out, float *__restrict__ tail_out) {
+    __shared__ uint32_t S[2][kN];
+    const int t = threadIdx.x;
+    for (int i = t; i < kN; i += kMtThreads) S[0][i] = state[i];
+    int pos = (int)state[kN];
+    int cur = 0;
+    __syncthreads();
+    const int64_t total = count + tail;
+    int64_t done = 0;
+    while (done < total) {
+        if (pos >= kN) {
+            const uint32_t *o = S[cur];
+            uint32_t *nw = S[cur ^ 1];
+            // words 0..226: every input is from the old block
+            if (t < kN - kM) nw[t] = twist(o[t], o[t + 1], o[t + kM]);
+            __syncthreads();
+            // words 227..453: the far input is a word of the new block (k - 227)
+            if (t < kN - kM) nw[t + (kN - kM)] = twist(o[t + (kN - kM)], o[t + (kN - kM) + 1], nw[t]);
+            __syncthreads();
+            // words 454..622 likewise; word 623 wraps around to the new word 0
+            if (t < kN - 1 - 2 * (kN - kM)) {
+                const int k = 2 * (kN - kM) + t;
+                nw[k] = twist(o[k], o[k + 1], nw[k - (kN - kM)]);
+            } else if (t == kN - 1 - 2 * (kN - kM)) {
+                nw[kN - 1] = twist(o[kN - 1], nw[0], nw[kM - 1]);
+            }
+            __syncthreads();
+            cur ^= 1;
+            pos = 0;
+        }
+        const int64_t left = total - done;
+        const int m = (int)((int64_t)(kN - pos) < left ? (kN - pos) : left);
+        for (int i = t; i < m; i += kMtThreads) {
+            const float u = (float)(temper(S[cur][pos + i]) & 0xffffffu) * 5.9604644775390625e-08f;       // 2^-24: exact
+            const int64_t g = done + i;
+            if (g < count) out[g] = u; else tail_out[g - count] = u;
+        }
+        pos += m;
+        done += m;
+    }
+    __syncthreads();
+    for (int i = t; i < kN; i += kMtThreads) state[i] = S[cur][i];
+    if (t == 0) state[kN] = (uint32_t)pos;
+}
+
+// ---- log256_ps / sincos256_ps of ATen/native/cpu/avx_mathfun.h (cephes single-precision polynomials), one lane -----------------
+// Plain float32 arithmetic; every fmaf() below is a multiply-add that GCC contracts in torch's build of that header (-mfma: the
+// FIRST multiplication feeding an addition is fused), everything else stays a separately rounded multiply / add (contraction is
+// switched off for these functions).  oracle/prior_torch_oracle.c holds the same statements for the CPU and is pinned against
+// torch.randn bit for bit (tests/test_prior_torch.py).
+__device__ __forceinline__ float log_ps(float x) {          // x in [2^-24, 1]
+#pragma clang fp contract(off)
+    uint32_t xi = __float_as_uint(x);
+    int32_t imm0 = (int32_t)(xi >> 23);
+    xi = (xi & ~0x7f800000u) | 0x3f000000u;
+    x = __uint_as_float(xi);
+    imm0 -= 0x7f;
+    float e = (float)imm0 + 1.0f;
+    const bool mask = x < 0.707106781186547524f;
+    const float tmp = mask ? x : 0.0f;
+    x = x - 1.0f;
+    e = e - (mask ? 1.0f : 0.0f);
+    x = x + tmp;
+    const float z = x * x;
+    float y = 7.0376836292E-2f;
+    y = fmaf(y, x, -1.1514610310E-1f); y = fmaf(y, x, 1.1676998740E-1f); y = fmaf(y, x, -1.2420140846E-1f);
+    y = fmaf(y, x, 1.4249322787E-1f); y = fmaf(y, x, -1.6668057665E-1f); y = fmaf(y, x, 2.0000714765E-1f);
+    y = fmaf(y, x, -2.4999993993E-1f); y = fmaf(y, x, 3.3333331174E-1f);
+    y = y * x;
+    y = fmaf(y, z, e * -2.12194440e-4f);
+    y = fmaf(-z, 0.5f, y);
+    x = x + y;
+    return fmaf(e, 0.693359375f, x);
+}
+
+__device__ __forceinline__ void sincos_ps(float x, float *s, float *c) {        // x >= 0
+#pragma clang fp contract(off)
+    float y = x * 1.27323954473516f;
+    int32_t imm2 = (int32_t)y;
+    imm2 = (imm2 + 1) & ~1;
+    y = (float)imm2;
+    const uint32_t sign_bit_sin = ((uint32_t)(imm2 & 4)) << 29;
+    const bool poly_mask = (imm2 & 2) == 0;
+    x = fmaf(y, -0.78515625f, x); x = fmaf(y, -2.4187564849853515625e-4f, x); x = fmaf(y, -3.77489497744594108e-8f, x);
+    const uint32_t sign_bit_cos = ((uint32_t)(~(imm2 - 2) & 4)) << 29;
+    const float z = x * x;
+    float yc = 2.443315711809948E-005f;
+    yc = fmaf(yc, z, -1.388731625493765E-003f); yc = fmaf(yc, z, 4.166664568298827E-002f);
+    yc = yc * z;
+    yc = fmaf(yc, z, -(z * 0.5f));
+    yc = yc + 1.0f;
+    float ys = -1.9515295891E-4f;
+    ys = fmaf(ys, z, 8.3321608736E-3f); ys = fmaf(ys, z, -1.6666654611E-1f);
+    ys = ys * z;
+    ys = fmaf(ys, x, x);
+    const float xs = poly_mask ? ys : yc, xc = poly_mask ? yc : ys;
+    *s = __uint_as_float(__float_as_uint(xs) ^ sign_bit_sin);
+    *c = __uint_as_float(__float_as_uint(xc) ^ sign_bit_cos);
+}
+
+// one thread per (block of 16, j < 8): the pair data[16 b + j], data[16 b + j + 8]; with a tail, the last 16 elements come from
+// the 16 extra uniforms instead (and the main blocks do not write them)
+__global__ void __launch_bounds__(256)
+k_normal_fill_16(float *__restrict__ data, int64_t count, const float *__restrict__ tail_u) {
+#pragma clang fp contract(off)
+    const int64_t nblk = count / 16;
+    const bool has_tail = (count % 16) != 0;
+    const int64_t pairs = (nblk + (has_tail ? 1 : 0)) * 8;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = p >> 3;
+        const int j = (int)(p & 7);
+        const bool tl = b == nblk;                     // the redrawn last 16
+        const float ua = tl ? tail_u[j] : data[16 * b + j], ub = tl ? tail_u[j + 8] : data[16 * b + j + 8];
+        const float u1 = 1.0f - ua;
+        const float radius = sqrtf(-2.0f * log_ps(u1));
+        const float theta = 6.283185307179586f * ub;                        // float(2 pi) * u2
+        float sn, cs;
+        sincos_ps(theta, &sn, &cs);
+        const float za = fmaf(radius * cs, 1.0f, 0.0f), zb = fmaf(radius * sn, 1.0f, 0.0f);     // fmadd(radius cos, std, mean): -0 -> +0
+        const int64_t ia = tl ? count - 16 + j : 16 * b + j, ib = ia + 8;
+        const int64_t keep_below = has_tail ? count - 16 : count;       // main blocks leave the redrawn region alone
+        if (tl || ia < keep_below) data[ia] = za;
+        if (tl || ib < keep_below) data[ib] = zb;
+    }
+}
+
+}  // namespace
+}  // namespace rnvp
+
+extern "C" int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count, float *z_out, float *tail16) {
+    if (count < 16) return RNVP_EUNSUPPORTED;          // torch takes another path (a cached double-precision Box-Muller) there
+    if (!mt_state || !z_out || !tail16) return RNVP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tail = (count % 16) ? 16 : 0;
+    hipLaunchKernelGGL(rnvp::k_mt19937_uniform, dim3(1), dim3(rnvp::kMtThreads), 0, st, mt_state, count, tail, z_out, tail16);
+    RNVP_HIP_TRY(hipGetLastError());
+    const int64_t pairs = (count / 16 + (tail ? 1 : 0)) * 8;
+    int64_t blocks = (pairs + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rnvp::k_normal_fill_16, dim3((unsigned)blocks), dim3(256), 0, st, z_out, count, tail16);
+    RNVP_HIP_TRY(hipGetLastError());
+    return RNVP_OK;
+}

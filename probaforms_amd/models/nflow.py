@@ -7,6 +7,8 @@ layers is not evaluated layer by layer: the whole stack runs as one fused HIP ke
 (probaforms_amd/csrc) through ``FlowEngine``.
 """
 import math
+import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -72,7 +74,105 @@ class StandardNormalPrior:
             z = torch.empty((n, self.var_size), dtype=torch.float32, device=self.device)
             _hip.prior_normal(self.next_seed() if seed is None else seed, row_offset, n, self.var_size, z)
             return z.reshape(shape)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        if n >= 16 and HostStreamOnDevice.usable(self.device):
+            return HostStreamOnDevice(self.device).randn(shape)   # the same values, drawn on the device
         return torch.randn(shape).to(self.device)          # host generator: the reference's CPU stream
+
+
+class HostStreamOnDevice:
+    """`torch.randn` of a CPU generator, drawn ON THE DEVICE with the same bits (rnvp_prior_normal_torch_cpu): the reference's
+    prior stream (nflow.py:141) without the host's serial 2 ns per number.
+
+    A draw copies the generator's Mersenne-Twister state to the device (2.5 KB), lets the library walk it there (one workgroup
+    for the twister, all of them for torch's 16-element Box-Muller blocks), and writes the advanced state back into the
+    generator afterwards -- the generator ends exactly where `torch.randn` would have left it, so everything drawn later
+    (by this class or by torch) is unchanged.  Several draws can be chained on the device (`begin` / `draw` / `end`) with one
+    state round trip.
+
+    The library restates what THIS torch build's CPU kernel computes (mt19937, 24-bit uniforms, 16-element Box-Muller blocks on
+    avx_mathfun.h's polynomials with the multiply-adds its compiler contracted); another build could differ, so
+    `usable(device)` draws 4117 numbers both ways from a scratch generator once per process and device and compares values and
+    final states bit for bit; on any difference the callers keep the host draw."""
+
+    _ok = {}
+    _lock = threading.Lock()
+
+    @staticmethod
+    def _unpack(gen):
+        import numpy as np
+        st = gen.get_state().numpy()
+        if st.size != 5056:
+            raise RuntimeError("unknown CPU generator state layout (%d bytes)" % st.size)
+        left = int(st[8:12].view(np.int32)[0]); nxt = int(st[16:24].view(np.uint64)[0])
+        words = st[24:24 + 624 * 8].view(np.uint64).astype(np.uint32)
+        pos = 624 if left == 1 else nxt
+        if not (0 <= pos <= 624) or (left != 1 and left + nxt != 625):
+            raise RuntimeError("inconsistent CPU generator state (left %d, next %d)" % (left, nxt))
+        return st, np.concatenate([words, np.array([pos], np.uint32)]).view(np.int32)
+
+    @staticmethod
+    def _pack(gen, st, mt):
+        import numpy as np
+        mt = mt.view(np.uint32)
+        pos = int(mt[624])
+        new = st.copy()
+        new[8:12] = np.array([1 if pos == 624 else 625 - pos], np.int32).view(np.uint8)
+        new[16:24] = np.array([pos], np.uint64).view(np.uint8)
+        new[24:24 + 624 * 8] = mt[:624].astype(np.uint64).view(np.uint8)
+        gen.set_state(torch.from_numpy(new))
+
+    def __init__(self, device, generator=None):
+        self.device = torch.device(device)
+        self.gen = torch.default_generator if generator is None else generator
+        self._st = None
+
+    def begin(self):
+        st, mt = self._unpack(self.gen)
+        self._st = st
+        self._mt = torch.from_numpy(mt.copy()).to(self.device)
+        self._tail = torch.empty(16, dtype=torch.float32, device=self.device)
+        return self
+
+    def draw(self, out):
+        """out (contiguous float32 device tensor, numel >= 16) <- the generator's next out.numel() normals"""
+        _hip.prior_normal_torch_cpu(self._mt, out.numel(), out, self._tail)
+        return out
+
+    def end(self):
+        """hand the advanced state back to the generator (waits for the draws)"""
+        self._pack(self.gen, self._st, self._mt.cpu().numpy())
+        self._st = None
+
+    def randn(self, shape):
+        z = torch.empty(shape, dtype=torch.float32, device=self.device)
+        self.begin(); self.draw(z); self.end()
+        return z
+
+    @classmethod
+    def usable(cls, device):
+        device = torch.device(device)
+        if device.type != "cuda" or os.environ.get("RNVP_HOST_PRIOR_ON_DEVICE", "1") == "0":
+            return False
+        key = device.index
+        with cls._lock:
+            if key not in cls._ok:
+                ok = False
+                try:
+                    g1 = torch.Generator(); g1.manual_seed(20240717)
+                    torch.rand(100, generator=g1)                       # start inside a block
+                    g2 = torch.Generator(); g2.set_state(g1.get_state())
+                    ref = torch.randn(4117, generator=g1)               # not a multiple of 16: the redrawn tail, 6 twists
+                    got = cls(device, g2).randn((4117,)).cpu()
+                    ok = bool(torch.equal(ref, got)) and bool(torch.equal(g1.get_state(), g2.get_state()))
+                    if ok:                                              # and a second call continues the stream
+                        ok = bool(torch.equal(torch.randn(32, generator=g1), cls(device, g2).randn((32,)).cpu()))
+                except Exception:
+                    ok = False
+                cls._ok[key] = ok
+            return cls._ok[key]
 
 
 def row_chunks(n, rows):
@@ -259,7 +359,10 @@ class NormalizingFlow(nn.Module):
         NB, cap = 3, rows + 15
         out = torch.empty((n, d), dtype=torch.float32, pin_memory=True)
         zdev = [torch.empty((cap, d), dtype=torch.float32, device=dev) for _ in range(NB)]
-        zpin = [torch.empty((cap, d), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if host_rng else None
+        # the reference's stream: drawn on the device with the host generator's bits where that is validated (HostStreamOnDevice),
+        # on its own stream so that the twister's serial walk overlaps the inverse kernels and the downloads; else on the host
+        hs = HostStreamOnDevice(dev).begin() if (host_rng and HostStreamOnDevice.usable(dev)) else None
+        zpin = [torch.empty((cap, d), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if (host_rng and hs is None) else None
         stage_c = cdim > 0 and Cn is not None
         cdev = [torch.empty((cap, cdim), dtype=torch.float32, device=dev) for _ in range(NB)] if stage_c else None
         cpin = [torch.empty((cap, cdim), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if stage_c else None
@@ -269,24 +372,34 @@ class NormalizingFlow(nn.Module):
         ev_in = [torch.cuda.Event() for _ in range(NB)]
         ev_k = [torch.cuda.Event() for _ in range(NB)]
         ev_out = [torch.cuda.Event() for _ in range(NB)]
+        gen = torch.cuda.Stream(dev) if hs is not None else None
+        ev_gen = [torch.cuda.Event() for _ in range(NB)] if hs is not None else None
         h2d.wait_stream(cur)
+        if gen is not None:
+            gen.wait_stream(cur)
         for k, (lo, m) in enumerate(row_chunks(n, rows)):
             i = k % NB
             if k >= NB:
                 ev_out[i].synchronize()                 # buffer set i is free again (its D2H has landed)
-            if host_rng:
+            if hs is not None:
+                with torch.cuda.stream(gen):
+                    hs.draw(zdev[i][:m])                # the global CPU generator's next m * d normals, made on the device
+                    ev_gen[i].record(gen)
+            elif host_rng:
                 torch.randn((m, d), out=zpin[i][:m])    # global CPU generator: the reference's stream
             if stage_c:
                 # numpy's single-threaded copy/cast (float32 rounding = torch's): torch's CPU copy_ wakes
                 # its whole thread pool per call, measured 5 ms per 8 MB chunk on a 256-core host
                 np.copyto(cpin_np[i][:m], Cn[lo:lo + m], casting="unsafe")
             with torch.cuda.stream(h2d):
-                if host_rng:
+                if zpin is not None:
                     zdev[i][:m].copy_(zpin[i][:m], non_blocking=True)
                 if stage_c:
                     cdev[i][:m].copy_(cpin[i][:m], non_blocking=True)
                 ev_in[i].record(h2d)
             cur.wait_event(ev_in[i])
+            if hs is not None:
+                cur.wait_event(ev_gen[i])
             cc = None if cdim == 0 else (cdev[i][:m] if stage_c else Cd[lo:lo + m])
             if host_rng:
                 eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
@@ -299,4 +412,7 @@ class NormalizingFlow(nn.Module):
                 ev_out[i].record(d2h)
         d2h.synchronize()
         cur.wait_stream(d2h)
+        if hs is not None:
+            cur.wait_stream(gen)
+            hs.end()                                    # the generator ends where the host draws would have left it
         return out.numpy()
