@@ -12,7 +12,8 @@
 // torch's build contracts, they give the host's bits (pinned on the CPU side by oracle/prior_torch_oracle.c against torch.randn,
 // on the device by tests/test_prior_torch.py against torch.randn).  The Mersenne Twister itself is serial between its 624-word
 // blocks; inside a block the recurrence x[k + 624] = x[k + 397] ^ twist(x[k], x[k + 1]) has three phases of up to 227 independent
-// words: one workgroup, state double buffered in LDS, three barriers per block.
+// words, each needing only the same thread's previous result besides words of the old block: one workgroup, state double
+// buffered in LDS, ONE barrier per block.
 // The Python host (probaforms_amd/models/nflow.py HostStreamOnDevice) validates this path against torch.randn on a scratch
 // generator once per process and keeps the host draw when they differ (another torch build).
 #include "rnvp_common.h"
@@ -35,10 +36,39 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
     return y;
 }
 
+__device__ __forceinline__ float uniform24(uint32_t word) {
+    return (float)(temper(word) & 0xffffffu) * 5.9604644775390625e-08f;        // (x & (2^24 - 1)) * 2^-24: exact
+}
+
+// One block step: thread t < 227 forms the new words t, 227 + t and 454 + t (thread 169: word 623) -- each needs the thread's OWN
+// previous result as its far operand (new[k - 227]) and otherwise only words of the OLD block, so the three dependent phases of a
+// block run register to register without a barrier; word 623 also needs the new word 0, which its thread recomputes.
+__device__ __forceinline__ void twist_block(const uint32_t *o, uint32_t *nw, int t, uint32_t &a, uint32_t &b, uint32_t &c) {
+    constexpr int D = kN - kM;            // 227
+    if (t < D) {
+        a = twist(o[t], o[t + 1], o[t + kM]);
+        b = twist(o[D + t], o[D + t + 1], a);
+        nw[t] = a;
+        nw[D + t] = b;
+        if (t < kN - 1 - 2 * D) {
+            c = twist(o[2 * D + t], o[2 * D + t + 1], b);
+            nw[2 * D + t] = c;
+        } else if (t == kN - 1 - 2 * D) {            // word 623: its neighbour is the NEW word 0, its far word the new word 396 = b
+            const uint32_t n0 = twist(o[0], o[1], o[kM]);
+            c = twist(o[kN - 1], n0, b);
+            nw[kN - 1] = c;
+        }
+    }
+}
+
 // state [625]: 624 words + the position of the next unread word (624: the block is used up).  Writes `count` uniforms to
-// out and `tail` more (0 or 16) to tail_out; leaves the advanced state behind.
+// out and `tail` more (0 or 16) to tail_out -- as RAW 32-bit words (tempering and the conversion to a 24-bit uniform are left to
+// the parallel kernel below: this one is a single workgroup and bound by its instruction count); leaves the advanced state
+// behind.  Whole blocks that land in `out` go straight from the registers that formed them (one barrier per block); the partial
+// blocks at either end go through LDS.
 __global__ void __launch_bounds__(kMtThreads)
 k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *__restrict__ out, float *__restrict__ tail_out) {
+    constexpr int D = kN - kM;
     __shared__ uint32_t S[2][kN];
     const int t = threadIdx.x;
     for (int i = t; i < kN; i += kMtThreads) S[0][i] = state[i];
@@ -48,22 +78,24 @@ k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *
     const int64_t total = count + tail;
     int64_t done = 0;
     while (done < total) {
-        if (pos >= kN) {
-            const uint32_t *o = S[cur];
-            uint32_t *nw = S[cur ^ 1];
-            // words 0..226: every input is from the old block
-            if (t < kN - kM) nw[t] = twist(o[t], o[t + 1], o[t + kM]);
-            __syncthreads();
-            // words 227..453: the far input is a word of the new block (k - 227)
-            if (t < kN - kM) nw[t + (kN - kM)] = twist(o[t + (kN - kM)], o[t + (kN - kM) + 1], nw[t]);
-            __syncthreads();
-            // words 454..622 likewise; word 623 wraps around to the new word 0
-            if (t < kN - 1 - 2 * (kN - kM)) {
-                const int k = 2 * (kN - kM) + t;
-                nw[k] = twist(o[k], o[k + 1], nw[k - (kN - kM)]);
-            } else if (t == kN - 1 - 2 * (kN - kM)) {
-                nw[kN - 1] = twist(o[kN - 1], nw[0], nw[kM - 1]);
+        if (pos >= kN && done + kN <= count) {           // a whole block for `out`
+            uint32_t a = 0, b = 0, c = 0;
+            twist_block(S[cur], S[cur ^ 1], t, a, b, c);
+            float *dst = out + done;
+            if (t < D) {                                 // raw words: the parallel kernel tempers and converts them
+                dst[t] = __uint_as_float(a);
+                dst[D + t] = __uint_as_float(b);
+                if (t < kN - 1 - 2 * D) dst[2 * D + t] = __uint_as_float(c);
+                else if (t == kN - 1 - 2 * D) dst[kN - 1] = __uint_as_float(c);
             }
+            __syncthreads();
+            cur ^= 1;
+            done += kN;                                  // pos stays at 624: the block is used up
+            continue;
+        }
+        if (pos >= kN) {
+            uint32_t a, b, c;
+            twist_block(S[cur], S[cur ^ 1], t, a, b, c);
             __syncthreads();
             cur ^= 1;
             pos = 0;
@@ -71,7 +103,7 @@ k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *
         const int64_t left = total - done;
         const int m = (int)((int64_t)(kN - pos) < left ? (kN - pos) : left);
         for (int i = t; i < m; i += kMtThreads) {
-            const float u = (float)(temper(S[cur][pos + i]) & 0xffffffu) * 5.9604644775390625e-08f;       // 2^-24: exact
+            const float u = __uint_as_float(S[cur][pos + i]);
             const int64_t g = done + i;
             if (g < count) out[g] = u; else tail_out[g - count] = u;
         }
@@ -138,29 +170,31 @@ __device__ __forceinline__ void sincos_ps(float x, float *s, float *c) {        
     *c = __uint_as_float(__float_as_uint(xc) ^ sign_bit_cos);
 }
 
-// one thread per (block of 16, j < 8): the pair data[16 b + j], data[16 b + j + 8]; with a tail, the last 16 elements come from
-// the 16 extra uniforms instead (and the main blocks do not write them)
+// one thread per (block of 16, j < 8): the pair data[16 b + j], data[16 b + j + 8].  tail_only = 0: the count / 16 whole blocks
+// (with a tail, the elements from count - 16 on are left alone: they are redrawn); tail_only = 1 (a SECOND launch, after the first
+// has read everything it needs): the last 16 elements from the 16 extra words.
 __global__ void __launch_bounds__(256)
-k_normal_fill_16(float *__restrict__ data, int64_t count, const float *__restrict__ tail_u) {
+k_normal_fill_16(float *__restrict__ data, int64_t count, const float *__restrict__ tail_u, int tail_only) {
 #pragma clang fp contract(off)
     const int64_t nblk = count / 16;
     const bool has_tail = (count % 16) != 0;
-    const int64_t pairs = (nblk + (has_tail ? 1 : 0)) * 8;
+    const int64_t pairs = tail_only ? 8 : nblk * 8;
+    const int64_t keep_below = has_tail ? count - 16 : count;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = p >> 3;
         const int j = (int)(p & 7);
-        const bool tl = b == nblk;                     // the redrawn last 16
-        const float ua = tl ? tail_u[j] : data[16 * b + j], ub = tl ? tail_u[j + 8] : data[16 * b + j + 8];
+        // (the twister kernel left raw words: temper, keep 24 bits, scale -- uniform_real_distribution<float>)
+        const float ua = uniform24(__float_as_uint(tail_only ? tail_u[j] : data[16 * b + j]));
+        const float ub = uniform24(__float_as_uint(tail_only ? tail_u[j + 8] : data[16 * b + j + 8]));
         const float u1 = 1.0f - ua;
         const float radius = sqrtf(-2.0f * log_ps(u1));
         const float theta = 6.283185307179586f * ub;                        // float(2 pi) * u2
         float sn, cs;
         sincos_ps(theta, &sn, &cs);
         const float za = fmaf(radius * cs, 1.0f, 0.0f), zb = fmaf(radius * sn, 1.0f, 0.0f);     // fmadd(radius cos, std, mean): -0 -> +0
-        const int64_t ia = tl ? count - 16 + j : 16 * b + j, ib = ia + 8;
-        const int64_t keep_below = has_tail ? count - 16 : count;       // main blocks leave the redrawn region alone
-        if (tl || ia < keep_below) data[ia] = za;
-        if (tl || ib < keep_below) data[ib] = zb;
+        const int64_t ia = tail_only ? count - 16 + j : 16 * b + j, ib = ia + 8;
+        if (tail_only || ia < keep_below) data[ia] = za;
+        if (tail_only || ib < keep_below) data[ib] = zb;
     }
 }
 
@@ -174,10 +208,14 @@ extern "C" int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int
     const int tail = (count % 16) ? 16 : 0;
     hipLaunchKernelGGL(rnvp::k_mt19937_uniform, dim3(1), dim3(rnvp::kMtThreads), 0, st, mt_state, count, tail, z_out, tail16);
     RNVP_HIP_TRY(hipGetLastError());
-    const int64_t pairs = (count / 16 + (tail ? 1 : 0)) * 8;
+    const int64_t pairs = (count / 16) * 8;
     int64_t blocks = (pairs + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(rnvp::k_normal_fill_16, dim3((unsigned)blocks), dim3(256), 0, st, z_out, count, tail16);
+    hipLaunchKernelGGL(rnvp::k_normal_fill_16, dim3((unsigned)blocks), dim3(256), 0, st, z_out, count, tail16, 0);
     RNVP_HIP_TRY(hipGetLastError());
+    if (tail) {         // the redrawn last 16 overlap the last whole block's inputs: after it, in stream order
+        hipLaunchKernelGGL(rnvp::k_normal_fill_16, dim3(1), dim3(64), 0, st, z_out, count, tail16, 1);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
     return RNVP_OK;
 }
