@@ -38,8 +38,10 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_
 // Fragment value for out tile m, k-step ks, lane (q, i): forward W_k[16m + i][4ks + q]; transposed W_k[4ks + q][16m + i]
 // (for k == 0 only the x columns: C gets no gradient).  First Linear: x column j is multiplied by mask[l][j].
 // Layout of one Linear's fragments: out tiles in blocks of MB = 2 (then one of 1; MB = 1 throughout for fewer than 8 tiles), a block stored
-// [k-step][tile in block][lane] with the k-steps padded to a multiple of 4 (zeros), so that the kernel's group of
-// 4 k-steps x MB tiles is MB * 4 loads at constant offsets from one base.  Blocks go round-robin to the waves.
+// [group of 4 k-steps][tile in block][lane][k-step in group] with the k-steps padded to a multiple of 4 (zeros), so that the
+// kernel's group of 4 k-steps x MB tiles is MB 16-byte loads at constant offsets from one base (round 4: one dwordx4 per tile and
+// group instead of four dword loads -- a quarter of the vector-memory instructions, whole 1-KiB lines through the L1).  Blocks go
+// round-robin to the waves.
 // tiles per block of a Linear with MT out tiles: 2 where that still gives every wave a block, else 1
 __host__ __device__ __forceinline__ int block_tiles(int MT) { return MT >= 2 * kW ? 2 : 1; }
 
@@ -49,10 +51,11 @@ __device__ __forceinline__ void block_decode(int o, int MT, int KSp, int *m, int
     const int nb = MT / MB;                       // full blocks; a last single tile follows when MB == 2 and MT is odd
     if (o < nb * MB * per) { m0 = MB * (o / (MB * per)); oo = o % (MB * per); }
     else { m0 = nb * MB; oo = o - nb * MB * per; MB = 1; }
-    *lane = oo & 63;
-    const int rest = oo >> 6;
+    // inside a block: [group of 4 k-steps][tile][lane][k-step in group] -- a lane's four k-steps of one tile are ONE 16-byte load
+    *lane = (oo >> 2) & 63;
+    const int rest = oo >> 8;
     *m = m0 + rest % MB;
-    *ks = rest / MB;
+    *ks = 4 * (rest / MB) + (oo & 3);
 }
 
 __global__ void __launch_bounds__(256)
@@ -105,19 +108,18 @@ __device__ __forceinline__ void linear_mb(const float *__restrict__ fblk, int m0
             for (int e = 0; e < 4; ++e) { const int o = 16 * (m0 + t) + 4 * q + e; acc[t][e] = o < nout ? bias[o] : 0.f; }
         }
     }
-    const float *fa = fblk + lane;                 // + ((ks + u) * MB + t) * 64
+    const float *fa = fblk + lane * 4;             // + ((ks / 4) * MB + t) * 256: a lane's four k-steps of tile t
     const float *fb = in + q * RS + r;             // + (ks + u) * 4 * RS
-    float a0[MB][4], b0[4], a1[MB][4], b1[4], a2[MB][4], b2[4];
-    auto fetch = [&](float (&a)[MB][4], float (&b)[4], int ks) {
+    f4 a0[MB], a1[MB], a2[MB];
+    float b0[4], b1[4], b2[4];
+    auto fetch = [&](f4 (&a)[MB], float (&b)[4], int ks) {
         const float *pa = fa + ks * MB * 64, *pb = fb + ks * 4 * RS;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int t = 0; t < MB; ++t) a[t] = *reinterpret_cast<const f4 *>(pa + t * 256);
 #pragma unroll
-            for (int t = 0; t < MB; ++t) a[t][u] = pa[(u * MB + t) * 64];
-            b[u] = pb[u * 4 * RS];
-        }
+        for (int u = 0; u < 4; ++u) b[u] = pb[u * 4 * RS];
     };
-    auto mul = [&](const float (&a)[MB][4], const float (&b)[4]) {
+    auto mul = [&](const f4 (&a)[MB], const float (&b)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll

@@ -198,3 +198,49 @@ def test_fit_epoch_reports_what_bench_labels():
     assert got["gemm1_fwd"] == "bx3"
     assert got["launches"] == 2                  # training kernel + finish (sum, Adam, re-pack): the pack launch ran once, before the first batch
     assert torch.isfinite(hist).all()
+
+
+REPACK_CASES = [
+    # (L, d, c, h, n, batch): every register-chained training variant, several steps in ONE rnvp_fit_epoch call
+    (8, 16, 4, 128, 3 * 65536 + 777, 65536),      # C2: net-split kernel, ragged tail
+    (8, 16, 4, 128, 2 * 70000, 70000),            # row-parallel (compact dW2)
+    (8, 16, 4, 128, 5 * 32, 32),                  # tile split at the reference's default batch
+    (3, 16, 0, 40, 3 * 5000, 5000),               # no condition (NF 2, CQ 0), padded hidden tiles
+    (12, 32, 8, 256, 2 * 40000 + 100, 40000),     # C3: wide kernel
+    (4, 32, 8, 64, 3 * 9000, 9000),               # NF 4 net-split / row-parallel
+    (8, 64, 16, 128, 2 * 20000, 20000),           # C4's geometry (NF 8)
+    (3, 5, 3, 40, 4 * 64, 64),                    # the reference's own test widths (d = 5, cdim = 3): padded d, cdim, hidden (40 units: not LDS-resident)
+]
+
+
+@pytest.mark.parametrize("L,d,c,h,n,batch", REPACK_CASES)
+def test_fit_epoch_repack_equals_a_loop_of_train_steps_bit_for_bit(L, d, c, h, n, batch):
+    """rnvp_fit_epoch packs the weight fragments ONCE and lets every step's finish kernel re-pack what Adam updated;
+    rnvp_train_step packs at the head of every call.  Same kernels otherwise: parameters, both Adam moments and the batch losses
+    must agree bit for bit after several steps -- a stale or misplaced fragment would change the second step's gradient."""
+    from probaforms_amd import _hip
+    shape = _hip.RnvpShape.make(L, d, c, (h,), "tanh", alt_masks=1)
+    P = _hip.param_count(shape)
+    gen = torch.Generator(device="cuda").manual_seed(L * 1000 + d + n)
+    p0 = (torch.rand(P, device="cuda", generator=gen) - 0.5) * min(0.6, 3.0 / np.sqrt(h + d + c))
+    x = torch.randn(n, d, device="cuda", generator=gen)
+    cc = torch.randn(n, c, device="cuda", generator=gen) if c else None
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    ws = torch.empty(_hip.workspace_bytes(shape, _hip.OP_TRAIN, batch), dtype=torch.uint8, device="cuda")
+    nb = (n + batch - 1) // batch
+    # (a) one library call for the epoch
+    pa = p0.clone(); ma = torch.zeros(P, device="cuda"); va = torch.zeros(P, device="cuda"); ga = torch.empty(P, device="cuda")
+    la = torch.zeros(nb, device="cuda")
+    _hip.fit_epoch(shape, pa, None, x, cc, perm, n, batch, ga, la, ma, va, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, ws)
+    assert _hip.last_dispatch(_hip.PROFILE_TRAIN)["launches"] == (2 if nb > 1 else 3)
+    # (b) the same batches, one rnvp_train_step call each
+    pb = p0.clone(); mb = torch.zeros(P, device="cuda"); vb = torch.zeros(P, device="cuda"); gb = torch.empty(P, device="cuda")
+    lb = torch.zeros(nb, device="cuda")
+    for k in range(nb):
+        lo = k * batch; rows = min(batch, n - lo)
+        _hip.train_step(shape, pb, None, x, cc, perm[lo:lo + rows].contiguous(), rows, 1.0 / rows, gb, lb[k:k + 1], mb, vb,
+                        1e-3, 0.9, 0.999, 1e-8, 0.01, k + 1, ws)
+    torch.cuda.synchronize()
+    assert torch.isfinite(la).all() and torch.isfinite(pa).all()
+    assert torch.equal(la, lb) and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(pa, p0)
