@@ -56,8 +56,8 @@ BATCH = 65_536
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # split-bf16 GEMM1 (precision 'bx3'): six bf16 products per f32 product on the dense bf16 MFMA peak (16x the f32 one)
 BX3_EFFECTIVE_TFLOPS = 16.0 * F32_MFMA_PEAK_TFLOPS / 6.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")             # the C2 step (this command, default workload)
-TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r03_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic_pmc.json")             # the C2 step (this command, default workload)
+TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r04_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
 
 
 def mixed_bound_seconds_per_row(d, c, hidden, L, passes=1):
@@ -135,10 +135,9 @@ def pmc_traffic(kernel_prefix, traffic_file=None):
         return None
     if d.get("csrc_hash") != csrc_hash():
         return None
-    for k, v in d.get("kernels", {}).items():
-        if k.startswith(kernel_prefix):
-            return float(v["hbm_bytes_per_launch"])
-    return None
+    # several instantiations share a prefix (the ragged batch runs another row-tile count): the one with the most launches
+    hits = [(v.get("launches", 0), float(v["hbm_bytes_per_launch"])) for k, v in d.get("kernels", {}).items() if k.startswith(kernel_prefix)]
+    return max(hits)[1] if hits else None
 
 
 def cpu_baseline(X, C, rows=4 * BATCH):
@@ -450,8 +449,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)      # ~0.53 s of timed GPU work at C2 (20 steps left the driver's 1 Hz sampler nothing to see)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-level", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",

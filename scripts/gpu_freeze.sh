@@ -3,10 +3,11 @@
 # one-wave split-GEMM1 variant librnvp_hip_bxv.so when it has been built), flow-kernel PMC for C2 / C4, the microbenchmarks, the
 # single-rank data-parallel A/B.  The bench line itself (which reads the traffic file) is a second gpurun call AFTER the results
 # were copied into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /root/repo; mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt; cat gpurun_out/${TAG}_gpu_tests.txt
 bash scripts/gpu_micro.sh $TAG > gpurun_out/${TAG}_micro.log 2>&1 || echo "gpu_micro.sh FAILED (see gpurun_out/${TAG}_micro.log)"; tail -3 gpurun_out/${TAG}_micro_overlap.txt
+python bench.py --no-cpu-baseline --no-api-level > gpurun_out/${TAG}_bench_plain.json 2> gpurun_out/${TAG}_bench_plain.err
 bash scripts/gpu_profiles.sh $TAG > gpurun_out/${TAG}_profiles.log 2>&1; tail -25 gpurun_out/${TAG}_profiles.log
 NT=65536 N=1048576 bash scripts/gpu_pmc.sh ${TAG}train c2 train > gpurun_out/${TAG}_train_pmc.log 2>&1
 python scripts/make_train_pmc.py $TAG
@@ -16,7 +17,7 @@ if [ -f probaforms_amd/csrc/librnvp_hip_bxv.so ]; then
   { echo "whole rnvp_loss_grad call, 65536 rows (scripts/bench_kernels.py), ms; [] = product library, [_bxv] = one-wave split-GEMM1 variant"; OPS=train bash scripts/gpu_ab.sh "" _bxv; } > gpurun_out/${TAG}_train_bx_ab.txt 2>&1
 fi
 N=1048576 bash scripts/gpu_pmc.sh ${TAG}flowc2 c2 fwd,inv > gpurun_out/${TAG}_flow_pmc_c2.log 2>&1
-python scripts/make_train_pmc.py $TAG ${TAG}flowc2 "k_flow_bx3<2, 1, 3" ${TAG}_flow_pmc_c2.json "C2 forward / inverse, 1M rows, bx3 kernels (precision auto; barrier-free variant for d <= 16)"
+python scripts/make_train_pmc.py $TAG ${TAG}flowc2 "k_mfma_flow<2, 1, 4" ${TAG}_flow_pmc_c2.json "C2 forward / inverse, 1M rows, f32 kernels (what precision auto runs for d <= 16 since round 4)"
 N=1048576 bash scripts/gpu_pmc.sh ${TAG}flowc4 c4 fwd,inv > gpurun_out/${TAG}_flow_pmc_c4.log 2>&1
 python scripts/make_train_pmc.py $TAG ${TAG}flowc4 "k_flow_bx3<8, 4" ${TAG}_flow_pmc_c4.json "C4 forward / inverse, 1M rows, bx3 kernels (LDS-staged weights)"
 # single-rank data-parallel A/B: the same bench step through rnvp_fit_epoch (fused) and through rnvp_fit_epoch_dp on a one-rank RCCL communicator
@@ -35,4 +36,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/${
 cp $(find /root/repo/gpurun_out/${TAG}_prof_lmm -name "*kernel_stats.csv" | head -1) /root/repo/gpurun_out/${TAG}_lmm_h128x128_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/${TAG}_prof_cvae -o p -- python3 /root/repo/scripts/cvae_c5.py > /root/repo/gpurun_out/${TAG}_prof_cvae.log 2>&1
 cp $(find /root/repo/gpurun_out/${TAG}_prof_cvae -name "*kernel_stats.csv" | head -1) /root/repo/gpurun_out/${TAG}_cvae_c5_kernel_stats.csv
+# round 4: the fit-epoch step per kernel (training kernel + ONE finish launch), the event-vs-rocprof reconciliation of the bench line,
+# the reference-exact prior drawn on the device
+cd /root/repo
+bash scripts/gpu_step_profile.sh $TAG > gpurun_out/${TAG}_step_profile.log 2>&1; tail -12 gpurun_out/${TAG}_step_profile.log
+python scripts/event_vs_rocprof.py $TAG
+python scripts/api_sample_prior.py > gpurun_out/${TAG}_api_sample_prior.txt 2>&1; tail -8 gpurun_out/${TAG}_api_sample_prior.txt
 cd /root/repo; ls -la gpurun_out/${TAG}_*kernel_stats.csv gpurun_out/${TAG}_*pmc*.json

@@ -5,7 +5,7 @@
 #   2. HBM traffic, --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md "HBM":
 #      FETCH_SIZE x2 on gfx950), for bench.py and for the c3 / c4 kernels
 # The program itself follows `--` (python3 ...): no shell or env hop under the profiler.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /root/repo; mkdir -p gpurun_out; OUT=/root/repo/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
@@ -15,7 +15,9 @@ stats() {  # name, then the command
   cp $(find $OUT/${TAG}_prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
   head -8 $OUT/${TAG}_${name}_kernel_stats.csv | cut -c1-200
 }
-stats bench python3 /root/repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-api-level
+# the driver's own command (default steps / warmup), minus the CPU legs that launch no kernel; its JSON line (HIP events taken UNDER
+# the profiler) lands in ${TAG}_prof_bench.log and is compared with the CSV by scripts/event_vs_rocprof.py
+stats bench python3 /root/repo/bench.py --no-cpu-baseline --no-api-level
 export N=1048576 NT=65536
 stats kernels_c2 python3 /root/repo/scripts/bench_kernels.py c2
 stats kernels_c3 python3 /root/repo/scripts/bench_kernels.py c3
