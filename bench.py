@@ -124,6 +124,21 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def tile_geometry(d, c):
+    """(NF, CQ) of the register-chained kernels' template arguments (csrc/rnvp_mfma.h pick_tiles)"""
+    if d <= 16 and c == 0: return 2, 0
+    if d <= 16 and c <= 4: return 2, 1
+    if d <= 32 and c <= 8: return 4, 2
+    return 8, 4
+
+
+def kernel_prefix(disp, d, c, inverse=None):
+    """the instantiation rocprofv3 lists for a dispatch record: name<NF, CQ, row tiles[, INVERSE]"""
+    nf, cq = tile_geometry(d, c)
+    p = "%s<%d, %d, %d" % (disp["kernel"], nf, cq, disp["row_tiles"])
+    return p if inverse is None else p + (", true" if inverse else ", false")
+
+
 def pmc_traffic(kernel_prefix, traffic_file=None):
     """HBM bytes per launch of a kernel from the committed PMC profile of this same command
     (scripts/gpu_traffic.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled per
@@ -602,8 +617,17 @@ def main():
     n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
     # what the library launched for the timed region's last batch / sampling call (rnvp_last_dispatch: written by the launch
     # sites themselves): the kernel names, variants and arithmetic below are the library's statement, not a copy of its rules
-    disp_train = _hip.last_dispatch(_hip.PROFILE_TRAIN) if do_fit else None
+    disp_train = _hip.last_dispatch(_hip.PROFILE_TRAIN) if do_fit else None          # the epoch's LAST batch: the ragged one
     disp_inv = _hip.last_dispatch(_hip.PROFILE_INVERSE) if do_sample else None
+    if do_fit:
+        # ... so the dispatch of a FULL batch is read from one more, untimed, gradient call of that size (same launch rules;
+        # no parameter update); the launches per batch stay those of the fit loop
+        eng.loss_grad(X, C, perms[0][:BATCH * world][rank * BATCH:(rank + 1) * BATCH].contiguous() if world > 1 else perms[0][:BATCH].contiguous(),
+                      BATCH, 1.0 / (BATCH * world))
+        torch.cuda.synchronize()
+        full = _hip.last_dispatch(_hip.PROFILE_TRAIN)
+        full["launches"] = disp_train["launches"]; full["ragged_batch"] = {k: disp_train[k] for k in ("kernel", "variant", "row_tiles", "grid", "rows")}
+        disp_train = full
     assert n_train == args.steps * nb and n_inv == args.steps * (1 if do_sample else 0), (n_train, n_inv, args.steps)
     final_loss = float(losses[n_steps - 1, nb - 1].item()) if do_fit else None
     assert final_loss is None or np.isfinite(final_loss), "training diverged"
@@ -639,7 +663,7 @@ def main():
                     "frac": train_tf / F32_MFMA_PEAK_TFLOPS,
                     "frac_mixed_bound": (train_mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS) * N_ROWS * args.steps / (train_ms * 1e-3)
                                          if train_bx3 else None),
-                    "traffic": pmc_traffic(kname + "<", TRAFFIC_FILE if args.workload == "c2" else TRAFFIC_FILE_C3C4),
+                    "traffic": pmc_traffic(kernel_prefix(disp_train, D, CDIM), TRAFFIC_FILE if args.workload == "c2" else TRAFFIC_FILE_C3C4),
                     "dispatch": disp_train,
                     "kernel": "%s (fused forward+backward; variant %s, %d row tiles per wave, %d waves per workgroup; GEMM1 of the "
                               "forward phase on %s, everything else on f32 MFMA): %d launches in the timed region, %.3f ms avg (15 of "
@@ -654,7 +678,7 @@ def main():
             roof = {"bound": "mfma", "achieved": inv_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": inv_tf / F32_MFMA_PEAK_TFLOPS,
                     # the committed PMC profile has this kernel at 1M rows per launch; scaled to this launch's rows
-                    "traffic": (lambda t: None if t is None else t * N_ROWS / 1048576.0)(pmc_traffic(flow_kernel + "<", TRAFFIC_FILE_C3C4)),
+                    "traffic": (lambda t: None if t is None else t * N_ROWS / 1048576.0)(pmc_traffic(kernel_prefix(disp_inv, D, CDIM, True), TRAFFIC_FILE_C3C4)),
                     "frac_mixed_bound": mixed * N_ROWS * args.steps / (inv_ms * 1e-3) if flow_bx3 else None,
                     "kernel": "%s inverse with the prior drawn in-kernel: %d launches of %d rows in the timed region, %.3f ms avg, "
                               "%d useful flop/row; `frac` prices it against the f32 MFMA peak, `frac_mixed_bound` against the "
