@@ -163,10 +163,14 @@ int rnvp_prior_normal(void *stream, uint64_t seed, int64_t row_offset, int64_t n
  * (torch draws smaller tensors another way: RNVP_EUNSUPPORTED); tail16 [16]: device scratch.  Restates torch's CPU kernel for
  * contiguous float tensors (mt19937, 24-bit uniforms, 16-element Box-Muller blocks on the cephes polynomials of avx_mathfun.h
  * with the multiply-adds torch's build contracts); the Python host checks it against torch.randn itself once per process and
- * keeps the host draw if another torch build disagrees.  One workgroup walks the twister's 624-word blocks (the recurrence is
- * serial between blocks), a second kernel applies the Box-Muller blocks.
+ * keeps the host draw if another torch build disagrees.  The twister is serial from one 624-word block to the next; up to 32
+ * workgroups nevertheless share ONE stream: segment k starts from the state k * 1024 blocks ahead, obtained as a binary convolution
+ * of the next 33 blocks with a precomputed jump polynomial x^J mod phi (csrc/rnvp_mt19937_jump.h, scripts/mt19937_jump_poly.py);
+ * a second kernel tempers the words and applies the Box-Muller blocks.  workspace: rnvp_prior_torch_workspace_bytes() bytes.
  */
-int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count, float *z_out, float *tail16);
+size_t rnvp_prior_torch_workspace_bytes(void);
+int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count, float *z_out, float *tail16,
+                                void *workspace, size_t workspace_bytes);
 
 /*
  * rnvp_prior_normal fused into rnvp_inverse: x_out = g(z(seed, row_offset + r, .), c[r]) for the n_rows

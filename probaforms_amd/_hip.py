@@ -128,7 +128,8 @@ _SIGNATURES = {
     "rnvp_forward_logprob": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_inverse": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _SZ]),
     "rnvp_prior_normal": (C.c_int, [_VP, _U64, _I64, _I64, C.c_int32, _VP]),
-    "rnvp_prior_normal_torch_cpu": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "rnvp_prior_normal_torch_cpu": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
+    "rnvp_prior_torch_workspace_bytes": (_SZ, []),
     "rnvp_sample": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _I64, _U64, _I64, _VP, _VP, _SZ]),
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
     "rnvp_loss_grad_zseed": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP, _SZ]),
@@ -279,11 +280,16 @@ def prior_normal(seed, row_offset, n_rows, d, z_out):
                                 _ptr(z_out, torch.float32, "z_out")))
 
 
-def prior_normal_torch_cpu(mt_state, count, z_out, tail16):
+def prior_torch_workspace_bytes():
+    return int(lib().rnvp_prior_torch_workspace_bytes())
+
+
+def prior_normal_torch_cpu(mt_state, count, z_out, tail16, ws):
     """z_out[:count] = torch.randn(count) of the CPU generator whose twister state is mt_state ([625] int32 on the device:
-    624 words + position), advanced in place (rnvp_prior_normal_torch_cpu)"""
+    624 words + position), advanced in place (rnvp_prior_normal_torch_cpu); ws: prior_torch_workspace_bytes() bytes"""
+    wp, wn = _ws(ws)
     _call("rnvp_prior_normal_torch_cpu", (_ptr(mt_state, torch.int32, "mt_state"), int(count), _ptr(z_out, torch.float32, "z_out"),
-                                          _ptr(tail16, torch.float32, "tail16")))
+                                          _ptr(tail16, torch.float32, "tail16"), wp, wn))
 
 
 def sample(shape, params, masks, c, n_rows, seed, row_offset, x_out, ws):

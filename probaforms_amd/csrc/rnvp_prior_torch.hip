@@ -17,6 +17,7 @@
 // The Python host (probaforms_amd/models/nflow.py HostStreamOnDevice) validates this path against torch.randn on a scratch
 // generator once per process and keeps the host draw when they differ (another torch build).
 #include "rnvp_common.h"
+#include "rnvp_mt19937_jump.h"
 
 namespace rnvp {
 namespace {
@@ -61,24 +62,83 @@ __device__ __forceinline__ void twist_block(const uint32_t *o, uint32_t *nw, int
     }
 }
 
-// state [625]: 624 words + the position of the next unread word (624: the block is used up).  Writes `count` uniforms to
-// out and `tail` more (0 or 16) to tail_out -- as RAW 32-bit words (tempering and the conversion to a 24-bit uniform are left to
-// the parallel kernel below: this one is a single workgroup and bound by its instruction count); leaves the advanced state
-// behind.  Whole blocks that land in `out` go straight from the registers that formed them (one barrier per block); the partial
-// blocks at either end go through LDS.
-__global__ void __launch_bounds__(kMtThreads)
-k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *__restrict__ out, float *__restrict__ tail_out) {
-    constexpr int D = kN - kM;
-    __shared__ uint32_t S[2][kN];
+// ---- several workgroups on ONE stream: jump-ahead -----------------------------------------------------------------------------
+// The twister is serial from block to block, but its raw word sequence W is an F2-linear recurrence: with g_J(x) = x^J mod phi(x)
+// (phi: the characteristic polynomial, degree 19937), W[J + j] = XOR over the set bits i of g_J of W[i + j] for every j.  So the
+// block k * kMtJumpBlocks twists after X0 is a binary convolution of the 33 blocks that follow X0 with a precomputed polynomial
+// (rnvp_mt19937_jump.h, generated and self-checked by scripts/mt19937_jump_poly.py) -- and workgroup k of k_mt19937_uniform can start
+// there while workgroup 0 is still at the beginning.  k_mt_jump: one workgroup per (segment k >= 1, quarter of the polynomial):
+// builds the 33 blocks in LDS (82 KB), thread j XORs W[i + j] over its quarter's set bits; the quarters are XORed by the consumer.
+constexpr int kJumpParts = 4;
+constexpr int kJumpThreads = 640;
+constexpr int kWBlocks = 33;                              // 19937 + 624 <= 33 * 624 raw words
+constexpr int kMtMaxSeg = kMtJumpPolys + 1;               // segments of one round: k = 0 .. 31
+
+__global__ void __launch_bounds__(kJumpThreads)
+k_mt_jump(const uint32_t *__restrict__ state_in, uint32_t *__restrict__ partial) {
+    extern __shared__ uint32_t W[];                       // kWBlocks * 624 words
     const int t = threadIdx.x;
-    for (int i = t; i < kN; i += kMtThreads) S[0][i] = state[i];
-    int pos = (int)state[kN];
+    const int k = blockIdx.x / kJumpParts + 1, part = blockIdx.x % kJumpParts;
+    for (int i = t; i < kN; i += kJumpThreads) W[i] = state_in[i];
+    __syncthreads();
+    for (int b = 0; b + 1 < kWBlocks; ++b) {
+        uint32_t a, bb, c;
+        twist_block(W + b * kN, W + (b + 1) * kN, t, a, bb, c);
+        __syncthreads();
+    }
+    if (t < kN) {
+        constexpr int kPer = kN / kJumpParts;             // 156 polynomial words per quarter
+        const uint32_t *g = kMtJumpPoly[k - 1] + part * kPer;
+        const uint32_t *w = W + 32 * part * kPer + t;
+        uint32_t acc = 0u;
+        for (int i = 0; i < kPer; ++i) {
+            uint32_t p = g[i];                            // (uniform over the workgroup: no divergence)
+            while (p) {
+                const int bit = __ffs(p) - 1;
+                acc ^= w[32 * i + bit];
+                p &= p - 1;
+            }
+        }
+        partial[((size_t)(k - 1) * kJumpParts + part) * kN + t] = acc;
+    }
+}
+
+// Workgroup k produces its segment of the stream that starts at (state_in, position state_in[624]): segment 0 the rest of the current
+// block and the kMtJumpBlocks blocks after it, segment k >= 1 the blocks k B + 1 .. (k + 1) B (B = kMtJumpBlocks), from the jumped
+// state k_mt_jump left in `partial`.  `count` uniforms go to out, `tail` more (0 or 16) to tail_out -- as RAW 32-bit words (tempering
+// and the conversion to a 24-bit uniform are left to the parallel kernel below: this one is bound by its instruction count); the
+// workgroup that produces the last word leaves the advanced state in state_out.  Whole blocks that land in `out` go straight from the
+// registers that formed them (one barrier per block); the partial blocks at either end go through LDS.
+__global__ void __launch_bounds__(kMtThreads)
+k_mt19937_uniform(const uint32_t *__restrict__ state_in, const uint32_t *__restrict__ partial, uint32_t *__restrict__ state_out,
+                  int64_t count, int tail, float *__restrict__ out, float *__restrict__ tail_out) {
+    constexpr int D = kN - kM;
+    constexpr int64_t kSegWords = (int64_t)kMtJumpBlocks * kN;
+    __shared__ uint32_t S[2][kN];
+    const int t = threadIdx.x, k = blockIdx.x;
+    const int pos0 = (int)state_in[kN];
+    const int64_t total = count + tail, first = kN - pos0;
+    const int64_t lo = k == 0 ? 0 : first + (int64_t)k * kSegWords;
+    int64_t hi = first + (int64_t)(k + 1) * kSegWords;
+    if (lo >= total) return;
+    if (hi > total) hi = total;
+    for (int i = t; i < kN; i += kMtThreads) {
+        uint32_t v;
+        if (k == 0) v = state_in[i];
+        else {
+            const uint32_t *pp = partial + (size_t)(k - 1) * kJumpParts * kN + i;
+            v = pp[0];
+#pragma unroll
+            for (int q = 1; q < kJumpParts; ++q) v ^= pp[q * kN];
+        }
+        S[0][i] = v;
+    }
+    int pos = k == 0 ? pos0 : kN;
     int cur = 0;
     __syncthreads();
-    const int64_t total = count + tail;
-    int64_t done = 0;
-    while (done < total) {
-        if (pos >= kN && done + kN <= count) {           // a whole block for `out`
+    int64_t done = lo;
+    while (done < hi) {
+        if (pos >= kN && done + kN <= hi && done + kN <= count) {           // a whole block for `out`
             uint32_t a = 0, b = 0, c = 0;
             twist_block(S[cur], S[cur ^ 1], t, a, b, c);
             float *dst = out + done;
@@ -100,7 +160,7 @@ k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *
             cur ^= 1;
             pos = 0;
         }
-        const int64_t left = total - done;
+        const int64_t left = hi - done;
         const int m = (int)((int64_t)(kN - pos) < left ? (kN - pos) : left);
         for (int i = t; i < m; i += kMtThreads) {
             const float u = __uint_as_float(S[cur][pos + i]);
@@ -110,9 +170,11 @@ k_mt19937_uniform(uint32_t *__restrict__ state, int64_t count, int tail, float *
         pos += m;
         done += m;
     }
-    __syncthreads();
-    for (int i = t; i < kN; i += kMtThreads) state[i] = S[cur][i];
-    if (t == 0) state[kN] = (uint32_t)pos;
+    if (hi == total) {                                   // this workgroup produced the last word: hand the state on
+        __syncthreads();
+        for (int i = t; i < kN; i += kMtThreads) state_out[i] = S[cur][i];
+        if (t == 0) state_out[kN] = (uint32_t)pos;
+    }
 }
 
 // ---- log256_ps / sincos256_ps of ATen/native/cpu/avx_mathfun.h (cephes single-precision polynomials), one lane -----------------
@@ -201,20 +263,51 @@ k_normal_fill_16(float *__restrict__ data, int64_t count, const float *__restric
 }  // namespace
 }  // namespace rnvp
 
-extern "C" int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count, float *z_out, float *tail16) {
+extern "C" size_t rnvp_prior_torch_workspace_bytes(void) {
+    return ((size_t)640 + (size_t)rnvp::kMtJumpPolys * rnvp::kJumpParts * rnvp::kN) * sizeof(uint32_t);
+}
+
+extern "C" int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count, float *z_out, float *tail16,
+                                           void *workspace, size_t workspace_bytes) {
+    using namespace rnvp;
     if (count < 16) return RNVP_EUNSUPPORTED;          // torch takes another path (a cached double-precision Box-Muller) there
     if (!mt_state || !z_out || !tail16) return RNVP_EINVAL;
+    if (!workspace || workspace_bytes < rnvp_prior_torch_workspace_bytes()) return RNVP_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t *state_in = static_cast<uint32_t *>(workspace), *partial = state_in + 640;
+    static std::atomic<uint64_t> attr{0};
+    const size_t jump_lds = (size_t)kWBlocks * kN * sizeof(uint32_t);
+    {
+        const int arc = allow_big_lds(reinterpret_cast<const void *>(k_mt_jump), 160 * 1024, attr);
+        if (arc) return arc;
+    }
+    // rounds of at most kMtMaxSeg segments (20.4M words): every round continues from the state the previous one left
+    // (a round stops 1024 words short of the segments' capacity so that the 16 extra words of a redrawn tail always fit)
+    constexpr int64_t kSegWords = (int64_t)kMtJumpBlocks * kN, kRound = (int64_t)kMtMaxSeg * kSegWords - 1024;
+    for (int64_t r0 = 0; r0 < count; r0 += kRound) {
+        const int64_t cnt = count - r0 < kRound ? count - r0 : kRound;
+        const bool last = r0 + cnt >= count;
+        const int tail = (last && (count % 16)) ? 16 : 0;
+        RNVP_HIP_TRY(hipMemcpyAsync(state_in, mt_state, (kN + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        // the current block may be nearly unread (position 0), so cnt + tail words need at most this many segments
+        int64_t nseg = (cnt + tail + kSegWords - 1) / kSegWords;
+        if (nseg > kMtMaxSeg) nseg = kMtMaxSeg;
+        if (nseg > 1) {
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)((nseg - 1) * kJumpParts)), dim3(kJumpThreads), jump_lds, st, state_in, partial);
+            RNVP_HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_mt19937_uniform, dim3((unsigned)nseg), dim3(kMtThreads), 0, st, state_in, partial, mt_state, cnt, tail,
+                           z_out + r0, tail16);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
     const int tail = (count % 16) ? 16 : 0;
-    hipLaunchKernelGGL(rnvp::k_mt19937_uniform, dim3(1), dim3(rnvp::kMtThreads), 0, st, mt_state, count, tail, z_out, tail16);
-    RNVP_HIP_TRY(hipGetLastError());
     const int64_t pairs = (count / 16) * 8;
     int64_t blocks = (pairs + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(rnvp::k_normal_fill_16, dim3((unsigned)blocks), dim3(256), 0, st, z_out, count, tail16, 0);
+    hipLaunchKernelGGL(k_normal_fill_16, dim3((unsigned)blocks), dim3(256), 0, st, z_out, count, tail16, 0);
     RNVP_HIP_TRY(hipGetLastError());
     if (tail) {         // the redrawn last 16 overlap the last whole block's inputs: after it, in stream order
-        hipLaunchKernelGGL(rnvp::k_normal_fill_16, dim3(1), dim3(64), 0, st, z_out, count, tail16, 1);
+        hipLaunchKernelGGL(k_normal_fill_16, dim3(1), dim3(64), 0, st, z_out, count, tail16, 1);
         RNVP_HIP_TRY(hipGetLastError());
     }
     return RNVP_OK;

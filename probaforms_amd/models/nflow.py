@@ -134,11 +134,12 @@ class HostStreamOnDevice:
         self._st = st
         self._mt = torch.from_numpy(mt.copy()).to(self.device)
         self._tail = torch.empty(16, dtype=torch.float32, device=self.device)
+        self._ws = torch.empty(_hip.prior_torch_workspace_bytes(), dtype=torch.uint8, device=self.device)
         return self
 
     def draw(self, out):
         """out (contiguous float32 device tensor, numel >= 16) <- the generator's next out.numel() normals"""
-        _hip.prior_normal_torch_cpu(self._mt, out.numel(), out, self._tail)
+        _hip.prior_normal_torch_cpu(self._mt, out.numel(), out, self._tail, self._ws)
         return out
 
     def end(self):
@@ -360,8 +361,17 @@ class NormalizingFlow(nn.Module):
         out = torch.empty((n, d), dtype=torch.float32, pin_memory=True)
         zdev = [torch.empty((cap, d), dtype=torch.float32, device=dev) for _ in range(NB)]
         # the reference's stream: drawn on the device with the host generator's bits where that is validated (HostStreamOnDevice),
-        # on its own stream so that the twister's serial walk overlaps the inverse kernels and the downloads; else on the host
+        # on its own stream, a WINDOW of chunks per draw (up to 32M numbers: the twister's workgroups share one stream through
+        # jump-ahead, so one large draw costs a fraction of many small ones); else on the host, chunk by chunk
         hs = HostStreamOnDevice(dev).begin() if (host_rng and HostStreamOnDevice.usable(dev)) else None
+        chunks = row_chunks(n, rows)
+        if hs is not None:
+            cpw = max(1, (32 << 20) // (rows * d))                           # chunks per window
+            nwin = (len(chunks) + cpw - 1) // cpw
+            win = [(chunks[w * cpw][0], sum(m for _, m in chunks[w * cpw:(w + 1) * cpw])) for w in range(nwin)]
+            zwin = [torch.empty((max(r for _, r in win), d), dtype=torch.float32, device=dev) for _ in range(min(2, nwin))]
+            ev_win = [torch.cuda.Event() for _ in zwin]
+            ev_used = [None for _ in zwin]                                    # the window buffer's last reader (an inverse kernel)
         zpin = [torch.empty((cap, d), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if (host_rng and hs is None) else None
         stage_c = cdim > 0 and Cn is not None
         cdev = [torch.empty((cap, cdim), dtype=torch.float32, device=dev) for _ in range(NB)] if stage_c else None
@@ -373,18 +383,29 @@ class NormalizingFlow(nn.Module):
         ev_k = [torch.cuda.Event() for _ in range(NB)]
         ev_out = [torch.cuda.Event() for _ in range(NB)]
         gen = torch.cuda.Stream(dev) if hs is not None else None
-        ev_gen = [torch.cuda.Event() for _ in range(NB)] if hs is not None else None
         h2d.wait_stream(cur)
+
+        def draw_window(w):             # the global CPU generator's next normals for window w, made on the device
+            b = w % len(zwin)
+            with torch.cuda.stream(gen):
+                if ev_used[b] is not None:
+                    gen.wait_event(ev_used[b])
+                hs.draw(zwin[b][:win[w][1]])
+                ev_win[b].record(gen)
+
         if gen is not None:
             gen.wait_stream(cur)
-        for k, (lo, m) in enumerate(row_chunks(n, rows)):
+            draw_window(0)
+        for k, (lo, m) in enumerate(chunks):
             i = k % NB
             if k >= NB:
                 ev_out[i].synchronize()                 # buffer set i is free again (its D2H has landed)
             if hs is not None:
-                with torch.cuda.stream(gen):
-                    hs.draw(zdev[i][:m])                # the global CPU generator's next m * d normals, made on the device
-                    ev_gen[i].record(gen)
+                w = k // cpw
+                if k % cpw == 0:
+                    cur.wait_event(ev_win[w % len(zwin)])
+                    if w + 1 < nwin:
+                        draw_window(w + 1)              # overlaps this window's inverse kernels and downloads
             elif host_rng:
                 torch.randn((m, d), out=zpin[i][:m])    # global CPU generator: the reference's stream
             if stage_c:
@@ -398,10 +419,14 @@ class NormalizingFlow(nn.Module):
                     cdev[i][:m].copy_(cpin[i][:m], non_blocking=True)
                 ev_in[i].record(h2d)
             cur.wait_event(ev_in[i])
-            if hs is not None:
-                cur.wait_event(ev_gen[i])
             cc = None if cdim == 0 else (cdev[i][:m] if stage_c else Cd[lo:lo + m])
-            if host_rng:
+            if hs is not None:
+                w = k // cpw
+                eng.inverse(zwin[w % len(zwin)][lo - win[w][0]:lo - win[w][0] + m], cc, out=zdev[i][:m])
+                if k % cpw == cpw - 1 or k + 1 == len(chunks):
+                    ev_used[w % len(zwin)] = torch.cuda.Event()
+                    ev_used[w % len(zwin)].record(cur)
+            elif host_rng:
                 eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
             else:
                 eng.sample(m, cc, seed, row_offset=lo, out=zdev[i][:m])   # chunk lo..lo+m of the one-shot draw

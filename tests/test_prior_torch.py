@@ -53,7 +53,7 @@ def test_device_draw_is_validated_on_this_host():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", SIZES + [1 << 20, 16 * 1000 * 1000 + 5])
+@pytest.mark.parametrize("n", SIZES + [1 << 20, 638976 + 100, 2 * 638976, 16 * 1000 * 1000 + 5, 25 * 1000 * 1000 + 3])   # ... several jump segments, two rounds
 def test_device_draw_equals_torch_randn(n):
     from probaforms_amd.models.nflow import HostStreamOnDevice as H
     if not H.usable("cuda"):
@@ -75,10 +75,10 @@ def test_device_draw_equals_torch_randn(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1000, 300001])
+@pytest.mark.parametrize("n", [1000, 300001, 6000011])      # one draw / the chunked pipeline / two draw windows
 def test_realnvp_sample_default_prior_is_the_host_stream(n):
     """RealNVP.sample with the default prior: the same bytes whether z is drawn on the host or on the device, and the global
-    generator ends in the same state (n = 300001 takes the chunked sample_to_host pipeline)"""
+    generator ends in the same state (n = 300001 takes the chunked sample_to_host pipeline, 6000011 rows need two draw windows)"""
     from probaforms_amd.models import RealNVP
     from probaforms_amd.models.nflow import HostStreamOnDevice as H
     rng = np.random.default_rng(0)
