@@ -281,7 +281,9 @@ class RealNVP(GenModel):
             x = eng.sample(hi - lo, Cl, int(t.item()), row_offset=lo)
         else:
             if isinstance(self.prior, StandardNormalPrior):
-                z = torch.randn((n, self.prior.var_size))[lo:hi].to(eng.device).contiguous()     # the full reference stream, sliced
+                # the full reference stream, sliced: every rank consumes its generator like a single process would; drawn on
+                # the device where that is validated (nflow.HostStreamOnDevice: 1 ms instead of 34 per 16M numbers)
+                z = self.prior.sample((n,))[lo:hi].contiguous()
             else:
                 z = torch.as_tensor(self.prior.sample((n,)), dtype=torch.float32)[lo:hi].to(eng.device).contiguous()
             x = eng.inverse(z, Cl, out=z) if hi > lo else z
