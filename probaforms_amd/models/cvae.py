@@ -134,11 +134,18 @@ class _FitDraws:
         self.gen = torch.Generator()
         self.gen.set_state(torch.get_rng_state())
         pin = device is not None and torch.device(device).type == "cuda" and n * lat >= (1 << 16)
+        # Round 4: the SAME stream drawn on the device (nflow.HostStreamOnDevice: torch.randn's bits, validated against torch at
+        # run time) whenever every draw of the fit has at least 16 elements (torch draws smaller tensors another way): the eps
+        # buffers then live in device memory, the host keeps only the two seed draws per epoch and the shuffle
+        from .nflow import HostStreamOnDevice
+        self.on_device = (pin and n * lat >= 16 and all((e - s) * lat >= 16 for (s, e) in bounds) and HostStreamOnDevice.usable(device))
+        self.device = torch.device(device) if device is not None else None
         self.free, self.ready = queue.Queue(), queue.Queue()
+        edev = self.device if self.on_device else None
         for _ in range(max(1, min(slots, n_epochs))):
             self.free.put((torch.empty(n, dtype=torch.int64, pin_memory=pin),
-                           torch.empty(n, lat, dtype=torch.float32, pin_memory=pin),
-                           torch.empty(n, lat, dtype=torch.float32, pin_memory=pin)))
+                           torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin),
+                           torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin)))
         self.stop = False
         self.thread = threading.Thread(target=self._run, name="cvae-draws", daemon=True)
         self.thread.start()
@@ -148,6 +155,9 @@ class _FitDraws:
         try:
             g = self.gen
             pool = _perm_pool(2) if self.n >= 65536 else None
+            side = torch.cuda.Stream(self.device) if self.on_device else None
+            if self.on_device:
+                from .nflow import HostStreamOnDevice
             for _ in range(self.n_epochs):
                 slot = None
                 while slot is None and not self.stop:
@@ -161,9 +171,19 @@ class _FitDraws:
                 torch.empty((), dtype=torch.int64).random_(generator=g)                    # loader base seed
                 seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item())  # RandomSampler seed
                 fut = pool.submit(_perm_into, perm, seed) if pool else _perm_into(perm, seed)
-                for (s, e) in self.bounds:
-                    torch.randn(e - s, self.lat, generator=g, out=eps[s:e])
-                torch.randn(self.n, self.lat, generator=g, out=eps_full)
+                if self.on_device:
+                    # the generator's state goes down, the epoch's draws are chained on the device (this thread's own stream),
+                    # the advanced state comes back (end() waits for the draws): g is where the host draws would have left it
+                    with torch.cuda.stream(side):
+                        hs = HostStreamOnDevice(self.device, g).begin()
+                        for (s, e) in self.bounds:
+                            hs.draw(eps[s:e])
+                        hs.draw(eps_full)
+                        hs.end()
+                else:
+                    for (s, e) in self.bounds:
+                        torch.randn(e - s, self.lat, generator=g, out=eps[s:e])
+                    torch.randn(self.n, self.lat, generator=g, out=eps_full)
                 self.ready.put((slot, fut))
         except BaseException as ex:               # surfaces in the consumer
             self.ready.put(ex)
