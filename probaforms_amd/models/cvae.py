@@ -142,6 +142,10 @@ class _FitDraws:
         self.device = torch.device(device) if device is not None else None
         self.free, self.ready = queue.Queue(), queue.Queue()
         edev = self.device if self.on_device else None
+        if self.on_device:
+            # the device draws of an epoch take ~1 ms; what takes time is the epoch's host randperm (12 ms at n = 1M, on the shared
+            # pool): a deeper ring lets eight of them run at once (the eps buffers are device memory: 2 x n x latent floats a slot)
+            slots = max(slots, 8)
         for _ in range(max(1, min(slots, n_epochs))):
             self.free.put((torch.empty(n, dtype=torch.int64, pin_memory=pin),
                            torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin),
@@ -154,7 +158,7 @@ class _FitDraws:
         import queue
         try:
             g = self.gen
-            pool = _perm_pool(2) if self.n >= 65536 else None
+            pool = _perm_pool(8 if self.on_device else 2) if self.n >= 65536 else None
             side = torch.cuda.Stream(self.device) if self.on_device else None
             if self.on_device:
                 from .nflow import HostStreamOnDevice
