@@ -82,6 +82,9 @@ typedef struct rnvp_shape {
 #define RNVP_FAMILY_AUTO 0       /* RNVP_PATH_LMM whenever a 16-row tile's LDS image fits, else RNVP_PATH_GENERIC          */
 #define RNVP_FAMILY_VALU 1       /* always RNVP_PATH_GENERIC (one thread per row, VALU + LDS)                               */
 #define RNVP_FAMILY_LMM  2       /* as AUTO (kept distinct so that a test can say what it asks for)                          */
+#define RNVP_FAMILY_LMM16 3      /* RNVP_PATH_LMM with the training call pinned to the 16-rows-per-workgroup form (k_lmm_train)   */
+#define RNVP_FAMILY_LMM64 4      /* ... to the 64-rows-per-workgroup form with in-kernel weight gradients (k_lmm_train64)
+                                    wherever its LDS image and register slots fit; AUTO picks it from 8192 rows per call on   */
 
 #define RNVP_SMALL_INVARIANT 0   /* default: a row's result never depends on how the rows are split into calls (chunks
                                     of a pipelined draw, shards of ranks and the one-shot call agree bit for bit)      */

@@ -33,7 +33,7 @@ LIB_PATH = os.environ.get("RNVP_HIP_LIB") or os.path.join(_HERE, "csrc", "librnv
 SMALL_CALLS = {"invariant": 0, "latency": 1}
 # rnvp_shape.family (per call; test / measurement aid): kernels for shapes outside the register-chained MFMA path --
 # 'auto' / 'lmm': the any-shape MFMA kernels whenever their LDS image fits; 'valu': always the one-thread-per-row kernels
-FAMILIES = {"auto": 0, "valu": 1, "lmm": 2}
+FAMILIES = {"auto": 0, "valu": 1, "lmm": 2, "lmm16": 3, "lmm64": 4}
 
 
 class RnvpShape(C.Structure):

@@ -43,7 +43,7 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     if (s->precision < RNVP_PREC_AUTO || s->precision > RNVP_PREC_BX3) return RNVP_EINVAL;
     if (s->small_calls != RNVP_SMALL_INVARIANT && s->small_calls != RNVP_SMALL_LATENCY) return RNVP_EINVAL;
     k->small_latency = s->small_calls == RNVP_SMALL_LATENCY;
-    if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM) return RNVP_EINVAL;
+    if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM64) return RNVP_EINVAL;
     k->family = s->family;
     k->prec_auto = s->precision == RNVP_PREC_AUTO;
     // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) -- measured

@@ -32,6 +32,12 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
               Seeds sd);
+// rnvp_lmm64.hip: the training call on 64-row blocks with the weight gradients inside the kernel (loss_grad dispatches to it)
+bool use_train64(const KShape &k, int64_t n);
+size_t train64_workspace_bytes(const KShape &k, int64_t max_rows);
+int loss_grad64(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
+                const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
+                Seeds sd);
 
 // ---- CVAE (encoder / decoder MLPs of any depth and width) on the same building blocks ---------------------------------
 // op: RNVP_OP_TRAIN (cvae_loss_grad), RNVP_OP_FORWARD (cvae_encode), RNVP_OP_INVERSE (cvae_decode)

@@ -697,6 +697,7 @@ size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
         b += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);               // wgrad operands of one chunk
         b += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);                        // layer inputs of one chunk
         b += align_up((size_t)kSplits * k.L * 2 * g.gnet_floats * sizeof(float), 256);              // split partials
+        if (use_train64(k, max_rows)) { const size_t b64 = train64_workspace_bytes(k, max_rows); if (b64 > b) b = b64; }
     }
     return b;
 }
@@ -749,6 +750,7 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
               Seeds sd) {
+    if (use_train64(k, n)) return loss_grad64(st, k, params, masks, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, sd);
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
     const LGeo g = make_lgeo(k);
     const int64_t cr = chunk_rows(k, g);

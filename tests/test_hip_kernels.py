@@ -610,11 +610,13 @@ def test_auto_mode_takes_lmm_for_generic_shapes_and_is_bitwise_reproducible():
 
 
 def test_lmm_row_chunks_add_up():
-    """the lmm training pass works through a big batch in row chunks (bounded workspace: the dumped weight-gradient
-    operands take 38 KB per row for hidden=(128,128)); the chunked gradient equals the sum of separately computed parts"""
+    """the 16-row lmm training pass works through a big batch in row chunks (bounded workspace: the dumped weight-gradient
+    operands take 38 KB per row for hidden=(128,128)); the chunked gradient equals the sum of separately computed parts
+    (the 64-row form's chunks: tests/test_lmm64_gpu.py)"""
     from probaforms_amd import _hip
     L, d, c, hidden, n = 8, 16, 4, (128, 128), 60000            # chunk = 28160 rows -> 3 chunks
     sh, p, rng = _rand_flow(L, d, c, hidden, "tanh", 9, scale=0.15)
+    sh.family = _hip.FAMILIES["lmm16"]
     masks = ((np.arange(d)[None] + np.arange(L)[:, None]) % 2).astype(np.uint8)
     assert _hip.kernel_path(sh, masks, _hip.OP_TRAIN) == _hip.PATH_LMM
     assert _hip.workspace_bytes(sh, _hip.OP_TRAIN, 10 ** 7) == _hip.workspace_bytes(sh, _hip.OP_TRAIN, 10 ** 6) < 2 ** 31
