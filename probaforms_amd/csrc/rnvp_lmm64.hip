@@ -32,6 +32,17 @@ constexpr int kSlots = 4;              // weight-gradient units a wave keeps in 
 constexpr int kUnitFloats = 4 * 256 + 64;   // one unit's partial: four accumulator tiles + its bias sums
 constexpr int kSlackFg = 16;           // zeroed feature groups past the last region (padded k-groups / strided unit reads end here)
 
+// RNVP_STAMP: diagnostic build that accumulates cycle-counter deltas per kind of work and printf()s them for workgroup 0 (read
+// the SHARES, not the absolute time: the stamps serialise the wave)
+struct Stamps64 { unsigned long long t0, gemm, epi, bar, wgrad, other; };
+#ifdef RNVP_STAMP
+#define STAMP64(field) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1__ = __builtin_readcyclecounter(); \
+                            __builtin_amdgcn_sched_barrier(0); stp.field += t1__ - stp.t0; stp.t0 = t1__; } while (0)
+#else
+#define STAMP64(field) do { } while (0)
+#endif
+#define SYNC64() do { STAMP64(other); __syncthreads(); STAMP64(bar); } while (0)
+
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 struct G64 {
@@ -82,104 +93,143 @@ k_lmm64_pack(KShape s, G64 g, const float *__restrict__ params, const uint8_t *_
     }
 }
 
+// The first two fragment groups of a wave's first unit of a Linear, requested BEFORE the barrier that ends the previous phase
+// (an L2 round trip is ~1 000 cycles; after a barrier both waves of a SIMD would wait for it together).
+struct Pre { f4 a0, a1; };
+struct Lin { const float *frag; int MT, KG; };                   // fragments of one Linear (forward or transposed)
+__device__ __forceinline__ int units_per_tile(int MT) { return MT >= 8 ? 1 : (MT >= 4 ? 2 : 4); }
+__device__ __forceinline__ Pre prefetch(const Lin &L, int lane, int wave) {
+    Pre p;
+    p.a0 = p.a1 = f4{0.f, 0.f, 0.f, 0.f};
+    const int per = units_per_tile(L.MT);
+    if (L.frag && wave < L.MT * per) {
+        const float *pa = L.frag + (size_t)(wave / per) * L.KG * 256 + lane * 4;
+        p.a0 = *reinterpret_cast<const f4 *>(pa);
+        if (L.KG > 1) p.a1 = *reinterpret_cast<const f4 *>(pa + 256);
+    }
+    return p;
+}
+
 // acc[t] (t < RG) = W tile m . in^T for row tiles rt0 .. rt0 + RG - 1: `ftile` = the tile's fragments [group][lane][4], `inb` the
-// LDS region of the input.  Three operand sets rotate: two groups of fragments (L2) in flight while one multiplies.
+// LDS region of the input.  Fragments (L2) are requested two groups ahead, the LDS operands one; the first two fragment groups
+// come from `pre` when use_pre.
 template <int RG>
-__device__ __forceinline__ void gemm_acc(const float *__restrict__ ftile, int KG, const float *inb, int rt0, int lane, f4 (&acc)[RG]) {
+__device__ __forceinline__ void gemm_acc(const float *__restrict__ ftile, int KG, const float *inb, int rt0, int lane, f4 (&acc)[RG],
+                                         const Pre &pre, bool use_pre) {
     const int q = lane >> 4, i = lane & 15;
     const float *pa = ftile + lane * 4;                          // + G * 256
     const float *pb = inb + q * FS + (16 * rt0 + i) * 4;         // + G * 4 * FS + t * 64
 #pragma unroll
     for (int t = 0; t < RG; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-    f4 a0, a1, a2, b0[RG], b1[RG], b2[RG];
-    auto fetch = [&](f4 &a, f4 (&b)[RG], int G) {
-        a = *reinterpret_cast<const f4 *>(pa + G * 256);
+    f4 a[3], b[2][RG];
+    auto fetch_b = [&](f4 (&bb)[RG], int G) {
 #pragma unroll
-        for (int t = 0; t < RG; ++t) b[t] = *reinterpret_cast<const f4 *>(pb + G * 4 * FS + t * 64);
+        for (int t = 0; t < RG; ++t) bb[t] = *reinterpret_cast<const f4 *>(pb + G * 4 * FS + t * 64);
     };
-    auto mul = [&](const f4 &a, const f4 (&b)[RG]) {
+    a[0] = pre.a0; a[1] = pre.a1;
+    if (!use_pre) {
+        a[0] = *reinterpret_cast<const f4 *>(pa);
+        a[1] = *reinterpret_cast<const f4 *>(pa + min(1, KG - 1) * 256);
+    }
+    fetch_b(b[0], 0);
+#pragma unroll 1
+    for (int G0 = 0; G0 < KG; G0 += 6) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int j = 0; j < 6; ++j) {
+            const int G = G0 + j;
+            if (G >= KG) break;
+            // unconditional (the last groups re-request the last one): a load under a branch makes the compiler wait for ALL
+            // outstanding loads at the join, i.e. for the groups just requested
+            a[(j + 2) % 3] = *reinterpret_cast<const f4 *>(pa + min(G + 2, KG - 1) * 256);
+            fetch_b(b[(j + 1) % 2], min(G + 1, KG - 1));
+            __builtin_amdgcn_sched_barrier(0);                    // or the scheduler sinks the requests down to their uses
 #pragma unroll
-            for (int t = 0; t < RG; ++t) acc[t] = mfma16(a[e], b[t][e], acc[t]);
-    };
-    fetch(a0, b0, 0);
-    if (1 < KG) fetch(a1, b1, 1);
-    for (int G = 0; G < KG; G += 3) {
-        if (G + 2 < KG) fetch(a2, b2, G + 2);
-        mul(a0, b0);
-        if (G + 1 >= KG) break;
-        if (G + 3 < KG) fetch(a0, b0, G + 3);
-        mul(a1, b1);
-        if (G + 2 >= KG) break;
-        if (G + 4 < KG) fetch(a1, b1, G + 4);
-        mul(a2, b2);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < RG; ++t) acc[t] = mfma16(a[j % 3][e], b[j % 2][t][e], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
 enum { EP_FWD_ACT = 0, EP_FWD_LIN, EP_GRAD, EP_GRAD0 };
 
-// one Linear for the block: the (out tile, row-tile group) units go round-robin to the waves.  Epilogues:
+// one Linear for the block: the (out tile, row-tile group) units go round-robin to the waves.  Epilogues (`ep`, wave-uniform):
 //   EP_FWD_ACT  out = act(acc + bias)           EP_FWD_LIN  out = acc + bias
 //   EP_GRAD     out = acc * act'(out)  (in place: `out` holds the activation, and receives the pre-activation gradient)
 //   EP_GRAD0    out += acc             (input gradient of Linear 0, added to the layer's running d loss / d x)
-// Outputs past nvalid are written as 0.
-template <int RG, int EP>
-__device__ __forceinline__ void gemm_units(const float *__restrict__ frag, int MT, int KG, const float *inb, float *outb,
-                                           const float *__restrict__ bias, int nvalid, int act, int lane, int wave) {
+// Outputs past nvalid are written as 0.  `pre` = prefetch(this Linear); returns prefetch(next), requested between the wave's last
+// product and its epilogue.  One instantiation per RG serves every call: the kernel's code has to stay inside the instruction cache.
+template <int RG>
+__device__ __forceinline__ Pre gemm_units(const Lin &L, const float *inb, float *outb, const float *__restrict__ bias, int nvalid,
+                                          int ep, int act, int lane, int wave, const Pre &pre, const Lin &next, Stamps64 &stp) {
     constexpr int per = 4 / RG;
     const int q = lane >> 4, i = lane & 15;
-    for (int u = wave; u < MT * per; u += kW8) {
+    Pre nx;
+    bool requested = false;
+    STAMP64(other);
+#pragma unroll 1
+    for (int u = wave; u < L.MT * per; u += kW8) {
         const int m = u / per, rt0 = (u - m * per) * RG;
-        f4 acc[RG];
-        gemm_acc<RG>(frag + (size_t)m * KG * 256, KG, inb, rt0, lane, acc);
         const int o0 = 16 * m + 4 * q;
         f4 bv = f4{0.f, 0.f, 0.f, 0.f};
-        if (EP == EP_FWD_ACT || EP == EP_FWD_LIN) {
+        if (ep <= EP_FWD_LIN) {                                   // requested ahead of the products
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = o0 + e < nvalid ? bias[o0 + e] : 0.f;
         }
+        f4 acc[RG];
+        gemm_acc<RG>(L.frag + (size_t)m * L.KG * 256, L.KG, inb, rt0, lane, acc, pre, u == wave);
+        if (u + kW8 >= L.MT * per) { nx = prefetch(next, lane, wave); requested = true; }
+        STAMP64(gemm);
 #pragma unroll
         for (int t = 0; t < RG; ++t) {
             f4 *po = reinterpret_cast<f4 *>(outb + (4 * m + q) * FS + (16 * (rt0 + t) + i) * 4);
-            f4 v, cur = f4{0.f, 0.f, 0.f, 0.f};
-            if (EP == EP_GRAD || EP == EP_GRAD0) cur = *po;
+            f4 v = acc[t];
+            if (ep == EP_FWD_ACT) {
+                v += bv;
+                if (act == RNVP_ACT_TANH) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float r = acc[t][e];
-                if (EP == EP_FWD_ACT) r = act_fwd(r + bv[e], act);
-                else if (EP == EP_FWD_LIN) r = r + bv[e];
-                else if (EP == EP_GRAD) r = (act == RNVP_ACT_TANH) ? r * (1.f - cur[e] * cur[e]) : (cur[e] > 0.f ? r : 0.f);
-                if (o0 + e >= nvalid) r = 0.f;
-                v[e] = EP == EP_GRAD0 ? cur[e] + r : r;
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], RNVP_ACT_TANH);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+            } else if (ep == EP_FWD_LIN) {
+                v += bv;
+            } else {
+                const f4 cur = *po;
+                if (ep == EP_GRAD0) v += cur;
+                else if (act == RNVP_ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= fmaf(-cur[e], cur[e], 1.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = cur[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            if (16 * m + 16 > nvalid) {                           // a ragged last tile (wave-uniform): outputs past nvalid are 0
+                const f4 keep = ep == EP_GRAD0 ? *po : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (o0 + e >= nvalid) v[e] = keep[e];
             }
             *po = v;
         }
+        STAMP64(epi);
     }
+    if (!requested) nx = prefetch(next, lane, wave);
+    return nx;
 }
 
-template <int EP>
-__device__ __forceinline__ void gemm(const float *__restrict__ frag, int MT, int KG, const float *inb, float *outb,
-                                     const float *__restrict__ bias, int nvalid, int act, int lane, int wave) {
-    if (MT >= 8) gemm_units<4, EP>(frag, MT, KG, inb, outb, bias, nvalid, act, lane, wave);
-    else if (MT >= 4) gemm_units<2, EP>(frag, MT, KG, inb, outb, bias, nvalid, act, lane, wave);
-    else gemm_units<1, EP>(frag, MT, KG, inb, outb, bias, nvalid, act, lane, wave);
+__device__ __forceinline__ Pre gemm(const Lin &L, const float *inb, float *outb, const float *__restrict__ bias, int nvalid, int ep,
+                                    int act, int lane, int wave, const Pre &pre, const Lin &next, Stamps64 &stp) {
+    if (L.MT >= 8) return gemm_units<4>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, stp);
+    if (L.MT >= 4) return gemm_units<2>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, stp);
+    return gemm_units<1>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, stp);
 }
 
-// one net forward for the block, every hidden activation kept in its own region; the last Linear writes `out` (skipped when null)
-__device__ __forceinline__ void net_fwd64(const float *__restrict__ pk, const float *__restrict__ pn, const KShape &s, const G64 &g,
-                                          float *lds, float *out, int lane, int wave) {
-    const float *cur = lds + g.fgXC * FS;
-    for (int k = 0; k < g.nlin; ++k) {
-        const bool last = k == g.nlin - 1;
-        if (last && !out) break;
-        float *ob = last ? out : lds + g.fgA[k] * FS;
-        if (last) gemm<EP_FWD_LIN>(pk + g.offF[k], g.MT[k], g.KG[k], cur, ob, pn + s.boff[k], g.nout[k], s.act, lane, wave);
-        else gemm<EP_FWD_ACT>(pk + g.offF[k], g.MT[k], g.KG[k], cur, ob, pn + s.boff[k], g.nout[k], s.act, lane, wave);
-        __syncthreads();
-        cur = ob;
-    }
-}
+__device__ __forceinline__ Lin lin_fwd(const float *pk, const G64 &g, int k) { return Lin{pk + g.offF[k], g.MT[k], g.KG[k]}; }
+__device__ __forceinline__ Lin lin_t(const float *pk, const G64 &g, int k) { return Lin{pk + g.offT[k], g.MTt[k], g.KGt[k]}; }
+__device__ __forceinline__ Lin lin_none() { return Lin{nullptr, 0, 0}; }
 
 // weight-gradient unit, accumulated over the block's 64 rows (k-step ks of lane group q stands for row 4 ks + q):
 //   KIND 0: outputs 16 ua .. + 15 (lane i: one value per k-step) x inputs 64 ub + 4 i + e (one b128: four tiles e)
@@ -188,33 +238,37 @@ __device__ __forceinline__ void net_fwd64(const float *__restrict__ pk, const fl
 template <int KIND>
 __device__ __forceinline__ void wgrad_unit(const float *ldsA, const float *ldsB, int ua, int ub, int lane, f4 (&acc)[4], f4 &bs) {
     const int q = lane >> 4, i = lane & 15;
-    if (KIND == 0) {
-        const float *pa = ldsA + (4 * ua + (i >> 2)) * FS + q * 4 + (i & 3);
-        const float *pb = ldsB + (16 * ub + i) * FS + q * 4;
-        float a[2]; f4 b[2];
-        a[0] = pa[0]; b[0] = *reinterpret_cast<const f4 *>(pb);
+    // the four-tile operand: one b128 per k-step at [16 u + i][4 ks + q]; the one-tile operand: one dword at feature 16 u + i
+    const float *p4 = (KIND == 0 ? ldsB + (16 * ub + i) * FS : ldsA + (16 * ua + i) * FS) + q * 4;
+    const float *p1 = (KIND == 0 ? ldsA + (4 * ua + (i >> 2)) * FS : ldsB + (4 * ub + (i >> 2)) * FS) + q * 4 + (i & 3);
+    f4 w0 = *reinterpret_cast<const f4 *>(p4), w1;
+    float n0 = p1[0], n1;
+    auto mul = [&](const f4 &w, float nv) {
+        if (KIND == 0) {
+            bs[0] += nv;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) { a[(ks + 1) & 1] = pa[(ks + 1) * 16]; b[(ks + 1) & 1] = *reinterpret_cast<const f4 *>(pb + (ks + 1) * 16); }
-            const float av = a[ks & 1]; const f4 bv = b[ks & 1];
-            bs[0] += av;
+            for (int e = 0; e < 4; ++e) acc[e] = mfma16(nv, w[e], acc[e]);
+        } else {
+            bs += w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = mfma16(av, bv[e], acc[e]);
+            for (int e = 0; e < 4; ++e) acc[e] = mfma16(w[e], nv, acc[e]);
         }
-    } else {
-        const float *pa = ldsA + (16 * ua + i) * FS + q * 4;
-        const float *pb = ldsB + (4 * ub + (i >> 2)) * FS + q * 4 + (i & 3);
-        f4 a[2]; float b[2];
-        a[0] = *reinterpret_cast<const f4 *>(pa); b[0] = pb[0];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) { a[(ks + 1) & 1] = *reinterpret_cast<const f4 *>(pa + (ks + 1) * 16); b[(ks + 1) & 1] = pb[(ks + 1) * 16]; }
-            const f4 av = a[ks & 1]; const float bv = b[ks & 1];
-            bs += av;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = mfma16(av[e], bv, acc[e]);
-        }
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < 14; ks += 2) {                           // no load under a branch (see gemm_acc): the last pair is peeled
+        w1 = *reinterpret_cast<const f4 *>(p4 + (ks + 1) * 16); n1 = p1[(ks + 1) * 16];
+        __builtin_amdgcn_sched_barrier(0);
+        mul(w0, n0);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = *reinterpret_cast<const f4 *>(p4 + (ks + 2) * 16); n0 = p1[(ks + 2) * 16];
+        __builtin_amdgcn_sched_barrier(0);
+        mul(w1, n1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    w1 = *reinterpret_cast<const f4 *>(p4 + 15 * 16); n1 = p1[15 * 16];
+    __builtin_amdgcn_sched_barrier(0);
+    mul(w0, n0);
+    mul(w1, n1);
 }
 
 // block-wide copies between a region of the image and its [feature group][64 rows][4] copy in global memory
@@ -225,6 +279,24 @@ __device__ __forceinline__ void region_load(float *reg, const float *__restrict_
 __device__ __forceinline__ void region_store(const float *reg, float *__restrict__ dst, int fgs, int tid) {
     for (int e = tid; e < fgs * BR; e += 64 * kW8)
         *reinterpret_cast<f4 *>(dst + (size_t)e * 4) = *reinterpret_cast<const f4 *>(reg + (e >> 6) * FS + (e & 63) * 4);
+}
+
+// one net forward for the block, every hidden activation kept in its own region; the last Linear writes `out` (skipped when
+// null).  `pre` = prefetch(Linear 0 of this net); returns prefetch(`after`).
+__device__ __forceinline__ Pre net_fwd64(const float *__restrict__ pk, const float *__restrict__ pn, const KShape &s, const G64 &g,
+                                         float *lds, float *out, int lane, int wave, Pre pre, const Lin &after, Stamps64 &stp) {
+    const float *cur = lds + g.fgXC * FS;
+    const int nl = out ? g.nlin : g.nlin - 1;
+#pragma unroll 1
+    for (int k = 0; k < nl; ++k) {
+        const bool last = k == g.nlin - 1;
+        float *ob = last ? out : lds + g.fgA[k] * FS;
+        pre = gemm(lin_fwd(pk, g, k), cur, ob, pn + s.boff[k], g.nout[k], last ? EP_FWD_LIN : EP_FWD_ACT, s.act, lane, wave, pre,
+                   k + 1 < nl ? lin_fwd(pk, g, k + 1) : after, stp);
+        SYNC64();
+        cur = ob;
+    }
+    return pre;
 }
 
 __global__ void __launch_bounds__(64 * kW8)
@@ -246,8 +318,14 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
     const float *__restrict__ gz = sd.gz;
     const size_t xs_blk = (size_t)s.L * g.xc_fgs * BR * 4, gy_blk = (size_t)g.d_fgs * BR * 4;
     float wave_sum = 0.f;
+    Stamps64 stp = {};
+#ifdef RNVP_STAMP
+    const unsigned long long tk0 = __builtin_readcyclecounter();
+    stp.t0 = tk0;
+#endif
 
     // ---- forward over the workgroup's blocks: saves every layer's input image and the seed of the backward ----
+#pragma unroll 1
     for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const int64_t base = b * BR;
         for (int e = tid; e < BR * d; e += 64 * kW8) {
@@ -260,15 +338,18 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
             const int64_t r = base + rr;
             XC[(jj >> 2) * FS + rr * 4 + (jj & 3)] = r < n ? c[(row_index ? row_index[r] : r) * cd + j] : 0.f;
         }
-        __syncthreads();
+        Pre pre = prefetch(lin_fwd(packed, g, 0), lane, wave);
+        SYNC64();
         float ld = 0.f;
-        for (int l = 0; l < s.L; ++l) {
-            const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
-            region_store(XC, xsave + (size_t)b * xs_blk + (size_t)l * g.xc_fgs * BR * 4, g.xc_fgs, tid);
-            net_fwd64(pk, pn, s, g, lds, T, lane, wave);
-            net_fwd64(pk + g.net_floats, pn + s.npn, s, g, lds, S, lane, wave);
+#pragma unroll 1
+        for (int ln = 0; ln < 2 * s.L; ++ln) {                    // (layer, net): t then s
+            const int l = ln >> 1, net = ln & 1;
+            if (net == 0) region_store(XC, xsave + (size_t)b * xs_blk + (size_t)l * g.xc_fgs * BR * 4, g.xc_fgs, tid);
+            pre = net_fwd64(packed + (size_t)ln * g.net_floats, params + (size_t)ln * s.npn, s, g, lds, net ? S : T, lane, wave, pre,
+                            ln + 1 < 2 * s.L ? lin_fwd(packed + (size_t)(ln + 1) * g.net_floats, g, 0) : lin_none(), stp);
+            if (net == 0) continue;
             const uint8_t *m = masks + l * d;
-            for (int fg = wave; fg < g.d_fgs; fg += kW8) {
+            for (int fg = wave; fg < g.d_fgs; fg += kW8) {       // the coupling, realnvp.py:91-101
                 f4 *px = reinterpret_cast<f4 *>(XC + fg * FS + row * 4);
                 f4 xv = *px;
                 const f4 sv = *reinterpret_cast<const f4 *>(S + fg * FS + row * 4), tv = *reinterpret_cast<const f4 *>(T + fg * FS + row * 4);
@@ -279,7 +360,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
                 }
                 *px = xv;
             }
-            __syncthreads();
+            SYNC64();
         }
         {   // loss terms of the block's rows and the seed d loss / d z
             const int64_t r = base + row;
@@ -297,7 +378,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
                 *reinterpret_cast<f4 *>(gysave + (size_t)b * gy_blk + ((size_t)fg * BR + row) * 4) = gv;
             }
             RED[wave * 64 + row] = ld; RED[(kW8 + wave) * 64 + row] = ss;
-            __syncthreads();
+            SYNC64();
             if (wave == 0) {
                 float lds_ = 0.f, sss = 0.f;
 #pragma unroll
@@ -306,103 +387,114 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
                 wave_sum += v;
             }
-            __syncthreads();
+            SYNC64();
         }
     }
     if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;      // chunks run in order on one stream
 
     // ---- backward: layer-major over the blocks; a wave's weight-gradient units stay in registers across its blocks ----
-    for (int l = s.L - 1; l >= 0; --l) {
+#pragma unroll 1
+    for (int ln = 2 * s.L - 1; ln >= 0; --ln) {                  // (layer, net): s first -- t only adds to what s leaves in GYB
+        const int l = ln >> 1, net = ln & 1;
         const uint8_t *m = masks + l * d;
-        for (int net = 1; net >= 0; --net) {                     // s first: t only adds to what s leaves in GYB
-            const float *pkn = packed + ((size_t)l * 2 + net) * g.net_floats, *pnn = params + ((size_t)l * 2 + net) * s.npn;
-            f4 acc[kSlots][4], bs[kSlots];
+        const float *pkn = packed + (size_t)ln * g.net_floats, *pnn = params + (size_t)ln * s.npn;
+        f4 acc[kSlots][4], bs[kSlots];
 #pragma unroll
-            for (int sl = 0; sl < kSlots; ++sl) {
-                bs[sl] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < kSlots; ++sl) {
+            bs[sl] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[sl][e] = f4{0.f, 0.f, 0.f, 0.f};
-            }
-            for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-                const int64_t r = b * BR + row;
-                const bool valid = r < n;
-                region_load(XC, xsave + (size_t)b * xs_blk + (size_t)l * g.xc_fgs * BR * 4, g.xc_fgs, tid);
-                region_load(GY, gysave + (size_t)b * gy_blk, g.d_fgs, tid);
-                if (net == 0) region_load(GYB, gybsave + (size_t)b * gy_blk, g.d_fgs, tid);
-                __syncthreads();
-                net_fwd64(pkn, pnn, s, g, lds, net ? S : nullptr, lane, wave);
-                const float gld = valid ? (sd.gld ? sd.gld[r] : -inv_B) : 0.f;
-                for (int fg = wave; fg < g.d_fgs; fg += kW8) {
-                    const f4 gy = *reinterpret_cast<const f4 *>(GY + fg * FS + row * 4);
-                    f4 go, gyb;
-                    if (net) {
-                        const f4 xv = *reinterpret_cast<const f4 *>(XC + fg * FS + row * 4), sv = *reinterpret_cast<const f4 *>(S + fg * FS + row * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int j = 4 * fg + e;
-                            const bool tr = j < d && !m[j];             // a transformed feature
-                            const float es = expf(sv[e]);
-                            go[e] = tr ? fmaf(gy[e] * xv[e], es, gld) : 0.f;      // d / d s: (1-m)(gy x e^s + gld)
-                            gyb[e] = j < d ? (tr ? gy[e] * es : gy[e]) : 0.f;     // the direct part of d loss / d x
-                        }
-                        *reinterpret_cast<f4 *>(GYB + fg * FS + row * 4) = gyb;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const int j = 4 * fg + e; go[e] = (j < d && !m[j]) ? gy[e] : 0.f; }     // d / d t: (1-m) gy
-                    }
-                    *reinterpret_cast<f4 *>(GO + fg * FS + row * 4) = go;
-                }
-                __syncthreads();
-                for (int k = g.nlin - 1; k >= 0; --k) {
-                    const float *ga = k == g.nlin - 1 ? GO : lds + g.fgA[k] * FS;              // pre-activation gradient of Linear k
-                    float *in = k == 0 ? XC : lds + g.fgA[k - 1] * FS;                         // its input
-#pragma unroll
-                    for (int sl = 0; sl < kSlots; ++sl) {
-                        const int ul = kW8 * sl + wave - g.uoff[k];
-                        if (ul >= 0 && ul < g.unA[k] * g.unB[k]) {
-                            const int ua = ul / g.unB[k], ub = ul - ua * g.unB[k];
-                            if (g.ukind[k] == 0) wgrad_unit<0>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
-                            else wgrad_unit<1>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
-                        }
-                    }
-                    __syncthreads();
-                    if (k == 0) gemm<EP_GRAD0>(pkn + g.offT[0], g.MTt[0], g.KGt[0], ga, GYB, nullptr, d, s.act, lane, wave);
-                    else gemm<EP_GRAD>(pkn + g.offT[k], g.MTt[k], g.KGt[k], ga, in, nullptr, g.nin[k], s.act, lane, wave);
-                    __syncthreads();
-                }
-                region_store(GYB, (net ? gybsave : gysave) + (size_t)b * gy_blk, g.d_fgs, tid);
-                if (net == 0 && l == 0 && sd.gx) {                      // rnvp_backward: d loss / d x of the batch rows
-                    for (int fg = wave; fg < g.d_fgs; fg += kW8) {
-                        const f4 gv = *reinterpret_cast<const f4 *>(GYB + fg * FS + row * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const int j = 4 * fg + e; if (valid && j < d) sd.gx[r * d + j] = gv[e]; }
-                    }
-                }
-                __syncthreads();
-            }
-            // flush this (layer, net)'s units: [workgroup][layer, net][unit][4 tiles x 64 lanes x 4 | 64 bias sums]
-            float *dst = gpart + (((size_t)blockIdx.x * g.nnets + (size_t)l * 2 + net) * g.nunits) * kUnitFloats;
-#pragma unroll
-            for (int sl = 0; sl < kSlots; ++sl) {
-                const int u = kW8 * sl + wave;
-                if (u < g.nunits) {
-                    float *du = dst + (size_t)u * kUnitFloats;
+            for (int e = 0; e < 4; ++e) acc[sl][e] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+            const int64_t r = b * BR + row;
+            const bool valid = r < n;
+            region_load(XC, xsave + (size_t)b * xs_blk + (size_t)l * g.xc_fgs * BR * 4, g.xc_fgs, tid);
+            region_load(GY, gysave + (size_t)b * gy_blk, g.d_fgs, tid);
+            if (net == 0) region_load(GYB, gybsave + (size_t)b * gy_blk, g.d_fgs, tid);
+            Pre pre = prefetch(lin_fwd(pkn, g, 0), lane, wave);
+            SYNC64();
+            pre = net_fwd64(pkn, pnn, s, g, lds, net ? S : nullptr, lane, wave, pre, lin_t(pkn, g, g.nlin - 1), stp);
+            const float gld = valid ? (sd.gld ? sd.gld[r] : -inv_B) : 0.f;
+            for (int fg = wave; fg < g.d_fgs; fg += kW8) {
+                const f4 gy = *reinterpret_cast<const f4 *>(GY + fg * FS + row * 4);
+                f4 go, gyb;
+                if (net) {
+                    const f4 xv = *reinterpret_cast<const f4 *>(XC + fg * FS + row * 4), sv = *reinterpret_cast<const f4 *>(S + fg * FS + row * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        f4 *o = reinterpret_cast<f4 *>(du + e * 256 + lane * 4);
-                        *o = first_chunk ? acc[sl][e] : *o + acc[sl][e];             // row chunks of one call, in order: deterministic
+                        const int j = 4 * fg + e;
+                        const bool tr = j < d && !m[j];             // a transformed feature
+                        const float es = expf(sv[e]);
+                        go[e] = tr ? fmaf(gy[e] * xv[e], es, gld) : 0.f;      // d / d s: (1-m)(gy x e^s + gld)
+                        gyb[e] = j < d ? (tr ? gy[e] * es : gy[e]) : 0.f;     // the direct part of d loss / d x
                     }
-                    f4 bv = bs[sl];
+                    *reinterpret_cast<f4 *>(GYB + fg * FS + row * 4) = gyb;
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bv[e] += __shfl_xor(bv[e], 16); bv[e] += __shfl_xor(bv[e], 32); }
-                    if (lane < 16) {
-                        f4 *o = reinterpret_cast<f4 *>(du + 1024 + lane * 4);
-                        *o = first_chunk ? bv : *o + bv;
+                    for (int e = 0; e < 4; ++e) { const int j = 4 * fg + e; go[e] = (j < d && !m[j]) ? gy[e] : 0.f; }     // d / d t: (1-m) gy
+                }
+                *reinterpret_cast<f4 *>(GO + fg * FS + row * 4) = go;
+            }
+            SYNC64();
+#pragma unroll 1
+            for (int k = g.nlin - 1; k >= 0; --k) {
+                const float *ga = k == g.nlin - 1 ? GO : lds + g.fgA[k] * FS;              // pre-activation gradient of Linear k
+                float *in = k == 0 ? XC : lds + g.fgA[k - 1] * FS;                         // its input
+                STAMP64(other);
+#pragma unroll
+                for (int sl = 0; sl < kSlots; ++sl) {
+                    const int ul = kW8 * sl + wave - g.uoff[k];
+                    if (ul >= 0 && ul < g.unA[k] * g.unB[k]) {
+                        const int ua = ul / g.unB[k], ub = ul - ua * g.unB[k];
+                        if (g.ukind[k] == 0) wgrad_unit<0>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
+                        else wgrad_unit<1>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
                     }
+                }
+                STAMP64(wgrad);
+                SYNC64();
+                pre = gemm(lin_t(pkn, g, k), ga, k ? in : GYB, nullptr, k ? g.nin[k] : d, k ? EP_GRAD : EP_GRAD0, s.act, lane, wave, pre,
+                           k ? lin_t(pkn, g, k - 1) : lin_none(), stp);
+                SYNC64();
+            }
+            region_store(GYB, (net ? gybsave : gysave) + (size_t)b * gy_blk, g.d_fgs, tid);
+            if (net == 0 && l == 0 && sd.gx) {                      // rnvp_backward: d loss / d x of the batch rows
+                for (int fg = wave; fg < g.d_fgs; fg += kW8) {
+                    const f4 gv = *reinterpret_cast<const f4 *>(GYB + fg * FS + row * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const int j = 4 * fg + e; if (valid && j < d) sd.gx[r * d + j] = gv[e]; }
+                }
+            }
+            SYNC64();
+        }
+        // flush this (layer, net)'s units: [workgroup][layer, net][unit][4 tiles x 64 lanes x 4 | 64 bias sums]
+        float *dst = gpart + (((size_t)blockIdx.x * g.nnets + ln) * g.nunits) * kUnitFloats;
+#pragma unroll
+        for (int sl = 0; sl < kSlots; ++sl) {
+            const int u = kW8 * sl + wave;
+            if (u < g.nunits) {
+                float *du = dst + (size_t)u * kUnitFloats;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f4 *o = reinterpret_cast<f4 *>(du + e * 256 + lane * 4);
+                    *o = first_chunk ? acc[sl][e] : *o + acc[sl][e];             // row chunks of one call, in order: deterministic
+                }
+                f4 bv = bs[sl];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bv[e] += __shfl_xor(bv[e], 16); bv[e] += __shfl_xor(bv[e], 32); }
+                if (lane < 16) {
+                    f4 *o = reinterpret_cast<f4 *>(du + 1024 + lane * 4);
+                    *o = first_chunk ? bv : *o + bv;
                 }
             }
         }
     }
+#ifdef RNVP_STAMP
+    STAMP64(other);
+    if (blockIdx.x == 0 && lane == 0)
+        printf("STAMP64 wave %d total %llu gemm %llu epilogue %llu barrier %llu wgrad %llu other %llu\n", wave,
+               __builtin_readcyclecounter() - tk0, stp.gemm, stp.epi, stp.bar, stp.wgrad, stp.other);
+#endif
 }
 
 // flat reference-order gradient: thread = one float of one (layer, net)'s unit partials; sums the workgroups in index order and
