@@ -56,6 +56,7 @@ struct G64 {
     int unA[kMaxLin], unB[kMaxLin], uoff[kMaxLin], nunits;
     int fgA[kMaxLin];                      // feature-group offset of hidden activation k in the image
     int fgXC, fgT, fgS, fgGY, fgGYB, fgGO, fg_total, xc_fgs, d_fgs;
+    int h_fgs;                             // feature groups of all hidden regions (contiguous from fgA[0]): one net's saved activations
     size_t lds_bytes;
 };
 
@@ -162,7 +163,8 @@ enum { EP_FWD_ACT = 0, EP_FWD_LIN, EP_GRAD, EP_GRAD0 };
 // product and its epilogue.  One instantiation per RG serves every call: the kernel's code has to stay inside the instruction cache.
 template <int RG>
 __device__ __forceinline__ Pre gemm_units(const Lin &L, const float *inb, float *outb, const float *__restrict__ bias, int nvalid,
-                                          int ep, int act, int lane, int wave, const Pre &pre, const Lin &next, Stamps64 &stp) {
+                                          int ep, int act, int lane, int wave, const Pre &pre, const Lin &next, float *__restrict__ gsave,
+                                          Stamps64 &stp) {
     constexpr int per = 4 / RG;
     const int q = lane >> 4, i = lane & 15;
     Pre nx;
@@ -194,6 +196,12 @@ __device__ __forceinline__ Pre gemm_units(const Lin &L, const float *inb, float 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if (16 * m + 16 > nvalid) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (o0 + e >= nvalid) v[e] = 0.f;
+                }
+                // the backward reads the activation back instead of recomputing the net: [feature group][64 rows][4], as the region
+                if (gsave) *reinterpret_cast<f4 *>(gsave + ((size_t)(4 * m + q) * BR + 16 * (rt0 + t) + i) * 4) = v;
             } else if (ep == EP_FWD_LIN) {
                 v += bv;
             } else {
@@ -221,10 +229,10 @@ __device__ __forceinline__ Pre gemm_units(const Lin &L, const float *inb, float 
 }
 
 __device__ __forceinline__ Pre gemm(const Lin &L, const float *inb, float *outb, const float *__restrict__ bias, int nvalid, int ep,
-                                    int act, int lane, int wave, const Pre &pre, const Lin &next, Stamps64 &stp) {
-    if (L.MT >= 8) return gemm_units<4>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, stp);
-    if (L.MT >= 4) return gemm_units<2>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, stp);
-    return gemm_units<1>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, stp);
+                                    int act, int lane, int wave, const Pre &pre, const Lin &next, float *__restrict__ gsave, Stamps64 &stp) {
+    if (L.MT >= 8) return gemm_units<4>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, gsave, stp);
+    if (L.MT >= 4) return gemm_units<2>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, gsave, stp);
+    return gemm_units<1>(L, inb, outb, bias, nvalid, ep, act, lane, wave, pre, next, gsave, stp);
 }
 
 __device__ __forceinline__ Lin lin_fwd(const float *pk, const G64 &g, int k) { return Lin{pk + g.offF[k], g.MT[k], g.KG[k]}; }
@@ -281,18 +289,28 @@ __device__ __forceinline__ void region_store(const float *reg, float *__restrict
         *reinterpret_cast<f4 *>(dst + (size_t)e * 4) = *reinterpret_cast<const f4 *>(reg + (e >> 6) * FS + (e & 63) * 4);
 }
 
-// one net forward for the block, every hidden activation kept in its own region; the last Linear writes `out` (skipped when
-// null).  `pre` = prefetch(Linear 0 of this net); returns prefetch(`after`).
+// the same copy global -> image as LDS-DMA: one wave instruction moves a feature group (64 lanes x 16 bytes to a wave-uniform LDS
+// base + lane * 16), no registers, completion counted by vmcnt
+__device__ __forceinline__ void region_dma(float *reg, const float *__restrict__ src, int fgs, int lane, int wave) {
+    for (int fg = wave; fg < fgs; fg += kW8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(src + ((size_t)fg * BR + lane) * 4),
+                                         (__attribute__((address_space(3))) uint32_t *)(reg + fg * FS), 16, 0, 0);
+}
+
+// one net forward for the block, every hidden activation kept in its own region (and saved to `asave`, the net's
+// [hidden feature groups][64 rows][4] block, for the backward); the last Linear writes `out`.
+// `pre` = prefetch(Linear 0 of this net); returns prefetch(`after`).
 __device__ __forceinline__ Pre net_fwd64(const float *__restrict__ pk, const float *__restrict__ pn, const KShape &s, const G64 &g,
-                                         float *lds, float *out, int lane, int wave, Pre pre, const Lin &after, Stamps64 &stp) {
+                                         float *lds, float *out, float *__restrict__ asave, int lane, int wave, Pre pre, const Lin &after,
+                                         Stamps64 &stp) {
     const float *cur = lds + g.fgXC * FS;
-    const int nl = out ? g.nlin : g.nlin - 1;
+    const int nl = g.nlin;
 #pragma unroll 1
     for (int k = 0; k < nl; ++k) {
         const bool last = k == g.nlin - 1;
         float *ob = last ? out : lds + g.fgA[k] * FS;
         pre = gemm(lin_fwd(pk, g, k), cur, ob, pn + s.boff[k], g.nout[k], last ? EP_FWD_LIN : EP_FWD_ACT, s.act, lane, wave, pre,
-                   k + 1 < nl ? lin_fwd(pk, g, k + 1) : after, stp);
+                   k + 1 < nl ? lin_fwd(pk, g, k + 1) : after, last ? nullptr : asave + (size_t)(g.fgA[k] - g.fgA[0]) * BR * 4, stp);
         SYNC64();
         cur = ob;
     }
@@ -303,8 +321,8 @@ __global__ void __launch_bounds__(64 * kW8)
 k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__restrict__ params,
               const uint8_t *__restrict__ masks, const float *__restrict__ x, const float *__restrict__ c,
               const int64_t *__restrict__ row_index, int64_t n, float inv_B, Seeds sd, float *__restrict__ xsave,
-              float *__restrict__ gysave, float *__restrict__ gybsave, float *__restrict__ gpart, float *__restrict__ losspart,
-              int first_chunk) {
+              float *__restrict__ gysave, float *__restrict__ gybsave, float *__restrict__ asave, float *__restrict__ ssave,
+              float *__restrict__ gpart, float *__restrict__ losspart, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), d = s.d, cd = s.c;
     const int row = lane;                                   // elementwise passes: thread = (row, feature group wave, wave + 8, ..)
@@ -316,7 +334,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
     const int64_t nblocks = (n + BR - 1) / BR;
     const float prior_c = 0.5f * (float)d * kLog2Pi;
     const float *__restrict__ gz = sd.gz;
-    const size_t xs_blk = (size_t)s.L * g.xc_fgs * BR * 4, gy_blk = (size_t)g.d_fgs * BR * 4;
+    const size_t xs_blk = (size_t)s.L * g.xc_fgs * BR * 4, gy_blk = (size_t)g.d_fgs * BR * 4, as_net = (size_t)g.h_fgs * BR * 4;
     float wave_sum = 0.f;
     Stamps64 stp = {};
 #ifdef RNVP_STAMP
@@ -345,9 +363,11 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
         for (int ln = 0; ln < 2 * s.L; ++ln) {                    // (layer, net): t then s
             const int l = ln >> 1, net = ln & 1;
             if (net == 0) region_store(XC, xsave + (size_t)b * xs_blk + (size_t)l * g.xc_fgs * BR * 4, g.xc_fgs, tid);
-            pre = net_fwd64(packed + (size_t)ln * g.net_floats, params + (size_t)ln * s.npn, s, g, lds, net ? S : T, lane, wave, pre,
+            pre = net_fwd64(packed + (size_t)ln * g.net_floats, params + (size_t)ln * s.npn, s, g, lds, net ? S : T,
+                            asave + ((size_t)b * g.nnets + ln) * as_net, lane, wave, pre,
                             ln + 1 < 2 * s.L ? lin_fwd(packed + (size_t)(ln + 1) * g.net_floats, g, 0) : lin_none(), stp);
             if (net == 0) continue;
+            region_store(S, ssave + ((size_t)b * s.L + l) * gy_blk, g.d_fgs, tid);
             const uint8_t *m = masks + l * d;
             for (int fg = wave; fg < g.d_fgs; fg += kW8) {       // the coupling, realnvp.py:91-101
                 f4 *px = reinterpret_cast<f4 *>(XC + fg * FS + row * 4);
@@ -392,12 +412,16 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
     }
     if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;      // chunks run in order on one stream
 
-    // ---- backward: layer-major over the blocks; a wave's weight-gradient units stay in registers across its blocks ----
+    // ---- backward: layer-major over the blocks; a wave's weight-gradient units stay in registers across its blocks.  A visit
+    // (layer, net, block) reloads the block's layer input, d loss / d (layer output), the s net's output and the net's hidden
+    // activations; the activations arrive by LDS-DMA, each region requested as soon as the previous visit is done with it ----
+    float *H0 = lds + g.fgA[0] * FS;
+    if (blockIdx.x < nblocks) region_dma(H0, asave + ((size_t)blockIdx.x * g.nnets + 2 * s.L - 1) * as_net, g.h_fgs, lane, wave);
 #pragma unroll 1
     for (int ln = 2 * s.L - 1; ln >= 0; --ln) {                  // (layer, net): s first -- t only adds to what s leaves in GYB
         const int l = ln >> 1, net = ln & 1;
         const uint8_t *m = masks + l * d;
-        const float *pkn = packed + (size_t)ln * g.net_floats, *pnn = params + (size_t)ln * s.npn;
+        const float *pkn = packed + (size_t)ln * g.net_floats;
         f4 acc[kSlots][4], bs[kSlots];
 #pragma unroll
         for (int sl = 0; sl < kSlots; ++sl) {
@@ -409,12 +433,17 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
         for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
             const int64_t r = b * BR + row;
             const bool valid = r < n;
+            // the visit after this one: the next block of the same (layer, net), else the first block of the next net down
+            const bool more = b + gridDim.x < nblocks;
+            const float *anext = (more || ln > 0) ? asave + ((size_t)(more ? b + gridDim.x : blockIdx.x) * g.nnets + (more ? ln : ln - 1)) * as_net
+                                                  : nullptr;
             region_load(XC, xsave + (size_t)b * xs_blk + (size_t)l * g.xc_fgs * BR * 4, g.xc_fgs, tid);
             region_load(GY, gysave + (size_t)b * gy_blk, g.d_fgs, tid);
             if (net == 0) region_load(GYB, gybsave + (size_t)b * gy_blk, g.d_fgs, tid);
-            Pre pre = prefetch(lin_fwd(pkn, g, 0), lane, wave);
+            else region_load(S, ssave + ((size_t)b * s.L + l) * gy_blk, g.d_fgs, tid);
+            Pre pre = prefetch(lin_t(pkn, g, g.nlin - 1), lane, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the DMA'd activations of this visit
             SYNC64();
-            pre = net_fwd64(pkn, pnn, s, g, lds, net ? S : nullptr, lane, wave, pre, lin_t(pkn, g, g.nlin - 1), stp);
             const float gld = valid ? (sd.gld ? sd.gld[r] : -inv_B) : 0.f;
             for (int fg = wave; fg < g.d_fgs; fg += kW8) {
                 const f4 gy = *reinterpret_cast<const f4 *>(GY + fg * FS + row * 4);
@@ -454,8 +483,11 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
                 STAMP64(wgrad);
                 SYNC64();
                 pre = gemm(lin_t(pkn, g, k), ga, k ? in : GYB, nullptr, k ? g.nin[k] : d, k ? EP_GRAD : EP_GRAD0, s.act, lane, wave, pre,
-                           k ? lin_t(pkn, g, k - 1) : lin_none(), stp);
+                           k ? lin_t(pkn, g, k - 1) : lin_none(), nullptr, stp);
                 SYNC64();
+                // hidden region k is dead from here on: request the next visit's copy of it
+                if (k < g.nlin - 1 && anext)
+                    region_dma(lds + g.fgA[k] * FS, anext + (size_t)(g.fgA[k] - g.fgA[0]) * BR * 4, (g.nout[k] + 15) / 16 * 4, lane, wave);
             }
             region_store(GYB, (net ? gybsave : gysave) + (size_t)b * gy_blk, g.d_fgs, tid);
             if (net == 0 && l == 0 && sd.gx) {                      // rnvp_backward: d loss / d x of the batch rows
@@ -571,6 +603,7 @@ G64 make_g64(const KShape &k) {
     int fg = 0;
     g.fgXC = fg; fg += tiles(k.d + k.c);
     for (int i = 0; i < k.nh; ++i) { g.fgA[i] = fg; fg += tiles(k.nout[i]); }
+    g.h_fgs = fg - g.fgA[0];
     g.fgT = fg; fg += tiles(k.d);
     g.fgS = fg; fg += tiles(k.d);
     g.fgGY = fg; fg += tiles(k.d);
@@ -591,6 +624,14 @@ int grid64(int64_t n) {
 // rows per pass: the saved layer inputs take 4 L (d + c) bytes per row, so a very large call goes through in chunks (every chunk on
 // the same grid: workgroup w's partial always holds the same rows' sums)
 constexpr int64_t kChunkRows = 262144;
+// ... and the saved hidden activations 2 L x 16 bytes per hidden feature group and row: the chunk shrinks (in steps of a full grid
+// of blocks) until they fit ~1 GiB
+int64_t chunk_rows64(const KShape &k, const G64 &g) {
+    const double per_row = (double)g.nnets * g.h_fgs * 16.0;
+    int64_t r = (int64_t)((double)(1u << 30) / per_row) / 16384 * 16384;
+    if (r < 16384) r = 16384;
+    return r < kChunkRows ? r : kChunkRows;
+}
 
 }  // namespace
 
@@ -607,12 +648,14 @@ bool use_train64(const KShape &k, int64_t n) {
 
 size_t train64_workspace_bytes(const KShape &k, int64_t max_rows) {
     const G64 g = make_g64(k);
-    if (max_rows > kChunkRows) max_rows = kChunkRows;
+    if (max_rows > chunk_rows64(k, g)) max_rows = chunk_rows64(k, g);
     const int64_t nblocks = (max_rows + BR - 1) / BR;
     size_t b = align_up((size_t)g.nnets * g.net_floats * sizeof(float), 256);
     b += align_up((size_t)256 * sizeof(float), 256);
     b += align_up((size_t)nblocks * k.L * g.xc_fgs * BR * 4 * sizeof(float), 256);
     b += 2 * align_up((size_t)nblocks * g.d_fgs * BR * 4 * sizeof(float), 256);
+    b += align_up((size_t)nblocks * g.nnets * g.h_fgs * BR * 4 * sizeof(float), 256);                // hidden activations
+    b += align_up((size_t)nblocks * k.L * g.d_fgs * BR * 4 * sizeof(float), 256);                    // s outputs
     b += align_up((size_t)grid64(max_rows) * g.nnets * g.nunits * kUnitFloats * sizeof(float), 256);
     return b;
 }
@@ -622,7 +665,7 @@ int loss_grad64(hipStream_t st, const KShape &k, const float *params, const uint
                 Seeds sd) {
     if (!ws || ws_bytes < train64_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
     const G64 g = make_g64(k);
-    const int64_t cr = n < kChunkRows ? n : kChunkRows;
+    const int64_t cr = n < chunk_rows64(k, g) ? n : chunk_rows64(k, g);
     const int64_t nblocks = (cr + BR - 1) / BR;
     const int G = grid64(cr);
     char *w = static_cast<char *>(ws);
@@ -631,6 +674,8 @@ int loss_grad64(hipStream_t st, const KShape &k, const float *params, const uint
     float *xsave = reinterpret_cast<float *>(w); w += align_up((size_t)nblocks * k.L * g.xc_fgs * BR * 4 * sizeof(float), 256);
     float *gysave = reinterpret_cast<float *>(w); w += align_up((size_t)nblocks * g.d_fgs * BR * 4 * sizeof(float), 256);
     float *gybsave = reinterpret_cast<float *>(w); w += align_up((size_t)nblocks * g.d_fgs * BR * 4 * sizeof(float), 256);
+    float *asave = reinterpret_cast<float *>(w); w += align_up((size_t)nblocks * g.nnets * g.h_fgs * BR * 4 * sizeof(float), 256);
+    float *ssave = reinterpret_cast<float *>(w); w += align_up((size_t)nblocks * k.L * g.d_fgs * BR * 4 * sizeof(float), 256);
     float *gpart = reinterpret_cast<float *>(w);
     {
         const int64_t total = (int64_t)g.nnets * g.net_floats;
@@ -650,7 +695,7 @@ int loss_grad64(hipStream_t st, const KShape &k, const float *params, const uint
                            row_index ? x : x + r0 * k.d, (row_index || !c) ? c : c + r0 * k.c, row_index ? row_index + r0 : nullptr,
                            rows, inv_B,
                            Seeds{sd.gz ? sd.gz + r0 * k.d : nullptr, sd.gld ? sd.gld + r0 : nullptr, sd.gx ? sd.gx + r0 * k.d : nullptr},
-                           xsave, gysave, gybsave, gpart, losspart, r0 == 0 ? 1 : 0);
+                           xsave, gysave, gybsave, asave, ssave, gpart, losspart, r0 == 0 ? 1 : 0);
         RNVP_HIP_TRY(hipGetLastError());
     }
     const size_t total = (size_t)g.nnets * g.nunits * kUnitFloats;
