@@ -34,7 +34,7 @@ constexpr int kSlackFg = 16;           // zeroed feature groups past the last re
 
 // RNVP_STAMP: diagnostic build that accumulates cycle-counter deltas per kind of work and printf()s them for workgroup 0 (read
 // the SHARES, not the absolute time: the stamps serialise the wave)
-struct Stamps64 { unsigned long long t0, gemm, epi, bar, wgrad, other; };
+struct Stamps64 { unsigned long long t0, gemm, epi, bar, wgrad, other, load, elem, fwdx; };
 #ifdef RNVP_STAMP
 #define STAMP64(field) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1__ = __builtin_readcyclecounter(); \
                             __builtin_amdgcn_sched_barrier(0); stp.field += t1__ - stp.t0; stp.t0 = t1__; } while (0)
@@ -52,7 +52,8 @@ struct G64 {
     int MTt[kMaxLin], KGt[kMaxLin];        // transposed (input gradient): in tiles, groups of 16 outputs
     int offF[kMaxLin], offT[kMaxLin];      // float offsets of the fragment blocks inside one net's packed image
     int net_floats;
-    int ukind[kMaxLin];                    // weight-gradient units of Linear k: 0 = 16 outputs x 64 inputs, 1 = 64 outputs x 16 inputs
+    int ukind[kMaxLin];                    // weight-gradient units of Linear k: 0 = 16 outputs x 64 inputs, 1 = 64 outputs x 16 inputs,
+                                           // 2 = 16 x 16 (a Linear of at most 16 outputs: eight small units instead of two large ones)
     int unA[kMaxLin], unB[kMaxLin], uoff[kMaxLin], nunits;
     int fgA[kMaxLin];                      // feature-group offset of hidden activation k in the image
     int fgXC, fgT, fgS, fgGY, fgGYB, fgGO, fg_total, xc_fgs, d_fgs;
@@ -242,10 +243,20 @@ __device__ __forceinline__ Lin lin_none() { return Lin{nullptr, 0, 0}; }
 // weight-gradient unit, accumulated over the block's 64 rows (k-step ks of lane group q stands for row 4 ks + q):
 //   KIND 0: outputs 16 ua .. + 15 (lane i: one value per k-step) x inputs 64 ub + 4 i + e (one b128: four tiles e)
 //   KIND 1: outputs 64 ua + 4 i + e (one b128: four tiles e) x inputs 16 ub .. + 15
+//   KIND 2: outputs 16 ua .. + 15 x inputs 16 ub .. + 15 (one dword each, one tile)
 // bs collects the sums over rows of the A operand (the bias gradient, wanted from the unit with ub == 0).
 template <int KIND>
 __device__ __forceinline__ void wgrad_unit(const float *ldsA, const float *ldsB, int ua, int ub, int lane, f4 (&acc)[4], f4 &bs) {
     const int q = lane >> 4, i = lane & 15;
+    if (KIND == 2) {
+        const float *pa = ldsA + (4 * ua + (i >> 2)) * FS + q * 4 + (i & 3), *pb = ldsB + (4 * ub + (i >> 2)) * FS + q * 4 + (i & 3);
+        float a[16], b[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) { a[ks] = pa[ks * 16]; b[ks] = pb[ks * 16]; }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) { bs[0] += a[ks]; acc[0] = mfma16(a[ks], b[ks], acc[0]); }
+        return;
+    }
     // the four-tile operand: one b128 per k-step at [16 u + i][4 ks + q]; the one-tile operand: one dword at feature 16 u + i
     const float *p4 = (KIND == 0 ? ldsB + (16 * ub + i) * FS : ldsA + (16 * ua + i) * FS) + q * 4;
     const float *p1 = (KIND == 0 ? ldsA + (4 * ua + (i >> 2)) * FS : ldsB + (4 * ub + (i >> 2)) * FS) + q * 4 + (i & 3);
@@ -262,7 +273,7 @@ __device__ __forceinline__ void wgrad_unit(const float *ldsA, const float *ldsB,
             for (int e = 0; e < 4; ++e) acc[e] = mfma16(w[e], nv, acc[e]);
         }
     };
-#pragma unroll 1
+#pragma unroll
     for (int ks = 0; ks < 14; ks += 2) {                           // no load under a branch (see gemm_acc): the last pair is peeled
         w1 = *reinterpret_cast<const f4 *>(p4 + (ks + 1) * 16); n1 = p1[(ks + 1) * 16];
         __builtin_amdgcn_sched_barrier(0);
@@ -346,6 +357,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
 #pragma unroll 1
     for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const int64_t base = b * BR;
+        STAMP64(other);
         for (int e = tid; e < BR * d; e += 64 * kW8) {
             const int rr = e / d, j = e - rr * d;
             const int64_t r = base + rr;
@@ -357,6 +369,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
             XC[(jj >> 2) * FS + rr * 4 + (jj & 3)] = r < n ? c[(row_index ? row_index[r] : r) * cd + j] : 0.f;
         }
         Pre pre = prefetch(lin_fwd(packed, g, 0), lane, wave);
+        STAMP64(fwdx);
         SYNC64();
         float ld = 0.f;
 #pragma unroll 1
@@ -434,6 +447,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
             const int64_t r = b * BR + row;
             const bool valid = r < n;
             // the visit after this one: the next block of the same (layer, net), else the first block of the next net down
+            STAMP64(other);
             const bool more = b + gridDim.x < nblocks;
             const float *anext = (more || ln > 0) ? asave + ((size_t)(more ? b + gridDim.x : blockIdx.x) * g.nnets + (more ? ln : ln - 1)) * as_net
                                                   : nullptr;
@@ -443,6 +457,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
             else region_load(S, ssave + ((size_t)b * s.L + l) * gy_blk, g.d_fgs, tid);
             Pre pre = prefetch(lin_t(pkn, g, g.nlin - 1), lane, wave);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the DMA'd activations of this visit
+            STAMP64(load);
             SYNC64();
             const float gld = valid ? (sd.gld ? sd.gld[r] : -inv_B) : 0.f;
             for (int fg = wave; fg < g.d_fgs; fg += kW8) {
@@ -465,6 +480,7 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
                 }
                 *reinterpret_cast<f4 *>(GO + fg * FS + row * 4) = go;
             }
+            STAMP64(elem);
             SYNC64();
 #pragma unroll 1
             for (int k = g.nlin - 1; k >= 0; --k) {
@@ -477,11 +493,12 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
                     if (ul >= 0 && ul < g.unA[k] * g.unB[k]) {
                         const int ua = ul / g.unB[k], ub = ul - ua * g.unB[k];
                         if (g.ukind[k] == 0) wgrad_unit<0>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
-                        else wgrad_unit<1>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
+                        else if (g.ukind[k] == 1) wgrad_unit<1>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
+                        else wgrad_unit<2>(ga, in, ua, ub, lane, acc[sl], bs[sl]);
                     }
                 }
                 STAMP64(wgrad);
-                SYNC64();
+                if (k) SYNC64();              // Linear 0's input gradient goes to GYB, not into its input: it runs beside the units
                 pre = gemm(lin_t(pkn, g, k), ga, k ? in : GYB, nullptr, k ? g.nin[k] : d, k ? EP_GRAD : EP_GRAD0, s.act, lane, wave, pre,
                            k ? lin_t(pkn, g, k - 1) : lin_none(), nullptr, stp);
                 SYNC64();
@@ -524,8 +541,8 @@ k_lmm_train64(KShape s, G64 g, const float *__restrict__ packed, const float *__
 #ifdef RNVP_STAMP
     STAMP64(other);
     if (blockIdx.x == 0 && lane == 0)
-        printf("STAMP64 wave %d total %llu gemm %llu epilogue %llu barrier %llu wgrad %llu other %llu\n", wave,
-               __builtin_readcyclecounter() - tk0, stp.gemm, stp.epi, stp.bar, stp.wgrad, stp.other);
+        printf("STAMP64 wave %d total %llu gemm %llu epilogue %llu barrier %llu wgrad %llu visit-loads %llu elementwise %llu fwd-rows %llu other %llu\n",
+               wave, __builtin_readcyclecounter() - tk0, stp.gemm, stp.epi, stp.bar, stp.wgrad, stp.load, stp.elem, stp.fwdx, stp.other);
 #endif
 }
 
@@ -548,6 +565,7 @@ k_lmm64_reduce(KShape s, G64 g, const float *__restrict__ gpart, int G, const ui
     }
     const int ln = (int)(t / per_net), rest = (int)(t - (size_t)ln * per_net);
     const int u = rest / kUnitFloats, j = rest - u * kUnitFloats;
+    if (u < g.uoff[0]) return;                                  // unit numbers left free (make_g64)
     int k = 0;
     while (k + 1 < g.nlin && u >= g.uoff[k + 1]) ++k;
     const int ul = u - g.uoff[k], ua = ul / g.unB[k], ub = ul - ua * g.unB[k];
@@ -556,12 +574,13 @@ k_lmm64_reduce(KShape s, G64 g, const float *__restrict__ gpart, int G, const ui
     if (j < 1024) {
         const int tile = j >> 8, lane = (j >> 2) & 63, e = j & 3, q = lane >> 4, i = lane & 15;
         if (g.ukind[k] == 0) { out = 16 * ua + 4 * q + e; in = 64 * ub + 4 * i + tile; }
-        else { out = 64 * ua + 4 * (4 * q + e) + tile; in = 16 * ub + i; }
+        else if (g.ukind[k] == 1) { out = 64 * ua + 4 * (4 * q + e) + tile; in = 16 * ub + i; }
+        else { if (tile) return; out = 16 * ua + 4 * q + e; in = 16 * ub + i; }
         if (out >= nout || in >= nin) return;
     } else {
         if (ub != 0) return;
         const int jj = j - 1024;
-        if (g.ukind[k] == 0) { if (jj & 3) return; out = 16 * ua + (jj >> 2); }       // lane i wrote (sum, 0, 0, 0)
+        if (g.ukind[k] != 1) { if (jj & 3) return; out = 16 * ua + (jj >> 2); }      // lane i wrote (sum, 0, 0, 0)
         else out = 64 * ua + jj;                                                       // lane i wrote outputs 64 ua + 4 i + e
         if (out >= nout) return;
         in = nin;
@@ -569,7 +588,15 @@ k_lmm64_reduce(KShape s, G64 g, const float *__restrict__ gpart, int G, const ui
     const float *src = gpart + (size_t)ln * per_net + rest;
     const size_t stride = total;
     float a = 0.f;
-    for (int w = 0; w < G; ++w) a += src[(size_t)w * stride];
+    int w = 0;
+    for (; w + 8 <= G; w += 8) {                                   // eight requests in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(w + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    for (; w < G; ++w) a += src[(size_t)w * stride];
     float scale = 1.f;
     if (k == 0 && in < s.d) scale = (float)masks[(ln >> 1) * s.d + in];             // W'[:, j] = W[:, j] * mask_j
     const size_t p = (size_t)ln * s.npn + (in < nin ? (size_t)s.woff[k] + (size_t)out * nin + in : (size_t)s.boff[k] + out);
@@ -582,6 +609,13 @@ G64 make_g64(const KShape &k) {
     g.nlin = k.nh + 1;
     g.nnets = 2 * k.L;
     int oW = 0, u = 0;
+    // Linear 0's input gradient (one tile for d <= 16: four row-tile units, waves 0-3) runs beside its weight-gradient units: when
+    // those are at most four they take waves 4-7, i.e. unit numbers 4 .. 7 (0 .. 3 stay free)
+    {
+        const int nin0 = k.nin[0], nout0 = k.nout[0];
+        const int n0 = (nin0 <= 32 && nout0 > nin0) ? ((nout0 + 63) / 64) * ((nin0 + 15) / 16) : ((nout0 + 15) / 16) * ((nin0 + 63) / 64);
+        if (k.d <= 16 && n0 <= 4) u = 4;
+    }
     for (int i = 0; i < g.nlin; ++i) {
         g.nin[i] = k.nin[i]; g.nout[i] = k.nout[i];
         g.MT[i] = (k.nout[i] + 15) / 16; g.KG[i] = (k.nin[i] + 15) / 16;
@@ -589,9 +623,10 @@ G64 make_g64(const KShape &k) {
         g.offF[i] = oW; oW += g.MT[i] * g.KG[i] * 256;
         g.offT[i] = oW; oW += g.MTt[i] * g.KGt[i] * 256;
         // few inputs: 64 outputs x 16 inputs per unit wastes less of the four-tile operand than 16 x 64
-        g.ukind[i] = k.nin[i] <= 32 && k.nout[i] > k.nin[i] ? 1 : 0;
+        g.ukind[i] = k.nin[i] <= 32 && k.nout[i] > k.nin[i] ? 1 : ((k.nout[i] <= 16 && k.nin[i] > 16) ? 2 : 0);
         if (g.ukind[i] == 0) { g.unA[i] = (k.nout[i] + 15) / 16; g.unB[i] = (k.nin[i] + 63) / 64; }
-        else { g.unA[i] = (k.nout[i] + 63) / 64; g.unB[i] = (k.nin[i] + 15) / 16; }
+        else if (g.ukind[i] == 1) { g.unA[i] = (k.nout[i] + 63) / 64; g.unB[i] = (k.nin[i] + 15) / 16; }
+        else { g.unA[i] = 1; g.unB[i] = (k.nin[i] + 15) / 16; }
         g.uoff[i] = u; u += g.unA[i] * g.unB[i];
     }
     for (int i = g.nlin; i < kMaxLin; ++i) g.uoff[i] = u;
