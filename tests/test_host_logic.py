@@ -227,7 +227,14 @@ def test_shape_struct_matches_the_c_header():
     assert (size, o_hidden, o_alt, o_prec, o_small, o_fam) == (ctypes.sizeof(S), S.hidden.offset, S.alt_masks.offset,
                                                                S.precision.offset, S.small_calls.offset, S.family.offset)
     assert (csize, co_fam) == (ctypes.sizeof(_hip.CvaeShape), _hip.CvaeShape.family.offset)
-    assert _hip.FAMILIES == {"auto": 0, "valu": 1, "lmm": 2}
+    fam = ('#include <stdio.h>\n#include "include/rnvp_hip.h"\nint main(void){printf("%d %d %d %d %d", RNVP_FAMILY_AUTO, RNVP_FAMILY_VALU, '
+           'RNVP_FAMILY_LMM, RNVP_FAMILY_LMM16, RNVP_FAMILY_LMM64);return 0;}\n')
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "f.c"); exe = os.path.join(td, "f")
+        open(c, "w").write(fam)
+        subprocess.check_call(["gcc", "-std=c99", "-I", ROOT, c, "-o", exe])
+        values = list(map(int, subprocess.check_output([exe]).split()))
+    assert _hip.FAMILIES == dict(zip(["auto", "valu", "lmm", "lmm16", "lmm64"], values)) == {"auto": 0, "valu": 1, "lmm": 2, "lmm16": 3, "lmm64": 4}
     assert _hip.SMALL_CALLS == {"invariant": 0, "latency": 1}
     assert _hip.PRECISIONS == {"auto": 0, "f32": 1, "bx3": 2}
 
