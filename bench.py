@@ -334,6 +334,32 @@ def secondary_configs(Xh, Ch, dev):
                                                 "batch_size=32: %d steps in one cvae_fit_epoch call" % nsteps,
                                     "one_launch_per_epoch": bool(_hip.cvae_fit_epoch_resident(shape_v, bs)),
                                     "us_per_step": us, "rows_per_s": bs / (us * 1e-6), "final_loss": float(losses[-1])}
+    # the C2 arrays through a flow with TWO hidden layers (realnvp.py:22-38 builds any depth): outside the register-chained kernels,
+    # served by the any-shape MFMA kernels -- the training call on 64-row blocks with in-kernel weight gradients (rnvp_lmm64.hip)
+    torch.manual_seed(0)
+    hid2 = (128, 128)
+    layers = [RealNVPLayer(D, CDIM, (torch.arange(D) + i) % 2, hid2, "tanh") for i in range(LAYERS)]
+    nf2 = NormalizingFlow(layers, StandardNormalPrior(D, dev, host_rng=False))
+    for p in nf2.parameters():
+        p.data = p.data.to(dev)
+    eng2 = nf2.engine(); opt2 = _engine.FlatAdam(eng2.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+    K2 = 4
+    perm = torch.randperm(K2 * BATCH, device=dev); losses = torch.zeros(K2, device=dev)
+    eng2.fit_epoch(opt2, X[:K2 * BATCH], C[:K2 * BATCH], perm, BATCH, losses)
+    torch.cuda.synchronize(dev)
+    _hip.profile_enable(64)
+    e0.record()
+    eng2.fit_epoch(opt2, X[:K2 * BATCH], C[:K2 * BATCH], perm, BATCH, losses)
+    e1.record(); torch.cuda.synchronize(dev)
+    n_k, k_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
+    _hip.profile_enable(0)
+    flop_row = 3 * 2 * 2 * LAYERS * ((D + CDIM) * hid2[0] + hid2[0] * hid2[1] + hid2[1] * D)      # dense: the any-shape kernels read masks from a table
+    step_ms = e0.elapsed_time(e1) / K2
+    out["hidden_128x128"] = {"workload": "the C2 arrays, 8 coupling layers with hidden=(128, 128): loss+grad+Adam per 65536-row batch, %d batches "
+                                         "in one rnvp_fit_epoch call, device resident (any-shape MFMA kernels)" % K2,
+                             "dispatch": _hip.last_dispatch(_hip.PROFILE_TRAIN), "ms_per_step": step_ms, "rows_per_s": BATCH / (step_ms * 1e-3),
+                             "kernel_ms": k_ms / max(n_k, 1), "dense_flop_per_row": flop_row,
+                             "roofline_frac_f32_mfma": flop_row * BATCH / (k_ms / max(n_k, 1) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
     out["c2_precision_ab"] = precision_ab(Xh, Ch, dev)
     out.update(secondary_c3_c4(dev))
     return out
