@@ -42,4 +42,8 @@ cd /root/repo
 bash scripts/gpu_step_profile.sh $TAG > gpurun_out/${TAG}_step_profile.log 2>&1; tail -12 gpurun_out/${TAG}_step_profile.log
 python scripts/event_vs_rocprof.py $TAG
 python scripts/api_sample_prior.py > gpurun_out/${TAG}_api_sample_prior.txt 2>&1; tail -8 gpurun_out/${TAG}_api_sample_prior.txt
+# the any-shape training kernel on 64-row blocks: timings of the two forms on three nets, its counters, the shape fuzz
+{ python scripts/lmm64_time.py 128,128; python scripts/lmm64_time.py 64,64; python scripts/lmm64_time.py 10,20,15 65536 8 2 0; python scripts/lmm64_time.py 128 65536 8 64 16; } 2>/dev/null | grep -v "family=auto" > gpurun_out/${TAG}_lmm64_time.txt; cat gpurun_out/${TAG}_lmm64_time.txt
+bash scripts/gpu_pmc_any.sh ${TAG}lmm64 k_lmm_train64 /root/repo/scripts/lmm64_one.py > gpurun_out/${TAG}_lmm64_pmc.txt 2>&1; tail -28 gpurun_out/${TAG}_lmm64_pmc.txt
+python scripts/multi_hidden_timing.py 2>/dev/null | tail -4 > gpurun_out/${TAG}_multi_hidden_timing.txt
 cd /root/repo; ls -la gpurun_out/${TAG}_*kernel_stats.csv gpurun_out/${TAG}_*pmc*.json
