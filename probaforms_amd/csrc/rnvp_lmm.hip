@@ -128,17 +128,28 @@ __device__ __forceinline__ void linear_mb(const float *__restrict__ fblk, int m0
     // three named operand sets rotate: the fragments of two groups (2 x 16 MFMAs ~ 1000 cycles) are in flight while
     // one multiplies -- an L2 hit under load takes about that long, and the wave's LDS image, not its registers,
     // limits the occupancy, so nothing else would hide it
+    // The look-ahead requests are UNCONDITIONAL (past the end they re-request the last group): a load under a branch makes the
+    // compiler's s_waitcnt insertion wait for ALL outstanding loads at the join -- i.e. for the group just requested -- and the
+    // sched_barriers keep the machine scheduler from sinking the requests down to their uses (both seen in the ISA, rnvp_lmm64.hip)
+    const int last = KSp - 4;
+    auto ahead = [&](int ks) { return ks < last ? ks : last; };
     fetch(a0, b0, 0);
-    if (4 < KSp) fetch(a1, b1, 4);
+    fetch(a1, b1, ahead(4));
     for (int ks = 0; ks < KSp; ks += 12) {
-        if (ks + 8 < KSp) fetch(a2, b2, ks + 8);
+        fetch(a2, b2, ahead(ks + 8));
+        __builtin_amdgcn_sched_barrier(0);
         mul(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 4 >= KSp) break;
-        if (ks + 12 < KSp) fetch(a0, b0, ks + 12);
+        fetch(a0, b0, ahead(ks + 12));
+        __builtin_amdgcn_sched_barrier(0);
         mul(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 8 >= KSp) break;
-        if (ks + 16 < KSp) fetch(a1, b1, ks + 16);
+        fetch(a1, b1, ahead(ks + 16));
+        __builtin_amdgcn_sched_barrier(0);
         mul(a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int t = 0; t < MB; ++t)
