@@ -754,7 +754,8 @@ class _Guarded:
 @pytest.mark.parametrize("L,d,c,hidden,n,family", [
     (8, 16, 4, (128,), 200, "auto"), (8, 16, 4, (128,), 70001, "auto"), (3, 5, 3, (10,), 33, "auto"), (2, 1, 1, (10,), 17, "auto"),
     (12, 32, 8, (256,), 1000, "auto"), (4, 64, 16, (128,), 4097, "auto"), (4, 33, 0, (40,), 129, "auto"),
-    (3, 6, 2, (7, 9), 203, "lmm"), (3, 6, 2, (7, 9), 203, "valu"), (3, 80, 20, (24,), 301, "auto")])
+    (3, 6, 2, (7, 9), 203, "lmm"), (3, 6, 2, (7, 9), 203, "valu"), (3, 80, 20, (24,), 301, "auto"),
+    (3, 6, 2, (7, 9), 203, "lmm64"), (3, 80, 20, (24,), 301, "lmm64"), (4, 16, 4, (64, 48), 9001, "auto")])
 def test_no_kernel_writes_outside_its_output_buffers(L, d, c, hidden, n, family):
     """z_out, logdet/logp, x_out, grad_out, gx_out and loss_hist sit between poisoned guard bands; every entry point runs
     (forward, inverse, fused sampling, loss + gradient, backward, one fitted epoch) and the bands must be untouched"""

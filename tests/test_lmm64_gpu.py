@@ -186,3 +186,24 @@ def test_lmm64_fit_through_the_class_api_matches_the_16_row_form():
         losses[fam] = loss.cpu().numpy()
     assert losses["lmm64"][-1] < losses["lmm64"][0]
     assert np.abs(losses["lmm64"] - losses["lmm16"]).max() < 2e-5 * np.abs(losses["lmm16"]).max()
+
+
+@pytest.mark.parametrize("L,d,c,hidden,n", [(3, 6, 2, (7, 9), 203), (2, 16, 4, (128, 128), 8193), (3, 80, 20, (24,), 64), (2, 5, 0, (33,), 1)])
+def test_lmm64_stays_inside_the_workspace_it_asked_for(L, d, c, hidden, n):
+    """the saved layer inputs, hidden activations, gradient seeds and per-workgroup partials all live in the caller's workspace:
+    a poisoned band behind exactly rnvp_workspace_bytes stays untouched, and a workspace that is too small is refused"""
+    from probaforms_amd import _hip
+    sh, p, rng = _flow(L, d, c, hidden, "tanh", 31 + n, "lmm64")
+    masks = _masks("alt", L, d, rng)
+    X = rng.standard_normal((n, d)).astype(np.float32); C = rng.standard_normal((n, c)).astype(np.float32)
+    nb = _hip.workspace_bytes(sh, _hip.OP_TRAIN, n)
+    buf = torch.full((nb + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+    P = p.size
+    g = torch.empty(P + 1, device="cuda")
+    pd, mk, xd, cd = _dev(p), _dev(masks, torch.uint8), _dev(X), (_dev(C) if c else None)
+    _hip.loss_grad(sh, pd, mk, xd, cd, None, n, 1.0 / n, g[:P], g[P:], buf[:nb])
+    assert _hip.last_dispatch(_hip.PROFILE_TRAIN)["kernel"] == "k_lmm_train64"
+    torch.cuda.synchronize()
+    assert bool((buf[nb:] == 0xA5).all()) and bool(torch.isfinite(g).all())
+    with pytest.raises(Exception):
+        _hip.loss_grad(sh, pd, mk, xd, cd, None, n, 1.0 / n, g[:P], g[P:], buf[:1024])
