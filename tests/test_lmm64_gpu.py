@@ -207,3 +207,35 @@ def test_lmm64_stays_inside_the_workspace_it_asked_for(L, d, c, hidden, n):
     assert bool((buf[nb:] == 0xA5).all()) and bool(torch.isfinite(g).all())
     with pytest.raises(Exception):
         _hip.loss_grad(sh, pd, mk, xd, cd, None, n, 1.0 / n, g[:P], g[P:], buf[:1024])
+
+
+def test_lmm64_at_the_bench_size_equals_the_sum_of_its_quarters():
+    """hidden=(128, 128) on 65 536 rows (bench.py's `hidden_128x128`: four blocks per workgroup, units accumulated across them) against
+    four calls of 16 384 rows (one block per workgroup) and against the 16-row form on the same rows"""
+    from probaforms_amd import _hip
+    L, d, c, hidden, n = 8, 16, 4, (128, 128), 65536
+    sh, p, rng = _flow(L, d, c, hidden, "tanh", 41, "auto", scale=0.12)
+    sh16, _, _ = _flow(L, d, c, hidden, "tanh", 41, "lmm16")
+    masks = _masks("alt", L, d, rng)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randn(n, d, device="cuda", generator=gen); cc = torch.randn(n, c, device="cuda", generator=gen)
+    pd, mk = _dev(p), _dev(masks, torch.uint8)
+    P = p.size
+    ws = _ws(_hip, sh, _hip.OP_TRAIN, n)
+    full = torch.empty(P + 1, device="cuda")
+    _hip.loss_grad(sh, pd, mk, x, cc, None, n, 1.0 / n, full[:P], full[P:], ws)
+    disp = _hip.last_dispatch(_hip.PROFILE_TRAIN)
+    assert disp["kernel"] == "k_lmm_train64" and disp["grid"] == 256 and disp["rows"] == n
+    acc = torch.zeros(P + 1, device="cuda", dtype=torch.float64)
+    part = torch.empty(P + 1, device="cuda")
+    for lo in range(0, n, 16384):
+        _hip.loss_grad(sh, pd, mk, x[lo:lo + 16384].contiguous(), cc[lo:lo + 16384].contiguous(), None, 16384, 1.0 / n, part[:P], part[P:], ws)
+        acc += part.double()
+    scale = acc[:P].abs().max().item()
+    assert (full[:P].double() - acc[:P]).abs().max().item() < 3e-6 * scale
+    assert abs(full[P].item() - acc[P].item()) < 1e-5 * abs(acc[P].item())
+    g16 = torch.empty(P + 1, device="cuda")
+    _hip.loss_grad(sh16, pd, mk, x, cc, None, n, 1.0 / n, g16[:P], g16[P:], _ws(_hip, sh16, _hip.OP_TRAIN, n))
+    assert _hip.last_dispatch(_hip.PROFILE_TRAIN)["kernel"] == "k_lmm_train"
+    assert (full[:P] - g16[:P]).abs().max().item() < 3e-6 * scale
+    assert abs(full[P].item() - g16[P].item()) < 1e-5 * abs(g16[P].item())
