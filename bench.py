@@ -25,7 +25,10 @@ of `python -m torch.distributed.run`; nothing in the parent touches the GPU) and
                      validated against the reference in the build container) on the host cores of rank 0's box, on a
                      bounded sample of the same workload; cpu_baseline_c_oracle: the scalar C oracle on all cores;
   api_level       -- numpy in -> numpy out rates of RealNVP.fit / .sample on the same data (N = 1 only);
-  logprob_mae     -- second half of the metric: per-row log-prob of the HIP path against the oracle.
+  logprob_mae     -- second half of the metric: per-row log-prob of the HIP path against the oracle;
+  secondary_configs -- measured after the timed region, never `value` (N = 1, workload c2 only): the CVAE of configs[4], the C2 flow at
+                     the reference's default batch size, the reference's default networks, the C2 arrays through a flow with two
+                     hidden layers (any-shape kernels), the f32 / bx3 A/B, C3 and C4.
 """
 import argparse
 import glob
