@@ -176,6 +176,19 @@ int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int64_t count,
                                 void *workspace, size_t workspace_bytes);
 
 /*
+ * The REFERENCE's epoch shuffle drawn on the device: exactly `torch.randperm(n, generator=g)` of a CPU generator whose
+ * Mersenne-Twister state is `mt_state` [625] (as above; advanced by the n - 1 draws the host call makes).  realnvp.py:235's
+ * DataLoader(shuffle=True) calls it once per epoch on a private generator seeded from the global one (RandomSampler); on the host
+ * it is a serial Fisher-Yates pass (8.5 ms per million rows).  Here the swap targets come from the device twister and the swaps
+ * run in parallel rounds with deterministic reservations (csrc/rnvp_randperm.hip): the result is the sequential permutation bit
+ * for bit.  perm_out [n] int64; 1 <= n < 2^32 / 20 (torch shuffles larger n another way: RNVP_EUNSUPPORTED).  The Python host
+ * checks it against torch.randperm once per process and keeps the host shuffle if another torch build disagrees.
+ */
+size_t rnvp_randperm_workspace_bytes(int64_t n);
+int rnvp_randperm_torch_cpu(void *stream, uint32_t *mt_state, int64_t n, int64_t *perm_out, void *workspace,
+                            size_t workspace_bytes);
+
+/*
  * rnvp_prior_normal fused into rnvp_inverse: x_out = g(z(seed, row_offset + r, .), c[r]) for the n_rows
  * rows of this call; on the MFMA path z is drawn in registers and never written to memory.
  * Replaces nflow.py:141-143 as a whole.  Same workspace as RNVP_OP_INVERSE.

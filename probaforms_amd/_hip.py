@@ -130,6 +130,8 @@ _SIGNATURES = {
     "rnvp_prior_normal": (C.c_int, [_VP, _U64, _I64, _I64, C.c_int32, _VP]),
     "rnvp_prior_normal_torch_cpu": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _SZ]),
     "rnvp_prior_torch_workspace_bytes": (_SZ, []),
+    "rnvp_randperm_workspace_bytes": (_SZ, [_I64]),
+    "rnvp_randperm_torch_cpu": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _SZ]),
     "rnvp_sample": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _I64, _U64, _I64, _VP, _VP, _SZ]),
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
     "rnvp_loss_grad_zseed": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP, _SZ]),
@@ -290,6 +292,17 @@ def prior_normal_torch_cpu(mt_state, count, z_out, tail16, ws):
     wp, wn = _ws(ws)
     _call("rnvp_prior_normal_torch_cpu", (_ptr(mt_state, torch.int32, "mt_state"), int(count), _ptr(z_out, torch.float32, "z_out"),
                                           _ptr(tail16, torch.float32, "tail16"), wp, wn))
+
+
+def randperm_workspace_bytes(n):
+    return int(lib().rnvp_randperm_workspace_bytes(int(n)))
+
+
+def randperm_torch_cpu(mt_state, n, perm_out, ws):
+    """perm_out[:n] (int64, device) = torch.randperm(n, generator=g) of the CPU generator whose twister state is mt_state ([625] int32 on
+    the device), advanced in place (rnvp_randperm_torch_cpu); ws: randperm_workspace_bytes(n) bytes"""
+    wp, wn = _ws(ws)
+    _call("rnvp_randperm_torch_cpu", (_ptr(mt_state, torch.int32, "mt_state"), int(n), _ptr(perm_out, torch.int64, "perm_out"), wp, wn))
 
 
 def sample(shape, params, masks, c, n_rows, seed, row_offset, x_out, ws):

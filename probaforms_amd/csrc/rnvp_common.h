@@ -169,6 +169,9 @@ int adam_step(hipStream_t st, float *p, const float *g, float *m, float *v, int6
 // ---- prior draws: rnvp_prior.hip ------------------------------------------------------------
 int prior_normal(hipStream_t st, uint64_t seed, int64_t row0, int64_t n, int d, float *z);
 
+// ---- the reference's CPU mt19937 stream on the device: rnvp_prior_torch.hip --------------------------
+int mt19937_raw_words(hipStream_t st, uint32_t *mt_state, int64_t count, uint32_t *out, void *workspace);
+
 // ---- optional event bracket around the hot kernels (rnvp_profile_*, rnvp_api.hip) ---------------
 // kind: RNVP_PROFILE_TRAIN (fused forward+backward), _FORWARD (log-prob), _INVERSE (sampling)
 struct KernelTimer {

@@ -261,6 +261,33 @@ k_normal_fill_16(float *__restrict__ data, int64_t count, const float *__restric
 }
 
 }  // namespace
+
+// `count` RAW (untempered) 32-bit outputs of the mt19937 whose state is mt_state [625: 624 words + the position], written to out as
+// bit patterns; the advanced state is left in mt_state.  workspace: rnvp_prior_torch_workspace_bytes().  (rnvp_randperm.hip: the
+// DataLoader shuffle; the normals above are the other user.)
+int mt19937_raw_words(hipStream_t st, uint32_t *mt_state, int64_t count, uint32_t *out, void *workspace) {
+    uint32_t *state_in = static_cast<uint32_t *>(workspace), *partial = state_in + 640;
+    static std::atomic<uint64_t> attr{0};
+    const size_t jump_lds = (size_t)kWBlocks * kN * sizeof(uint32_t);
+    const int arc = allow_big_lds(reinterpret_cast<const void *>(k_mt_jump), 160 * 1024, attr);
+    if (arc) return arc;
+    constexpr int64_t kSegWords = (int64_t)kMtJumpBlocks * kN, kRound = (int64_t)kMtMaxSeg * kSegWords - 1024;
+    for (int64_t r0 = 0; r0 < count; r0 += kRound) {
+        const int64_t cnt = count - r0 < kRound ? count - r0 : kRound;
+        RNVP_HIP_TRY(hipMemcpyAsync(state_in, mt_state, (kN + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        int64_t nseg = (cnt + kSegWords - 1) / kSegWords;
+        if (nseg > kMtMaxSeg) nseg = kMtMaxSeg;
+        if (nseg > 1) {
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)((nseg - 1) * kJumpParts)), dim3(kJumpThreads), jump_lds, st, state_in, partial);
+            RNVP_HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_mt19937_uniform, dim3((unsigned)nseg), dim3(kMtThreads), 0, st, state_in, partial, mt_state, cnt, 0,
+                           reinterpret_cast<float *>(out) + r0, (float *)nullptr);
+        RNVP_HIP_TRY(hipGetLastError());
+    }
+    return RNVP_OK;
+}
+
 }  // namespace rnvp
 
 extern "C" size_t rnvp_prior_torch_workspace_bytes(void) {
