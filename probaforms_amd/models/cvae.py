@@ -304,7 +304,7 @@ class CVAE(GenModel):
         perms = None
         if not host_noise:
             from .._engine import PermutationPrefetcher
-            perms = PermutationPrefetcher(n, self.n_epochs).start()
+            perms = PermutationPrefetcher(n, self.n_epochs, device=dev).start()
         epoch_losses = None              # per-batch losses of cvae_fit_epoch (the reference keeps only the per-epoch loss)
         pending = []                     # device scalars of the per-epoch losses, read back once (or one epoch behind)
         inflight = None                  # (slot, event): host buffers the GPU may still be copying from

@@ -211,7 +211,7 @@ class RealNVP(GenModel):
         # first DataLoader draws them (nothing between here and the batch loop consumes the generator) -- and, on a single
         # GPU, the first permutations start computing on worker threads while the data uploads.  (Data parallel: the
         # seeds are rank 0's, broadcast inside fit_epochs, so nothing is started before that.)
-        perms = PermutationPrefetcher(len(X), self.n_epochs)
+        perms = PermutationPrefetcher(len(X), self.n_epochs, device=eng.device)
         if dist_info()[1] == 1:
             perms.start()
         # numpy (any float dtype) -> float32 on the device, once (realnvp.py:226-228); the cast runs on

@@ -41,3 +41,31 @@ def test_device_randperm_repeats_itself_and_refuses_what_torch_does_otherwise():
     mt = torch.zeros(625, dtype=torch.int32, device="cuda")
     with pytest.raises(Exception):
         _hip.randperm_torch_cpu(mt, 2 ** 32 // 20, torch.empty(4, dtype=torch.int64, device="cuda"), torch.empty(1024, dtype=torch.uint8, device="cuda"))
+
+
+def test_fit_with_device_drawn_first_permutations_equals_the_host_shuffle(monkeypatch):
+    """RealNVP.fit on 70 000 rows: the first two epochs' permutations come from the device (PermutationPrefetcher), the third from the
+    worker threads; losses, parameters and the global generator's final state equal those of a fit on host permutations only"""
+    from probaforms_amd import _engine
+    from probaforms_amd.models import RealNVP
+    rng = np.random.default_rng(0)
+    n = 70000
+    X = rng.standard_normal((n, 5)).astype(np.float32); C = rng.standard_normal((n, 3)).astype(np.float32)
+    assert _engine.DeviceShuffle.usable("cuda:0")
+    out = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("RNVP_HOST_SHUFFLE_ON_DEVICE", "1" if mode == "device" else "0")
+        torch.manual_seed(11)
+        m = RealNVP(n_layers=4, hidden=(16,), batch_size=8192, n_epochs=3, lr=1e-3)
+        m.fit(X, C)
+        out[mode] = (torch.stack([l.reshape(()) for l in m.loss_history]).cpu(), torch.cat([p.detach().reshape(-1).cpu() for p in m.nf.parameters()]),
+                     torch.get_rng_state().clone())
+    for a, b in zip(out["device"], out["host"]):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("RNVP_HOST_SHUFFLE_ON_DEVICE", "1")
+    p = _engine.PermutationPrefetcher(n, 3, device="cuda:0")
+    assert p.dev_epochs == (3 if _engine.effective_cpus() < 4 else 2)
+    assert p.get(0).is_cuda and torch.equal(p.get(1).cpu(), _engine.permutation_from_seed(n, p.seeds[1]))
+    p.close()
+    monkeypatch.setenv("RNVP_HOST_SHUFFLE_ON_DEVICE", "0")
+    assert _engine.PermutationPrefetcher(n, 3, device="cuda:0").dev_epochs == 0
