@@ -160,9 +160,15 @@ class _FitDraws:
             g = self.gen
             pool = _perm_pool(8 if self.on_device else 2) if self.n >= 65536 else None
             side = torch.cuda.Stream(self.device) if self.on_device else None
+            dev_perms = 0
             if self.on_device:
                 from .nflow import HostStreamOnDevice
-            for _ in range(self.n_epochs):
+                from .._engine import DeviceShuffle, effective_cpus
+                # the first epochs' shuffles on the device too (rnvp_randperm_torch_cpu: torch.randperm's bits): nothing hides the
+                # host's 12 ms in front of the first epoch; later ones come from the pool, ahead of the GPU
+                if pool is not None and self.n <= DeviceShuffle.MAX_N and DeviceShuffle.usable(self.device):
+                    dev_perms = self.n_epochs if effective_cpus() < 4 else 2
+            for epoch in range(self.n_epochs):
                 slot = None
                 while slot is None and not self.stop:
                     try:
@@ -174,7 +180,13 @@ class _FitDraws:
                 perm, eps, eps_full = slot
                 torch.empty((), dtype=torch.int64).random_(generator=g)                    # loader base seed
                 seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item())  # RandomSampler seed
-                fut = pool.submit(_perm_into, perm, seed) if pool else _perm_into(perm, seed)
+                perm_dev = None
+                if epoch < dev_perms:
+                    fut = None
+                    with torch.cuda.stream(side), torch.cuda.device(self.device):
+                        perm_dev = DeviceShuffle.draw(self.n, seed, self.device)                  # complete before end() returns below
+                else:
+                    fut = pool.submit(_perm_into, perm, seed) if pool else _perm_into(perm, seed)
                 if self.on_device:
                     # the generator's state goes down, the epoch's draws are chained on the device (this thread's own stream),
                     # the advanced state comes back (end() waits for the draws): g is where the host draws would have left it
@@ -188,7 +200,7 @@ class _FitDraws:
                     for (s, e) in self.bounds:
                         torch.randn(e - s, self.lat, generator=g, out=eps[s:e])
                     torch.randn(self.n, self.lat, generator=g, out=eps_full)
-                self.ready.put((slot, fut))
+                self.ready.put((slot, fut, perm_dev))
         except BaseException as ex:               # surfaces in the consumer
             self.ready.put(ex)
 
@@ -198,10 +210,10 @@ class _FitDraws:
         item = self.ready.get()
         if isinstance(item, BaseException):
             raise item
-        slot, fut = item
+        slot, fut, perm_dev = item
         if hasattr(fut, "result"):
             fut.result()
-        return slot, slot[0], slot[1], slot[2]
+        return slot, (slot[0] if perm_dev is None else perm_dev), slot[1], slot[2]
 
     def release(self, slot):
         self.free.put(slot)
@@ -326,6 +338,8 @@ class CVAE(GenModel):
                 if host_noise:
                     slot, perm_h, eps_h, eps_full_h = draws.next_epoch()           # DataLoader(shuffle=True), cvae.py:235
                     perm = _rank0(upload(perm_h))
+                    if perm_h.is_cuda:                  # drawn on the worker's stream (the first epochs): tell the allocator who reads it
+                        perm.record_stream(torch.cuda.current_stream(dev))
                     eps_all = _rank0(upload(eps_h))                                # sample_z of every batch, cvae.py:187
                     eps_full = upload(eps_full_h)
                     if inflight is not None:

@@ -273,7 +273,8 @@ def test_lookahead_draws_replay_the_serial_generator_stream(n):
     assert draws.on_device == HostStreamOnDevice.usable("cuda")
     for ref in serial:
         slot, *got = draws.next_epoch()
-        assert got[0].is_pinned() and torch.equal(got[0], ref[0])
+        # (the first epochs' permutations are drawn on the device where that is validated -- _engine.DeviceShuffle -- the rest on the pool)
+        assert (got[0].is_cuda or got[0].is_pinned()) and torch.equal(got[0].cpu(), ref[0])
         for a, b in zip(got[1:], ref[1:]):
             assert (a.is_cuda if draws.on_device else a.is_pinned()) and torch.equal(a.cpu(), b)
         draws.release(slot)
