@@ -186,7 +186,7 @@ class PermutationPrefetcher:
         self.pool = _perm_pool(max(1, workers)) if n_epochs >= 1 and n >= 65536 else None
         self.futs = {}
         self.next_submit = 0
-        self.device, self.dev_epochs, self._ws = None, 0, None
+        self.device, self.dev_epochs, self._ws, self._early = None, 0, None, {}
         if device is not None and self.pool is not None and n <= DeviceShuffle.MAX_N and DeviceShuffle.usable(device):
             self.device = torch.device(device)
             self.dev_epochs = n_epochs if effective_cpus() < 4 else min(2, n_epochs)
@@ -196,6 +196,7 @@ class PermutationPrefetcher:
         """every epoch from the worker threads after all (a caller that wants the permutations on the host); before the first get()"""
         if self.dev_epochs:
             self.dev_epochs, self.next_submit = 0, 0
+            self._early.clear()
         return self
 
     def _submit_upto(self, epoch):
@@ -208,6 +209,18 @@ class PermutationPrefetcher:
         """begin computing the first permutations now (they overlap whatever the caller does next, e.g. the upload)"""
         if self.pool is not None:
             self._submit_upto(self.dev_epochs)
+            if self.dev_epochs and not self._early:
+                # the device-drawn ones too: on their own stream, beside the caller's upload of X and C (copy engines)
+                with torch.cuda.device(self.device):
+                    st = torch.cuda.Stream(device=self.device)
+                    st.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(st):
+                        ws = torch.empty(_hip.randperm_workspace_bytes(self.n), dtype=torch.uint8, device=self.device)
+                        for e in range(self.dev_epochs):
+                            t = DeviceShuffle.draw(self.n, self.seeds[e], self.device, ws)
+                            ev = torch.cuda.Event()
+                            ev.record(st)
+                            self._early[e] = (t, ev)
         return self
 
     def get(self, epoch):
@@ -216,6 +229,12 @@ class PermutationPrefetcher:
             return permutation_from_seed(self.n, self.seeds[epoch])
         self._submit_upto(epoch)
         if epoch < self.dev_epochs:
+            if epoch in self._early:                                  # drawn by start(): hand it to the caller's stream
+                t, ev = self._early.pop(epoch)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                t.record_stream(cur)
+                return t
             with torch.cuda.device(self.device):
                 stream = torch.cuda.current_stream(self.device)
                 if self._ws is None or self._ws[1] != stream:        # (a fit draws all of them on one stream: one allocation)
