@@ -14,7 +14,8 @@
 //      either cell, so its swap is exactly the sequential one; losers bid again next round.  A third of the pending iterations
 //      commits per round (49 rounds for n = 1M); the result is the sequential permutation whatever the thread timing.
 //      Bids are 64-bit keys (round << 32 | ~i) under atomicMax, so a new round's bids override the old ones without a reset pass.
-//   After kGlobalRounds grid-wide rounds the few hundred iterations left finish inside one workgroup.
+//   Grid-wide rounds (two launches each) run while the host's bound on the pending count (x 3/4 per round) exceeds two workgroups'
+//   worth; the few hundred iterations left finish inside one workgroup.
 // The Python host validates this path against torch.randperm once per process (probaforms_amd/_engine.py) and keeps the host shuffle
 // when they differ.
 #include "rnvp_common.h"
@@ -22,7 +23,7 @@
 namespace rnvp {
 namespace {
 
-constexpr int kGlobalRounds = 18;
+constexpr int kGlobalRounds = 48;        // at most; the host stops launching them once its bound on the pending count fits one workgroup
 constexpr int kTailThreads = 1024;
 
 __device__ __forceinline__ uint32_t temper(uint32_t y) {
