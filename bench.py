@@ -9,7 +9,7 @@ cond=4, 8 coupling layers, hidden=(128,).  One STEP = one pass of the hot path o
             rows (15 x 65 536 + the ragged 16 960), each loss + gradient + Adam;
   sample -- RealNVP.sample for the same 1M conditions (realnvp.py:279-282; nflow.py:141-143): the prior
             draw (counter-based device prior, made inside the inverse kernel) + the inverse pass.
-X, C and the epoch permutations are resident in HBM before the timed region.  With N > 1 every rank owns
+X, C and the epoch permutations (the reference's DataLoader shuffles) are resident in HBM before the timed region.  With N > 1 every rank owns
 its own 1M rows (weak scaling): per batch each rank computes the gradient of its 65 536-row shard of the
 global batch of N x 65 536, the flat [gradient | loss] buffer is all-reduced over RCCL, every rank applies
 the same Adam step; sampling shards the global N x 1M rows with no collective.
@@ -579,11 +579,16 @@ def main():
     do_fit, do_sample = wl["fit"], wl["sample"]
     bounds = _engine.batch_bounds(N_ROWS, BATCH)
     nb = len(bounds) if do_fit else 0
-    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    # one shuffle per epoch, the reference's: DataLoader(shuffle=True)'s RandomSampler seed from the global CPU generator, then
+    # torch.randperm of a private generator -- drawn on the device with the host's bits where that is validated (_engine.DeviceShuffle,
+    # what RealNVP.fit uses for its first epochs), on the host otherwise; all of them before the timed region
+    torch.manual_seed(1 + rank)
+    dev_shuffle = _engine.DeviceShuffle.usable(dev)
     perms = []
     if do_fit:
-        for _ in range(n_steps):                                     # one shuffle per epoch
-            p_loc = torch.randperm(N_ROWS, device=dev, generator=gen)
+        for _ in range(n_steps):
+            seed = _engine.draw_loader_seed()
+            p_loc = _engine.DeviceShuffle.draw(N_ROWS, seed, dev) if dev_shuffle else _engine.permutation_from_seed(N_ROWS, seed).to(dev)
             if world == 1:
                 perms.append(p_loc)
                 continue
