@@ -65,7 +65,7 @@ __device__ __forceinline__ void twist_block(const uint32_t *o, uint32_t *nw, int
 // ---- several workgroups on ONE stream: jump-ahead -----------------------------------------------------------------------------
 // The twister is serial from block to block, but its raw word sequence W is an F2-linear recurrence: with g_J(x) = x^J mod phi(x)
 // (phi: the characteristic polynomial, degree 19937), W[J + j] = XOR over the set bits i of g_J of W[i + j] for every j.  So the
-// block k * kMtJumpBlocks twists after X0 is a binary convolution of the 33 blocks that follow X0 with a precomputed polynomial
+// block k * B twists after X0 (B: the jump unit, 64 / 256 / 1024 blocks) is a binary convolution of the 33 blocks that follow X0 with a precomputed polynomial
 // (rnvp_mt19937_jump.h, generated and self-checked by scripts/mt19937_jump_poly.py) -- and workgroup k of k_mt19937_uniform can start
 // there while workgroup 0 is still at the beginning.  k_mt_jump: one workgroup per (segment k >= 1, quarter of the polynomial):
 // builds the 33 blocks in LDS (82 KB), thread j XORs W[i + j] over its quarter's set bits; the quarters are XORed by the consumer.
@@ -75,7 +75,8 @@ constexpr int kWBlocks = 33;                              // 19937 + 624 <= 33 *
 constexpr int kMtMaxSeg = kMtJumpPolys + 1;               // segments of one round: k = 0 .. 31
 
 __global__ void __launch_bounds__(kJumpThreads)
-k_mt_jump(const uint32_t *__restrict__ state_in, uint32_t *__restrict__ partial) {
+k_mt_jump(const uint32_t *__restrict__ state_in, uint32_t *__restrict__ partial, int unit_blocks) {
+    const uint32_t (*polys)[624] = unit_blocks == 64 ? kMtJumpPolyB64 : (unit_blocks == 256 ? kMtJumpPolyB256 : kMtJumpPolyB1024);
     extern __shared__ uint32_t W[];                       // kWBlocks * 624 words
     const int t = threadIdx.x;
     const int k = blockIdx.x / kJumpParts + 1, part = blockIdx.x % kJumpParts;
@@ -88,7 +89,7 @@ k_mt_jump(const uint32_t *__restrict__ state_in, uint32_t *__restrict__ partial)
     }
     if (t < kN) {
         constexpr int kPer = kN / kJumpParts;             // 156 polynomial words per quarter
-        const uint32_t *g = kMtJumpPoly[k - 1] + part * kPer;
+        const uint32_t *g = polys[k - 1] + part * kPer;
         const uint32_t *w = W + 32 * part * kPer + t;
         uint32_t acc = 0u;
         for (int i = 0; i < kPer; ++i) {
@@ -104,16 +105,16 @@ k_mt_jump(const uint32_t *__restrict__ state_in, uint32_t *__restrict__ partial)
 }
 
 // Workgroup k produces its segment of the stream that starts at (state_in, position state_in[624]): segment 0 the rest of the current
-// block and the kMtJumpBlocks blocks after it, segment k >= 1 the blocks k B + 1 .. (k + 1) B (B = kMtJumpBlocks), from the jumped
+// block and the B blocks after it, segment k >= 1 the blocks k B + 1 .. (k + 1) B (B = seg_blocks, the jump unit), from the jumped
 // state k_mt_jump left in `partial`.  `count` uniforms go to out, `tail` more (0 or 16) to tail_out -- as RAW 32-bit words (tempering
 // and the conversion to a 24-bit uniform are left to the parallel kernel below: this one is bound by its instruction count); the
 // workgroup that produces the last word leaves the advanced state in state_out.  Whole blocks that land in `out` go straight from the
 // registers that formed them (one barrier per block); the partial blocks at either end go through LDS.
 __global__ void __launch_bounds__(kMtThreads)
 k_mt19937_uniform(const uint32_t *__restrict__ state_in, const uint32_t *__restrict__ partial, uint32_t *__restrict__ state_out,
-                  int64_t count, int tail, float *__restrict__ out, float *__restrict__ tail_out) {
+                  int64_t count, int tail, float *__restrict__ out, float *__restrict__ tail_out, int seg_blocks) {
     constexpr int D = kN - kM;
-    constexpr int64_t kSegWords = (int64_t)kMtJumpBlocks * kN;
+    const int64_t kSegWords = (int64_t)seg_blocks * kN;
     __shared__ uint32_t S[2][kN];
     const int t = threadIdx.x, k = blockIdx.x;
     const int pos0 = (int)state_in[kN];
@@ -262,6 +263,17 @@ k_normal_fill_16(float *__restrict__ data, int64_t count, const float *__restric
 
 }  // namespace
 
+// The jump unit for a stream of `words`: the smallest one whose 32 segments cover it in one round (a short stream wants short
+// segments: 1M words are 1 603 blocks -- two workgroups walking 800 blocks each with the 1024-block unit, twenty-six walking 64 with
+// the 64-block one), else the largest
+struct JumpUnit { int blocks; };
+static JumpUnit pick_jump_unit(int64_t words) {
+    const int64_t blocks = (words + kN - 1) / kN + 1;
+    if (blocks <= (int64_t)kMtMaxSeg * 64) return JumpUnit{64};
+    if (blocks <= (int64_t)kMtMaxSeg * 256) return JumpUnit{256};
+    return JumpUnit{1024};
+}
+
 // `count` RAW (untempered) 32-bit outputs of the mt19937 whose state is mt_state [625: 624 words + the position], written to out as
 // bit patterns; the advanced state is left in mt_state.  workspace: rnvp_prior_torch_workspace_bytes().  (rnvp_randperm.hip: the
 // DataLoader shuffle; the normals above are the other user.)
@@ -271,18 +283,19 @@ int mt19937_raw_words(hipStream_t st, uint32_t *mt_state, int64_t count, uint32_
     const size_t jump_lds = (size_t)kWBlocks * kN * sizeof(uint32_t);
     const int arc = allow_big_lds(reinterpret_cast<const void *>(k_mt_jump), 160 * 1024, attr);
     if (arc) return arc;
-    constexpr int64_t kSegWords = (int64_t)kMtJumpBlocks * kN, kRound = (int64_t)kMtMaxSeg * kSegWords - 1024;
+    const JumpUnit unit = pick_jump_unit(count);
+    const int64_t kSegWords = (int64_t)unit.blocks * kN, kRound = (int64_t)kMtMaxSeg * kSegWords - 1024;
     for (int64_t r0 = 0; r0 < count; r0 += kRound) {
         const int64_t cnt = count - r0 < kRound ? count - r0 : kRound;
         RNVP_HIP_TRY(hipMemcpyAsync(state_in, mt_state, (kN + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         int64_t nseg = (cnt + kSegWords - 1) / kSegWords;
         if (nseg > kMtMaxSeg) nseg = kMtMaxSeg;
         if (nseg > 1) {
-            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)((nseg - 1) * kJumpParts)), dim3(kJumpThreads), jump_lds, st, state_in, partial);
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)((nseg - 1) * kJumpParts)), dim3(kJumpThreads), jump_lds, st, state_in, partial, unit.blocks);
             RNVP_HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_mt19937_uniform, dim3((unsigned)nseg), dim3(kMtThreads), 0, st, state_in, partial, mt_state, cnt, 0,
-                           reinterpret_cast<float *>(out) + r0, (float *)nullptr);
+                           reinterpret_cast<float *>(out) + r0, (float *)nullptr, unit.blocks);
         RNVP_HIP_TRY(hipGetLastError());
     }
     return RNVP_OK;
@@ -310,7 +323,8 @@ extern "C" int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int
     }
     // rounds of at most kMtMaxSeg segments (20.4M words): every round continues from the state the previous one left
     // (a round stops 1024 words short of the segments' capacity so that the 16 extra words of a redrawn tail always fit)
-    constexpr int64_t kSegWords = (int64_t)kMtJumpBlocks * kN, kRound = (int64_t)kMtMaxSeg * kSegWords - 1024;
+    const JumpUnit unit = pick_jump_unit(count + 16);
+    const int64_t kSegWords = (int64_t)unit.blocks * kN, kRound = (int64_t)kMtMaxSeg * kSegWords - 1024;
     for (int64_t r0 = 0; r0 < count; r0 += kRound) {
         const int64_t cnt = count - r0 < kRound ? count - r0 : kRound;
         const bool last = r0 + cnt >= count;
@@ -320,11 +334,11 @@ extern "C" int rnvp_prior_normal_torch_cpu(void *stream, uint32_t *mt_state, int
         int64_t nseg = (cnt + tail + kSegWords - 1) / kSegWords;
         if (nseg > kMtMaxSeg) nseg = kMtMaxSeg;
         if (nseg > 1) {
-            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)((nseg - 1) * kJumpParts)), dim3(kJumpThreads), jump_lds, st, state_in, partial);
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)((nseg - 1) * kJumpParts)), dim3(kJumpThreads), jump_lds, st, state_in, partial, unit.blocks);
             RNVP_HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_mt19937_uniform, dim3((unsigned)nseg), dim3(kMtThreads), 0, st, state_in, partial, mt_state, cnt, tail,
-                           z_out + r0, tail16);
+                           z_out + r0, tail16, unit.blocks);
         RNVP_HIP_TRY(hipGetLastError());
     }
     const int tail = (count % 16) ? 16 : 0;

@@ -70,14 +70,30 @@ __global__ void __launch_bounds__(256)
 k_perm_commit(int round, const uint32_t *__restrict__ H, const uint32_t *__restrict__ pending, uint32_t *__restrict__ pending_next,
               uint32_t *__restrict__ counts, const unsigned long long *__restrict__ bids, int64_t *__restrict__ r) {
     const uint32_t cnt = counts[round & 1];
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < cnt; idx += gridDim.x * blockDim.x) {
-        const uint32_t i = pending[idx], j = H[i];
-        const unsigned long long key = bid_key(round, i);
-        if (bids[i] == key && bids[j] == key) {
-            const int64_t a = r[i], b = r[j];
-            r[i] = b; r[j] = a;
-        } else {
-            pending_next[atomicAdd(&counts[(round + 1) & 1], 1u)] = i;
+    const uint32_t lane = threadIdx.x & 63;
+    // wave-uniform trip count: the losers of a wave claim their slots of the next list with ONE atomic (a counter hit by two thirds
+    // of a million lanes individually is where this kernel's time went)
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < cnt; base += gridDim.x * blockDim.x) {
+        const uint32_t idx = base + lane;
+        bool lose = false;
+        uint32_t i = 0;
+        if (idx < cnt) {
+            i = pending[idx];
+            const uint32_t j = H[i];
+            const unsigned long long key = bid_key(round, i);
+            if (bids[i] == key && bids[j] == key) {
+                const int64_t a = r[i], b = r[j];
+                r[i] = b; r[j] = a;
+            } else {
+                lose = true;
+            }
+        }
+        const unsigned long long m = __ballot(lose);
+        if (m) {
+            uint32_t slot0 = 0;
+            if (lane == (uint32_t)__builtin_ctzll(m)) slot0 = atomicAdd(&counts[(round + 1) & 1], (uint32_t)__builtin_popcountll(m));
+            slot0 = __shfl(slot0, __builtin_ctzll(m));
+            if (lose) pending_next[slot0 + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
         }
     }
 }
