@@ -167,7 +167,7 @@ int rnvp_prior_normal(void *stream, uint64_t seed, int64_t row_offset, int64_t n
  * contiguous float tensors (mt19937, 24-bit uniforms, 16-element Box-Muller blocks on the cephes polynomials of avx_mathfun.h
  * with the multiply-adds torch's build contracts); the Python host checks it against torch.randn itself once per process and
  * keeps the host draw if another torch build disagrees.  The twister is serial from one 624-word block to the next; up to 32
- * workgroups nevertheless share ONE stream: segment k starts from the state k * 1024 blocks ahead, obtained as a binary convolution
+ * workgroups nevertheless share ONE stream: segment k starts from the state k * B blocks ahead (B = 64, 256 or 1024 by the length of the draw), obtained as a binary convolution
  * of the next 33 blocks with a precomputed jump polynomial x^J mod phi (csrc/rnvp_mt19937_jump.h, scripts/mt19937_jump_poly.py);
  * a second kernel tempers the words and applies the Box-Muller blocks.  workspace: rnvp_prior_torch_workspace_bytes() bytes.
  */
