@@ -39,7 +39,8 @@ def build(force=False):
     """Compile the oracle with gcc (make -C oracle). Building the checker is not using it."""
     libs = [os.path.join(_BUILD, "librnvp_oracle%d.so" % b) for b in (32, 64)]
     libs.append(os.path.join(_BUILD, "libprior_torch_oracle.so"))
-    srcs = [os.path.join(_HERE, f) for f in ("rnvp_oracle.c", "cvae_oracle.c", "prior_torch_oracle.c")]
+    libs.append(os.path.join(_BUILD, "librandperm_torch_oracle.so"))
+    srcs = [os.path.join(_HERE, f) for f in ("rnvp_oracle.c", "cvae_oracle.c", "prior_torch_oracle.c", "randperm_torch_oracle.c")]
     stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(f) for f in srcs)
                          for p in libs)
     if stale:
