@@ -7,6 +7,7 @@ decides WHICH rows each call sees and keeps the buffers the kernels read and wri
 import math
 import os
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -193,9 +194,14 @@ class PermutationPrefetcher:
             self.next_submit = self.dev_epochs
 
     def host_only(self):
-        """every epoch from the worker threads after all (a caller that wants the permutations on the host); before the first get()"""
+        """every epoch from the worker threads after all (a caller that wants the permutations on the host); before the first
+        get().  Futures start() already submitted (epochs >= dev_epochs) are kept; only the device-drawn epochs are added."""
         if self.dev_epochs:
-            self.dev_epochs, self.next_submit = 0, 0
+            for e in range(self.dev_epochs):
+                if e not in self.futs and self.pool is not None:
+                    self.futs[e] = self.pool.submit(permutation_from_seed, self.n, self.seeds[e])
+            self.next_submit = max(self.next_submit, self.dev_epochs)
+            self.dev_epochs = 0
             self._early.clear()
         return self
 
@@ -216,7 +222,10 @@ class PermutationPrefetcher:
                     st.wait_stream(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(st):
                         ws = torch.empty(_hip.randperm_workspace_bytes(self.n), dtype=torch.uint8, device=self.device)
-                        for e in range(self.dev_epochs):
+                        # at most TWO ahead (8 bytes a row each): a host with few CPUs draws every epoch on the device, and
+                        # n_epochs x n x 8 bytes up front (12.8 GB at 16M rows x 100 epochs) would sit in front of the first
+                        # batch; get() draws the later ones on the caller's stream as the fit reaches them
+                        for e in range(min(2, self.dev_epochs)):
                             t = DeviceShuffle.draw(self.n, self.seeds[e], self.device, ws)
                             ev = torch.cuda.Event()
                             ev.record(st)
@@ -246,6 +255,8 @@ class PermutationPrefetcher:
         for f in self.futs.values():          # the pool is shared and stays; drop what this fit no longer needs
             f.cancel()
         self.futs.clear()
+        self._early.clear()                   # device permutations start() drew and nobody fetched
+        self._ws = None
 
 
 def batch_bounds(n, batch_size):
@@ -312,11 +323,23 @@ def is_flat(params, flat):
 # counted here per storage (keyed by its base address), so that an autograd node recorded on a flow OR on one of its layers
 # alone (whose parameters are views of the flow's buffer) can tell that its parameters changed since the forward.
 _STORAGE_WRITES = {}
+_STORAGE_WATCHED = set()
+
+
+def _forget_storage(k):
+    _STORAGE_WRITES.pop(k, None)
+    _STORAGE_WATCHED.discard(k)
 
 
 def note_param_write(t):
-    k = t.untyped_storage().data_ptr()
+    st = t.untyped_storage()
+    k = st.data_ptr()
     _STORAGE_WRITES[k] = _STORAGE_WRITES.get(k, 0) + 1
+    if k not in _STORAGE_WATCHED:
+        # the entry dies with the storage: an allocation that later reuses the address must not inherit the count (a false
+        # "parameters changed since the forward"), and a long-lived process that builds many models must not grow the table
+        _STORAGE_WATCHED.add(k)
+        weakref.finalize(st, _forget_storage, k)
 
 
 def param_state(param_list):

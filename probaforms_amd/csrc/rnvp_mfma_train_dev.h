@@ -113,6 +113,14 @@ constexpr int kWaves = RNVP_TRAIN_WAVES;    // waves per workgroup
 #define RNVP_MAX_GRID_TRAIN 512
 #endif
 constexpr int kMaxGridTrain = RNVP_MAX_GRID_TRAIN;
+// RNVP_NS_PRIO: issue priority of the net-split wave pairs (the two waves of a SIMD).  Equal priorities are arbitrated by
+// age, so the s-net waves 4..7 lose every contended slot and the t-net waves wait for them at each barrier (profiles/r03_stamp_c2.txt).
+// 0: leave it to age; 1: static priority for the s waves; 2: the s waves raise theirs on odd hidden tiles; 3: the wave that is
+// behind its partner (tile counters in LDS) gets the priority
+#ifndef RNVP_NS_PRIO
+#define RNVP_NS_PRIO 0
+#endif
+constexpr int kNsPrio = RNVP_NS_PRIO;
 
 template <int NF, int CQ> struct Dims {
     static constexpr int KS1 = NF + CQ;
@@ -200,7 +208,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                           float *gp_layer, bool first, Stamps &stp, float *xown,
                                           const float *xother, int tile_lo, int tile_hi,
                                           BwdPre<NF, CQ, R> &pre_ref, bool use_pre, const float *__restrict__ Wprev = nullptr,
-                                          const float *__restrict__ scr_prev = nullptr) {
+                                          const float *__restrict__ scr_prev = nullptr, int *prog = nullptr, int *prog_cnt = nullptr) {
     BwdPre<NF, CQ, R> *const pre = &pre_ref;       // (a reference + flag, not a nullable pointer: the record must stay in registers)
     // pre (tile split only): this layer's opening loads, made by the caller / the layer above; Wprev, scr_prev (nullable):
     // the layer below, whose opening loads are requested here before the input-gradient rendezvous
@@ -355,6 +363,16 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
+            int prog_mine = 0, prog_other = 0; (void)prog_mine; (void)prog_other;
+            if constexpr (NS == 1 && kNsPrio == 2) {
+                if (__builtin_amdgcn_readfirstlane(role)) { if (__builtin_amdgcn_readfirstlane(ht) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            }
+            if constexpr (NS == 1 && kNsPrio == 3) {
+                prog_mine = ++*prog_cnt;
+                const int uw = __builtin_amdgcn_readfirstlane(wave);
+                reinterpret_cast<volatile int *>(prog)[uw] = prog_mine;
+                prog_other = reinterpret_cast<volatile int *>(prog)[uw ^ 4];
+            }
             f4 na1[NA1], na2t[NA2], na1t[NGI], nb1;
 #pragma unroll
             for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * NA1 + k4) * 256);
@@ -493,6 +511,10 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 }
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p4, t0);
+            }
+            if constexpr (NS == 1 && kNsPrio == 3) {      // ahead of the partner (as of this tile's start): yield
+                if (__builtin_amdgcn_readfirstlane(prog_mine) > __builtin_amdgcn_readfirstlane(prog_other)) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(1);
             }
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
             if constexpr (TS) {      // the only share there is: straight to the gradient record
@@ -706,6 +728,10 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     constexpr int SLOTN = DM::template slot<NS>(), TBN = DM::template tbn<R, NS>();
     float *tb = lds + NW * SLOTN + wave * TBN;
     float *xbuf = lds + NW * SLOTN + NW * TBN;                         // NS: 2 x NW x XW, double buffered by layer parity
+    int *prog = reinterpret_cast<int *>(xbuf + 2 * NW * XW);           // NS, RNVP_NS_PRIO 3: one tile counter per wave
+    int prog_cnt = 0;
+    if constexpr (NS == 1 && kNsPrio == 3) { if (threadIdx.x < NW) prog[threadIdx.x] = 0; }      // (the forward's barriers publish it)
+    if constexpr (NS == 1 && kNsPrio == 1) { if (__builtin_amdgcn_readfirstlane(role)) __builtin_amdgcn_s_setprio(1); }
     const int64_t rows_per_wg = (int64_t)WV * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
@@ -780,8 +806,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
             BwdPre<NF, CQ, R> nopre;            // (tile-split kernel only)
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false);
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
@@ -1133,7 +1159,7 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     const size_t per_wave_ns = (size_t)DM::template slot<1>() + DM::template tbn<R, 1>();
     // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
     // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
-    const size_t lds_ns = (2 * kWaves * per_wave_ns + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float);
+    const size_t lds_ns = (2 * kWaves * per_wave_ns + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float) + (kNsPrio == 3 ? 64 : 0);
     if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024) {
         lay->w2c = DM::template w2c<1>() ? 1 : 0;
         lay->glayer_floats = 2 * g.HT * DM::template tblk<1>() + DM::NT2 * 16;
@@ -1163,9 +1189,15 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
 }
 
 // rows the tile-split kernel takes for a geometry (launch_train below)
+// RNVP_TS_R2_NF4: d in (16, 32] takes two row tiles per workgroup from 4097 to 8192 rows (one round of 256 workgroups) -- the
+// per-rank batch of C3 under data parallelism over 8 GPUs (global batch 65 536); the row-parallel kernel gave
+// that batch 128 workgroups, half the chip
+#ifndef RNVP_TS_R2_NF4
+#define RNVP_TS_R2_NF4 1
+#endif
 static int64_t ts_max_rows(const Geo &g) {
     if (!RNVP_TILE_SPLIT || g.HT < 3) return 0;
-    return g.NF == 2 ? RNVP_TS_MAX_ROWS : RNVP_TS_MAX_ROWS / 2;
+    return (g.NF == 2 || (g.NF == 4 && RNVP_TS_R2_NF4)) ? RNVP_TS_MAX_ROWS : RNVP_TS_MAX_ROWS / 2;
 }
 
 template <int NF, int CQ>
@@ -1177,14 +1209,15 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
         // d <= 16: one workgroup per 16 rows up to 4096 rows, per 32 rows up to 8192 (numbers above k_mfma_train_ts); wider
         // rows: 16 rows per workgroup, up to 4096.  With two hidden tiles per net or fewer there is nothing to split
         // (h = 32 measured 47 vs 48 us).
-        constexpr int64_t kMaxRows = NF == 2 ? RNVP_TS_MAX_ROWS : RNVP_TS_MAX_ROWS / 2;
+        constexpr bool kR2 = NF == 2 || (NF == 4 && RNVP_TS_R2_NF4);
+        constexpr int64_t kMaxRows = kR2 ? RNVP_TS_MAX_ROWS : RNVP_TS_MAX_ROWS / 2;
         if (n <= kMaxRows && g.HT >= 3) {
-            const int R = (NF == 2 && n > RNVP_TS_MAX_ROWS / 2) ? 2 : 1;
+            const int R = (kR2 && n > RNVP_TS_MAX_ROWS / 2) ? 2 : 1;
             const int grid = (int)((n + 16 * R - 1) / (16 * R));
             lay->w2c = 0;
             lay->glayer_floats = pl.glayer_floats;
             *grid_out = grid;
-            if constexpr (NF == 2) {
+            if constexpr (kR2) {
                 if (R == 2) return launch_train_ts<NF, CQ, 2>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, sd, grid);
             }
             return launch_train_ts<NF, CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, sd, grid);

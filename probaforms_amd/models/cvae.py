@@ -147,9 +147,9 @@ class _FitDraws:
             # pool): a deeper ring lets eight of them run at once (the eps buffers are device memory: 2 x n x latent floats a slot)
             slots = max(slots, 8)
         for _ in range(max(1, min(slots, n_epochs))):
-            self.free.put((torch.empty(n, dtype=torch.int64, pin_memory=pin),
-                           torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin),
-                           torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin)))
+            self.free.put(((torch.empty(n, dtype=torch.int64, pin_memory=pin),
+                            torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin),
+                            torch.empty(n, lat, dtype=torch.float32, device=edev) if edev is not None else torch.empty(n, lat, dtype=torch.float32, pin_memory=pin)), None))
         self.stop = False
         self.thread = threading.Thread(target=self._run, name="cvae-draws", daemon=True)
         self.thread.start()
@@ -172,11 +172,15 @@ class _FitDraws:
                 slot = None
                 while slot is None and not self.stop:
                     try:
-                        slot = self.free.get(timeout=0.1)
+                        slot, last_reader = self.free.get(timeout=0.1)
                     except queue.Empty:
                         pass
                 if self.stop:
                     return
+                if last_reader is not None:
+                    # the slot's previous epoch: its H2D copies (pinned host buffers) / its kernels (device eps buffers) must be
+                    # done before anything overwrites them.  Waiting HERE stalls neither the consumer nor the GPU.
+                    last_reader.synchronize()
                 perm, eps, eps_full = slot
                 torch.empty((), dtype=torch.int64).random_(generator=g)                    # loader base seed
                 seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item())  # RandomSampler seed
@@ -206,7 +210,8 @@ class _FitDraws:
 
     def next_epoch(self):
         """-> (slot, perm [n] int64, eps of the batches [n, latent], eps of the loss pass [n, latent]); the tensors are
-        the slot's buffers: give the slot back with release() once nothing reads them any more"""
+        the slot's buffers: give the slot back with release() once every reader of them is ENQUEUED, handing over an event
+        recorded behind the last one (device eps buffers are read by the epoch's kernels, not only by its uploads)"""
         item = self.ready.get()
         if isinstance(item, BaseException):
             raise item
@@ -215,8 +220,10 @@ class _FitDraws:
             fut.result()
         return slot, (slot[0] if perm_dev is None else perm_dev), slot[1], slot[2]
 
-    def release(self, slot):
-        self.free.put(slot)
+    def release(self, slot, last_reader=None):
+        """last_reader: a recorded torch.cuda.Event (or None when nothing asynchronous reads the slot); the worker waits for it
+        before it overwrites the slot"""
+        self.free.put((slot, last_reader))
 
     def finish(self):
         self.thread.join()
@@ -319,7 +326,7 @@ class CVAE(GenModel):
             perms = PermutationPrefetcher(n, self.n_epochs, device=dev).start()
         epoch_losses = None              # per-batch losses of cvae_fit_epoch (the reference keeps only the per-epoch loss)
         pending = []                     # device scalars of the per-epoch losses, read back once (or one epoch behind)
-        inflight = None                  # (slot, event): host buffers the GPU may still be copying from
+        held = None                      # the epoch's slot of draw buffers, released behind the epoch's last reader
 
         def flush(keep):
             while len(pending) > keep:
@@ -330,6 +337,20 @@ class CVAE(GenModel):
 
         def upload(t):
             return t.to(dev, non_blocking=True) if dev.type == "cuda" else t.clone()
+
+        def release_slot():
+            # Give the epoch's draw buffers back with an event behind everything enqueued so far.  Device-resident eps (the
+            # round-4 stream, _FitDraws.on_device) is read in place by cvae_fit_epoch / cvae_train_step / compute_loss, so
+            # its slot goes back only after the epoch's LAST kernel is enqueued (an event recorded after the
+            # uploads let the worker overwrite noise the GPU had not read yet once all eight slots were in use).
+            nonlocal held
+            if held is None:
+                return
+            ev = None
+            if dev.type == "cuda":
+                ev = torch.cuda.Event(); ev.record()
+            draws.release(held, ev)
+            held = None
 
         try:
             for epoch in range(self.n_epochs):
@@ -342,14 +363,9 @@ class CVAE(GenModel):
                         perm.record_stream(torch.cuda.current_stream(dev))
                     eps_all = _rank0(upload(eps_h))                                # sample_z of every batch, cvae.py:187
                     eps_full = upload(eps_full_h)
-                    if inflight is not None:
-                        if inflight[1] is not None:
-                            inflight[1].synchronize()
-                        draws.release(inflight[0])
-                    ev = None
-                    if dev.type == "cuda":
-                        ev = torch.cuda.Event(); ev.record()
-                    inflight = (slot, ev)
+                    held = slot
+                    if not draws.on_device:
+                        release_slot()           # pinned host buffers: the uploads just enqueued are their only readers
                 else:
                     perm = _rank0(perms.get(epoch).to(dev))
                     eps_full = None
@@ -364,6 +380,7 @@ class CVAE(GenModel):
                                         lr, b1, b2, eps_adam, wd, self.opt.step_count + 1, core.workspace(min(n, self.batch_size)))
                     self.opt.step_count += len(bounds)
                     pending.append(self.compute_loss(Xd, Cd, eps_full))      # cvae.py:254-259
+                    release_slot()
                     flush(1 if bar is not None else self.n_epochs)
                     continue
                 for (s, e) in bounds:
@@ -385,6 +402,7 @@ class CVAE(GenModel):
                     _hip.adam_step(core.sync(), g[:core.P], self.opt.exp_avg[:core.P], self.opt.exp_avg_sq[:core.P],
                                    core.P, lr, b1, b2, eps_adam, wd, self.opt.step_count)
                 pending.append(self.compute_loss(Xd, Cd, eps_full))      # cvae.py:254-259
+                release_slot()
                 flush(1 if bar is not None else self.n_epochs)     # never make the GPU wait for the host between epochs
             flush(0)
             if draws is not None:

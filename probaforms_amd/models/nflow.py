@@ -94,8 +94,11 @@ class HostStreamOnDevice:
 
     The library restates what THIS torch build's CPU kernel computes (mt19937, 24-bit uniforms, 16-element Box-Muller blocks on
     avx_mathfun.h's polynomials with the multiply-adds its compiler contracted); another build could differ, so
-    `usable(device)` draws 4117 numbers both ways from a scratch generator once per process and device and compares values and
-    final states bit for bit; on any difference the callers keep the host draw."""
+    `usable(device)` draws 4117 + 32 + 100 003 numbers both ways from a scratch generator once per process and device and compares
+    values and final states bit for bit; on any difference the callers keep the host draw.  That check guards what depends on
+    the torch build (the uniform conversion, the Box-Muller arithmetic, the tail rule, the state layout) and one jump-ahead unit;
+    the twister's larger jump units and multi-round draws (>= 20M numbers) do not depend on torch and are pinned by the GPU
+    test suite against torch.randn instead (tests/test_prior_torch.py: up to 25M numbers)."""
 
     _ok = {}
     _lock = threading.Lock()
@@ -149,7 +152,11 @@ class HostStreamOnDevice:
 
     def randn(self, shape):
         z = torch.empty(shape, dtype=torch.float32, device=self.device)
-        self.begin(); self.draw(z); self.end()
+        self.begin()
+        try:
+            self.draw(z)
+        finally:
+            self.end()          # the window is this one draw; an error leaves the generator advanced by what was enqueued
         return z
 
     @classmethod
@@ -170,6 +177,9 @@ class HostStreamOnDevice:
                     ok = bool(torch.equal(ref, got)) and bool(torch.equal(g1.get_state(), g2.get_state()))
                     if ok:                                              # and a second call continues the stream
                         ok = bool(torch.equal(torch.randn(32, generator=g1), cls(device, g2).randn((32,)).cpu()))
+                    if ok:                                              # a draw long enough for the jump-ahead segments (64-block unit)
+                        ok = (bool(torch.equal(torch.randn(100_003, generator=g1), cls(device, g2).randn((100_003,)).cpu()))
+                              and bool(torch.equal(g1.get_state(), g2.get_state())))
                 except Exception:
                     ok = False
                 cls._ok[key] = ok
@@ -393,51 +403,57 @@ class NormalizingFlow(nn.Module):
                 hs.draw(zwin[b][:win[w][1]])
                 ev_win[b].record(gen)
 
-        if gen is not None:
-            gen.wait_stream(cur)
-            draw_window(0)
-        for k, (lo, m) in enumerate(chunks):
-            i = k % NB
-            if k >= NB:
-                ev_out[i].synchronize()                 # buffer set i is free again (its D2H has landed)
-            if hs is not None:
-                w = k // cpw
-                if k % cpw == 0:
-                    cur.wait_event(ev_win[w % len(zwin)])
-                    if w + 1 < nwin:
-                        draw_window(w + 1)              # overlaps this window's inverse kernels and downloads
-            elif host_rng:
-                torch.randn((m, d), out=zpin[i][:m])    # global CPU generator: the reference's stream
-            if stage_c:
-                # numpy's single-threaded copy/cast (float32 rounding = torch's): torch's CPU copy_ wakes
-                # its whole thread pool per call, measured 5 ms per 8 MB chunk on a 256-core host
-                np.copyto(cpin_np[i][:m], Cn[lo:lo + m], casting="unsafe")
-            with torch.cuda.stream(h2d):
-                if zpin is not None:
-                    zdev[i][:m].copy_(zpin[i][:m], non_blocking=True)
+        # The window from begin() to end() holds a COPY of the global CPU generator's state: end() writes the advanced state back.
+        # Whatever happens in between, the numbers the enqueued draws consumed stay consumed (try / finally); draws another thread
+        # makes on torch.default_generator inside the window are overwritten by end() -- torch.randn holds the generator only per
+        # call, so the reference has no such guarantee across a sample() either.
+        try:
+            if gen is not None:
+                gen.wait_stream(cur)
+                draw_window(0)
+            for k, (lo, m) in enumerate(chunks):
+                i = k % NB
+                if k >= NB:
+                    ev_out[i].synchronize()                 # buffer set i is free again (its D2H has landed)
+                if hs is not None:
+                    w = k // cpw
+                    if k % cpw == 0:
+                        cur.wait_event(ev_win[w % len(zwin)])
+                        if w + 1 < nwin:
+                            draw_window(w + 1)              # overlaps this window's inverse kernels and downloads
+                elif host_rng:
+                    torch.randn((m, d), out=zpin[i][:m])    # global CPU generator: the reference's stream
                 if stage_c:
-                    cdev[i][:m].copy_(cpin[i][:m], non_blocking=True)
-                ev_in[i].record(h2d)
-            cur.wait_event(ev_in[i])
-            cc = None if cdim == 0 else (cdev[i][:m] if stage_c else Cd[lo:lo + m])
+                    # numpy's single-threaded copy/cast (float32 rounding = torch's): torch's CPU copy_ wakes
+                    # its whole thread pool per call, measured 5 ms per 8 MB chunk on a 256-core host
+                    np.copyto(cpin_np[i][:m], Cn[lo:lo + m], casting="unsafe")
+                with torch.cuda.stream(h2d):
+                    if zpin is not None:
+                        zdev[i][:m].copy_(zpin[i][:m], non_blocking=True)
+                    if stage_c:
+                        cdev[i][:m].copy_(cpin[i][:m], non_blocking=True)
+                    ev_in[i].record(h2d)
+                cur.wait_event(ev_in[i])
+                cc = None if cdim == 0 else (cdev[i][:m] if stage_c else Cd[lo:lo + m])
+                if hs is not None:
+                    w = k // cpw
+                    eng.inverse(zwin[w % len(zwin)][lo - win[w][0]:lo - win[w][0] + m], cc, out=zdev[i][:m])
+                    if k % cpw == cpw - 1 or k + 1 == len(chunks):
+                        ev_used[w % len(zwin)] = torch.cuda.Event()
+                        ev_used[w % len(zwin)].record(cur)
+                elif host_rng:
+                    eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
+                else:
+                    eng.sample(m, cc, seed, row_offset=lo, out=zdev[i][:m])   # chunk lo..lo+m of the one-shot draw
+                ev_k[i].record(cur)
+                d2h.wait_event(ev_k[i])
+                with torch.cuda.stream(d2h):
+                    out[lo:lo + m].copy_(zdev[i][:m], non_blocking=True)
+                    ev_out[i].record(d2h)
+            d2h.synchronize()
+            cur.wait_stream(d2h)
+        finally:
             if hs is not None:
-                w = k // cpw
-                eng.inverse(zwin[w % len(zwin)][lo - win[w][0]:lo - win[w][0] + m], cc, out=zdev[i][:m])
-                if k % cpw == cpw - 1 or k + 1 == len(chunks):
-                    ev_used[w % len(zwin)] = torch.cuda.Event()
-                    ev_used[w % len(zwin)].record(cur)
-            elif host_rng:
-                eng.inverse(zdev[i][:m], cc, out=zdev[i][:m])
-            else:
-                eng.sample(m, cc, seed, row_offset=lo, out=zdev[i][:m])   # chunk lo..lo+m of the one-shot draw
-            ev_k[i].record(cur)
-            d2h.wait_event(ev_k[i])
-            with torch.cuda.stream(d2h):
-                out[lo:lo + m].copy_(zdev[i][:m], non_blocking=True)
-                ev_out[i].record(d2h)
-        d2h.synchronize()
-        cur.wait_stream(d2h)
-        if hs is not None:
-            cur.wait_stream(gen)
-            hs.end()                                    # the generator ends where the host draws would have left it
+                cur.wait_stream(gen)
+                hs.end()                                # the generator ends where the host draws would have left it
         return out.numpy()

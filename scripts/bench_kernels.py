@@ -47,7 +47,7 @@ def main():
             ws = torch.empty(_hip.workspace_bytes(shape, 2, nt), dtype=torch.uint8, device="cuda")
             gb = torch.empty(P + 4, device="cuda")
             idx = torch.randperm(n, device="cuda")[:nt].contiguous()
-            ms = timeit(lambda: _hip.loss_grad(shape, params, masks, x, cc, idx, nt, 1.0 / nt, gb[:P], gb[P:P + 1], ws), iters=5, warm=2)
+            ms = timeit(lambda: _hip.loss_grad(shape, params, masks, x, cc, idx, nt, 1.0 / nt, gb[:P], gb[P:P + 1], ws), iters=int(os.environ.get("ITERS", 5)), warm=2)
             res["train_ms"] = ms; res["train_TF_useful"] = 3 * useful * nt / ms / 1e9; res["train_Mrows_s"] = nt / ms / 1e3
             res["train_path"] = _hip.kernel_path(shape, None, 2)
         print(json.dumps(res), flush=True)

@@ -81,6 +81,13 @@ TRAIN_CASES = [
     ("c3-40000-auto", C3, 40000, "auto", "k_mfma_train_wide", "wide", "bx3"),
     ("c3-40000-f32", C3, 40000, "f32", "k_mfma_train_wide", "wide", "f32"),
     ("c3-16960-auto", C3, 16960, "auto", "k_mfma_train", "netsplit", "bx3"),
+    # the strong-batch regime SURVEY 8(d)/(e) names: global batch 65 536 over 8 ranks = 8 192 rows per rank (and the 2 120-row
+    # share of the ragged last batch): the tile-split kernel, two row tiles per workgroup from 4 097 rows on (round 5)
+    ("c3-8192-auto", C3, 8192, "auto", "k_mfma_train_ts", "tilesplit", "f32"),
+    ("c3-8192-f32", C3, 8192, "f32", "k_mfma_train_ts", "tilesplit", "f32"),
+    ("c3-5000-auto", C3, 5000, "auto", "k_mfma_train_ts", "tilesplit", "f32"),
+    ("c3-2120-auto", C3, 2120, "auto", "k_mfma_train_ts", "tilesplit", "f32"),
+    ("c2-2120-auto", C2, 2120, "auto", "k_mfma_train_ts", "tilesplit", "f32"),
     # C4's geometry (d = 64: NF = 8, one row tile per wave)
     ("c4-20000-auto", C4, 20000, "auto", "k_mfma_train", "rowpar", "f32"),
     ("c4-65536-auto", C4, 65536, "auto", "k_mfma_train", "rowpar", "f32"),

@@ -277,7 +277,7 @@ def test_lookahead_draws_replay_the_serial_generator_stream(n):
         assert (got[0].is_cuda or got[0].is_pinned()) and torch.equal(got[0].cpu(), ref[0])
         for a, b in zip(got[1:], ref[1:]):
             assert (a.is_cuda if draws.on_device else a.is_pinned()) and torch.equal(a.cpu(), b)
-        draws.release(slot)
+        draws.release(slot)          # (everything was read back by .cpu() above: no event needed)
     draws.finish()
     assert torch.equal(torch.get_rng_state(), end_state)
 
@@ -295,6 +295,27 @@ def test_large_fit_is_deterministic_and_learns(noise):
     assert np.array_equal(hists[0], hists[1])
     assert np.isfinite(hists[0]).all() and hists[0][-1] < hists[0][0]
     assert m.sample(C[:100]).shape == (100, 16)
+
+
+def test_device_noise_slots_are_not_recycled_under_their_readers(monkeypatch):
+    """with the reference's noise stream drawn on the device the eps buffers of an epoch are read in
+    place by that epoch's kernels; a slot handed back behind its UPLOADS could be overwritten by the draw worker while those
+    kernels were still queued.  A fit long enough to recycle all eight slots (16 epochs, each heavy enough for the GPU to fall
+    behind the worker) must equal, bit for bit, the same fit with the noise drawn on the host."""
+    from probaforms_amd.models import CVAE
+    from probaforms_amd.models.nflow import HostStreamOnDevice
+    if not HostStreamOnDevice.usable("cuda"):
+        pytest.skip("this torch build's CPU randn is not the one the device restates")
+    X, C = _c5_like(200_000)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RNVP_HOST_PRIOR_ON_DEVICE", mode)
+        torch.manual_seed(5)
+        m = CVAE(latent_dim=2, hidden=(128,), batch_size=4096, n_epochs=16, lr=1e-3).fit(X, C)
+        runs[mode] = (np.array([float(v) for v in m.loss_history]), m._core.flat.detach().cpu().numpy().copy(), torch.get_rng_state())
+    assert np.array_equal(runs["1"][0], runs["0"][0])
+    assert np.array_equal(runs["1"][1], runs["0"][1])
+    assert torch.equal(runs["1"][2], runs["0"][2])
 
 
 def test_device_noise_matches_host_noise_statistically():
