@@ -238,8 +238,105 @@ def api_level(Xh, Ch, dev):
             out["fit_rows_per_s"] = N_ROWS * epochs / t_fit
             out["fit_epochs"] = epochs
         out["sample_rows_per_s_%s_prior" % prior] = N_ROWS / t_s
+    # the metric's fit+sample at API level with the REFERENCE-EXACT prior stream (the default RealNVP()): rows of one epoch + rows
+    # of one sample call over the time both take -- the number to put next to `value`, which times the device-resident path with
+    # the counter-based prior
+    out["combined_rows_per_s"] = 2 * N_ROWS / (N_ROWS / out["fit_rows_per_s"] + N_ROWS / out["sample_rows_per_s_host_prior"])
     out["note"] = ("RealNVP(batch_size=65536).fit(X, C) / .sample(C) on the C2 arrays, numpy in -> numpy out; 'host' prior = "
-                   "the reference's CPU randn stream, 'device' = counter-based draw inside the inverse kernel")
+                   "the reference's CPU randn stream, 'device' = counter-based draw inside the inverse kernel; combined = one fit "
+                   "epoch + one sample(1M) call with the reference-exact prior, 2 x rows / (their times)")
+    return out
+
+
+def reference_stream_sampling(eng, C, dev):
+    """the sampling path with the REFERENCE's prior stream (prior_rng='host', the default): torch.randn's bits drawn on the device
+    (k_mt19937_uniform + jump-ahead + k_normal_fill_16: nflow.HostStreamOnDevice) + the inverse kernel -- device resident, after
+    the timed region; None where this torch build's CPU randn is not the one the device restates"""
+    import torch
+    from probaforms_amd import _hip
+    from probaforms_amd.models.nflow import HostStreamOnDevice
+    if not HostStreamOnDevice.usable(dev):
+        return None
+    g = torch.Generator(); g.manual_seed(123)
+    z = torch.empty(N_ROWS, D, dtype=torch.float32, device=dev); xs = torch.empty_like(z)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    best = None
+    for rep in range(4):
+        hs = HostStreamOnDevice(dev, g).begin()
+        torch.cuda.synchronize(dev)
+        _hip.profile_read(_hip.PROFILE_INVERSE)
+        ev[0].record(); hs.draw(z); ev[1].record(); eng.inverse(z, C, out=xs); ev[2].record()
+        hs.end()
+        torch.cuda.synchronize(dev)
+        nk, kms = _hip.profile_read(_hip.PROFILE_INVERSE)
+        cur = (ev[0].elapsed_time(ev[2]), ev[0].elapsed_time(ev[1]), kms / max(nk, 1))
+        if rep and (best is None or cur[0] < best[0]):
+            best = cur
+    f1 = useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 1)
+    tot, draw, inv = best
+    return {"bound": "mfma", "achieved": f1 * N_ROWS / (inv * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": f1 * N_ROWS / (inv * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": inv, "rows_per_launch": N_ROWS,
+            "prior_draw_ms": draw, "prior_numbers_per_s": N_ROWS * D / (draw * 1e-3),
+            "prior_write_GBps": N_ROWS * D * 4 / (draw * 1e-3) / 1e9,
+            "draw_plus_inverse_ms": tot, "rows_per_s": N_ROWS / (tot * 1e-3), "dispatch": _hip.last_dispatch(_hip.PROFILE_INVERSE),
+            "where": "after the timed region; frac = the inverse kernel alone; the draw (mt19937 on 32 workgroups by jump-ahead + "
+                     "torch's Box-Muller blocks) is bound by instruction issue, not by the 64 MB it writes"}
+
+
+def rank_steps_of_8(dev):
+    """SURVEY.md 8(d)/(e)'s data-parallel configuration on ONE GPU: global batch 65 536 over 8 ranks = 8 192 rows per rank and
+    step.  What one rank executes per step -- its loss + gradient, the [gradient | loss] all-reduce on the library's RCCL
+    communicator (here a ONE-rank communicator: the collective's launch and copy, not its latency across 8 GPUs), loss read-out +
+    Adam + re-pack -- through rnvp_fit_epoch_dp, the call RealNVP.fit makes per epoch under torch.distributed; next to the same
+    flow's one-GPU step on the whole 65 536-row batch.  8 x 8192 rows per rank-step against 65 536 rows per one-GPU step is the
+    scaling this regime can reach before the collective's cross-GPU latency."""
+    import torch
+    from probaforms_amd import _engine, _hip
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    out = {}
+    try:
+        comm = _hip.dp_init(_hip.dp_unique_id(), 0, 1)
+    except Exception as e:          # librccl not loadable
+        return {"error": "no RCCL communicator: %s" % e}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for key in ("c2", "c3"):
+        w = WORKLOADS[key]
+        d, c, L, hidden = w["d"], w["c"], w["L"], w["hidden"]
+        torch.manual_seed(0)
+        layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, hidden, "tanh") for i in range(L)]
+        nf = NormalizingFlow(layers, StandardNormalPrior(d, dev, host_rng=False))
+        for p in nf.parameters():
+            p.data = p.data.to(dev)
+        eng = nf.engine(); opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        nsteps, rb = 64, 8192
+        n = nsteps * rb
+        X = torch.randn(n, d, device=dev, generator=gen); C = torch.randn(n, c, device=dev, generator=gen)
+        perm = torch.randperm(n, device=dev, generator=gen); losses = torch.zeros(nsteps, device=dev)
+        res = {}
+        for name, fn, steps, rows in (
+                ("rank_step_8192_rows", lambda: eng.fit_epoch_dp(opt, comm, X, C, perm, rb, losses), nsteps, rb),
+                ("one_gpu_step_65536_rows", lambda: eng.fit_epoch(opt, X, C, perm, BATCH, losses), n // BATCH, BATCH)):
+            fn(); torch.cuda.synchronize(dev)
+            _hip.profile_enable(4 * nsteps)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize(dev)
+            nk, kms = _hip.profile_read(_hip.PROFILE_TRAIN)
+            _hip.profile_enable(0)
+            us = e0.elapsed_time(e1) / steps * 1e3
+            res[name] = {"us_per_step": us, "kernel_us": kms / max(nk, 1) * 1e3, "rows_per_s": rows / (us * 1e-6),
+                         "dispatch": _hip.last_dispatch(_hip.PROFILE_TRAIN),
+                         "roofline_frac_f32_mfma": 3 * useful_flops_per_row(d, c, hidden, L, 1) * rows / (kms / max(nk, 1) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+        res["eight_rank_steps_over_one_gpu_step"] = 8 * res["rank_step_8192_rows"]["rows_per_s"] / res["one_gpu_step_65536_rows"]["rows_per_s"]
+        res["workload"] = "%s: d=%d cond=%d L=%d hidden=%r" % (w["label"], d, c, L, hidden)
+        out[key] = res
+        del X, C, nf, eng
+        torch.cuda.empty_cache()
+    try:
+        _hip.dp_destroy(comm)
+    except Exception:
+        pass
+    out["note"] = ("per-rank step of the 8-GPU data-parallel configuration (global batch 65536 = 8192 rows per rank) measured on one GPU "
+                   "with a one-rank RCCL communicator; the cross-GPU latency of the [gradient | loss] all-reduce is not in it")
     return out
 
 
@@ -367,6 +464,7 @@ def secondary_configs(Xh, Ch, dev):
                              "roofline_frac_f32_mfma": flop_row * BATCH / (k_ms / max(n_k, 1) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
     out["c2_precision_ab"] = precision_ab(Xh, Ch, dev)
     out.update(secondary_c3_c4(dev))
+    out["dp8_rank_steps"] = rank_steps_of_8(dev)
     return out
 
 
@@ -499,10 +597,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-level", action="store_true")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="the reference's semantics (realnvp.py:237: ONE batch_size): a global batch of this many rows sharded over "
+                         "the ranks -- 65536 is SURVEY.md 8(d)/(e)'s headline (8192 rows per rank at 8 GPUs); every rank still owns "
+                         "its own data rows, so an epoch has N times as many steps")
+    ap.add_argument("--per-rank-batch", type=int, default=None,
+                    help="rows per rank and step (default 65536): the global batch grows with N")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default: the configuration the metric is quoted on), c3 (fit + sample, d=32 cond=8 L=12 hidden 256, "
                          "1M rows per GPU) or c4 (sampling only, d=64 cond=16, 2M draws per GPU)")
     args = ap.parse_args()
+    if args.global_batch is not None and args.per_rank_batch is not None:
+        ap.error("--global-batch and --per-rank-batch exclude each other")
     global N_ROWS, D, CDIM, LAYERS, HIDDEN, WORKLOAD_FIT
     wl = WORKLOADS[args.workload]
     N_ROWS, D, CDIM, LAYERS, HIDDEN, WORKLOAD_FIT = wl["n"], wl["d"], wl["c"], wl["L"], wl["hidden"], wl["fit"]
@@ -577,8 +683,19 @@ def main():
     X = torch.from_numpy(Xh).to(dev); C = torch.from_numpy(Ch).to(dev)
     n_steps = args.steps + args.warmup
     do_fit, do_sample = wl["fit"], wl["sample"]
-    bounds = _engine.batch_bounds(N_ROWS, BATCH)
-    nb = len(bounds) if do_fit else 0
+    # batch geometry: a GLOBAL batch of gbatch rows, of which this rank takes shard_bounds(...) -- by default gbatch = 65536 x N
+    # (--per-rank-batch: every rank's share stays 65536 rows), with --global-batch G the reference's one batch_size, shared out
+    if args.global_batch is not None:
+        if args.global_batch < world:
+            raise SystemExit("--global-batch smaller than the number of ranks")
+        gbatch, batch_mode = int(args.global_batch), "global"
+    else:
+        gbatch, batch_mode = int(args.per_rank_batch or BATCH) * world, "per_rank"
+    gbounds = _engine.batch_bounds(N_ROWS * world, gbatch)
+    shares = [_engine.shard_bounds(s, e, rank, world) for (s, e) in gbounds]       # this rank's slice of every global batch
+    assert sum(hi - lo for lo, hi in shares) == N_ROWS or world > 1
+    rank_batch = shares[0][1] - shares[0][0]
+    nb = len(gbounds) if do_fit else 0
     # one shuffle per epoch, the reference's: DataLoader(shuffle=True)'s RandomSampler seed from the global CPU generator, then
     # torch.randperm of a private generator -- drawn on the device with the host's bits where that is validated (_engine.DeviceShuffle,
     # what RealNVP.fit uses for its first epochs), on the host otherwise; all of them before the timed region
@@ -597,14 +714,13 @@ def main():
             # share of every batch, so the local shuffle is placed at those positions (the other ranks' entries are
             # never read) and the local block plays the data set.
             p_glob = torch.zeros(N_ROWS * world, dtype=torch.int64, device=dev)
-            for (s, e) in bounds:
-                b = e - s
-                p_glob[s * world + rank * b: s * world + (rank + 1) * b] = p_loc[s:e]
+            take = min(sum(hi - lo for lo, hi in shares), N_ROWS)
+            pos = torch.cat([torch.arange(lo, hi, device=dev) for lo, hi in shares])[:take]
+            p_glob[pos] = p_loc[:take]
             perms.append(p_glob)
     xs = torch.empty(N_ROWS, D, dtype=torch.float32, device=dev)
     losses = torch.zeros(n_steps, max(nb, 1), device=dev)
     P = eng.P
-    gbounds = _engine.batch_bounds(N_ROWS * world, BATCH * world)
 
     def step(i):
         """what RealNVP.fit and .sample(prior_rng='device') issue for one epoch: _engine.run_epoch -- one GPU:
@@ -612,7 +728,7 @@ def main():
         rnvp_fit_epoch_dp (per batch this rank's rows, the all-reduce of [gradient | loss] on the same stream, loss
         read-out + Adam) -- then the fused prior draw + inverse over the rank's rows"""
         if do_fit:
-            _engine.run_epoch(eng, opt, comm, X, C, perms[i], gbounds, BATCH * world, rank, world, losses[i])
+            _engine.run_epoch(eng, opt, comm, X, C, perms[i], gbounds, gbatch, rank, world, losses[i])
         if do_sample:
             eng.sample(N_ROWS, C, 1000 + i, row_offset=rank * N_ROWS, out=xs)
     for i in range(args.warmup):
@@ -620,20 +736,34 @@ def main():
     torch.cuda.synchronize()
     # HIP events around the hot kernels, recorded by the library on the stream it launches on, for every
     # launch of the timed region
-    _hip.profile_enable(args.steps * (nb + 1) + 8)
-    if dp:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    torch.cuda.synchronize()
-    if dp:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dp:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    MAX_BLOCKS = 64
+    _hip.profile_enable(MAX_BLOCKS * args.steps * (nb + 1) + 8)
+
+    def timed_block():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; the MAX over the ranks"""
+        torch.cuda.synchronize()
+        if dp:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        torch.cuda.synchronize()
+        if dp:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if dp:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # A block of --steps steps can be far shorter than a second (20 steps of C2 = 0.11 s): the block is then repeated until about
+    # one second of GPU work has been timed and the MEDIAN block is reported (`steps` stays as passed, `timed_blocks` says how
+    # many).  Every rank derives the count from the same max-reduced first block.
+    block_s = [timed_block()]
+    n_blocks = max(1, min(MAX_BLOCKS, int(np.ceil(1.0 / max(block_s[0], 1e-6)))))
+    for _ in range(n_blocks - 1):
+        block_s.append(timed_block())
+    dt = float(np.median(block_s))
+    timed_steps = n_blocks * args.steps
 
     # N > 1 self-check, after the clock stopped: every rank applied the identical Adam update to the identical all-reduced
     # gradient, so the replicas must still hold the same bits -- a checksum of the flat parameter buffer (and the last batch
@@ -649,6 +779,13 @@ def main():
             allchk = [chk]
         replicas_identical = bool(all(torch.equal(a, allchk[0]) for a in allchk))
         rccl_ranks = world if comm is not None else 0
+    # the first real multi-GPU run must not print a line for a job that fell back to the per-batch loop or whose replicas drifted
+    dp_failure = None
+    if world > 1 and not one_gpu:
+        if rccl_ranks != world:
+            dp_failure = "the library's RCCL communicator spans %d of %d ranks (fell back to the per-batch loop)" % (rccl_ranks, world)
+        elif not replicas_identical:
+            dp_failure = "the ranks' parameters / last loss differ after the timed region"
     n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
     n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
     # what the library launched for the timed region's last batch / sampling call (rnvp_last_dispatch: written by the launch
@@ -658,13 +795,12 @@ def main():
     if do_fit:
         # ... so the dispatch of a FULL batch is read from one more, untimed, gradient call of that size (same launch rules;
         # no parameter update); the launches per batch stay those of the fit loop
-        eng.loss_grad(X, C, perms[0][:BATCH * world][rank * BATCH:(rank + 1) * BATCH].contiguous() if world > 1 else perms[0][:BATCH].contiguous(),
-                      BATCH, 1.0 / (BATCH * world))
+        eng.loss_grad(X, C, perms[0][shares[0][0]:shares[0][1]].contiguous(), rank_batch, 1.0 / gbatch)
         torch.cuda.synchronize()
         full = _hip.last_dispatch(_hip.PROFILE_TRAIN)
         full["launches"] = disp_train["launches"]; full["ragged_batch"] = {k: disp_train[k] for k in ("kernel", "variant", "row_tiles", "grid", "rows")}
         disp_train = full
-    assert n_train == args.steps * nb and n_inv == args.steps * (1 if do_sample else 0), (n_train, n_inv, args.steps)
+    assert n_train == timed_steps * nb and n_inv == timed_steps * (1 if do_sample else 0), (n_train, n_inv, timed_steps)
     final_loss = float(losses[n_steps - 1, nb - 1].item()) if do_fit else None
     assert final_loss is None or np.isfinite(final_loss), "training diverged"
 
@@ -684,8 +820,8 @@ def main():
     if rank == 0:
         rows_per_step = (int(do_fit) + int(do_sample)) * N_ROWS * world
         f1 = useful_flops_per_row(D, CDIM, HIDDEN, LAYERS, 1)
-        train_tf = 3 * f1 * N_ROWS * args.steps / (train_ms * 1e-3) / 1e12 if do_fit else None     # fwd + dgrad + wgrad
-        inv_tf = f1 * N_ROWS * args.steps / (inv_ms * 1e-3) / 1e12
+        train_tf = 3 * f1 * N_ROWS * timed_steps / (train_ms * 1e-3) / 1e12 if do_fit else None     # fwd + dgrad + wgrad
+        inv_tf = f1 * N_ROWS * timed_steps / (inv_ms * 1e-3) / 1e12
         fwd_tf = f1 * N_ROWS * n_fwd / (fwd_ms * 1e-3) / 1e12
         path = _hip.kernel_path(eng.shape, eng.masks_host, _hip.OP_TRAIN)
         kname = disp_train["kernel"] if do_fit else None
@@ -694,20 +830,23 @@ def main():
         flow_kernel = (disp_inv or disp_fwd)["kernel"]
         fwd_bx3, fwd_kernel = disp_fwd["gemm1_fwd"] == "bx3", disp_fwd["kernel"]
         mixed = mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS)
+        last_share = shares[-1][1] - shares[-1][0]
+        batches_text = ("%d of every %d on %d rows, 1 on %d" % (nb - 1, nb, rank_batch, last_share) if last_share != rank_batch
+                        else "every launch on %d rows" % rank_batch)
         if do_fit:
             roof = {"bound": "mfma", "achieved": train_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": train_tf / F32_MFMA_PEAK_TFLOPS,
-                    "frac_mixed_bound": (train_mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS) * N_ROWS * args.steps / (train_ms * 1e-3)
+                    "frac_mixed_bound": (train_mixed_bound_seconds_per_row(D, CDIM, HIDDEN, LAYERS) * N_ROWS * timed_steps / (train_ms * 1e-3)
                                          if train_bx3 else None),
                     "traffic": pmc_traffic(kernel_prefix(disp_train, D, CDIM), TRAFFIC_FILE if args.workload == "c2" else TRAFFIC_FILE_C3C4),
                     "dispatch": disp_train,
                     "kernel": "%s (fused forward+backward; variant %s, %d row tiles per wave, %d waves per workgroup; GEMM1 of the "
-                              "forward phase on %s, everything else on f32 MFMA): %d launches in the timed region, %.3f ms avg (15 of "
-                              "every 16 on 65536 rows, 1 on 16960), %d useful flop/row x %d rows per epoch; %d kernel launches per "
+                              "forward phase on %s, everything else on f32 MFMA): %d launches in the timed region, %.3f ms avg (%s), "
+                              "%d useful flop/row x %d rows per epoch; %d kernel launches per "
                               "batch; `frac` prices the useful flops against the f32 MFMA peak%s"
                               % (kname, disp_train["variant"], disp_train["row_tiles"], disp_train["waves"],
                                  "3-term split-bf16 MFMA (float32-level accuracy)" if train_bx3 else "f32 MFMA", n_train,
-                                 train_ms / n_train, 3 * f1, N_ROWS, disp_train["launches"],
+                                 train_ms / n_train, batches_text, 3 * f1, N_ROWS, disp_train["launches"],
                                  ", `frac_mixed_bound` against the bound of what runs (forward GEMM1 as six bf16 products per f32 "
                                  "product on the dense bf16 peak)" if train_bx3 else "")}
         else:           # sampling only (C4): the inverse kernel is the dominant one
@@ -715,7 +854,7 @@ def main():
                     "frac": inv_tf / F32_MFMA_PEAK_TFLOPS,
                     # the committed PMC profile has this kernel at 1M rows per launch; scaled to this launch's rows
                     "traffic": (lambda t: None if t is None else t * N_ROWS / 1048576.0)(pmc_traffic(kernel_prefix(disp_inv, D, CDIM, True), TRAFFIC_FILE_C3C4)),
-                    "frac_mixed_bound": mixed * N_ROWS * args.steps / (inv_ms * 1e-3) if flow_bx3 else None,
+                    "frac_mixed_bound": mixed * N_ROWS * timed_steps / (inv_ms * 1e-3) if flow_bx3 else None,
                     "kernel": "%s inverse with the prior drawn in-kernel: %d launches of %d rows in the timed region, %.3f ms avg, "
                               "%d useful flop/row; `frac` prices it against the f32 MFMA peak, `frac_mixed_bound` against the "
                               "bound of what it executes (GEMM1 as six bf16 products per f32 product on the bf16 peak, "
@@ -728,7 +867,7 @@ def main():
                      "launches": n_fwd, "where": "after the timed region"}
         sample_entry["dispatch"], fwd_entry["dispatch"] = disp_inv, disp_fwd
         if flow_bx3 and do_sample:
-            sample_entry["frac_mixed_bound"] = mixed * N_ROWS * args.steps / (inv_ms * 1e-3)
+            sample_entry["frac_mixed_bound"] = mixed * N_ROWS * timed_steps / (inv_ms * 1e-3)
         if fwd_bx3:
             fwd_entry["frac_mixed_bound"] = mixed * N_ROWS * n_fwd / (fwd_ms * 1e-3)
         gemm1_text = "3-term split-bf16 MFMA, float32-level accuracy"
@@ -737,8 +876,8 @@ def main():
             dtype = "f32 (first Linear of the s/t nets on %s in: %s; everything else f32)" % (
                 gemm1_text, ", ".join(t for t, on in (("the training kernel's forward phase", train_bx3), ("sampling", flow_bx3 and do_sample),
                                                       ("log-prob", fwd_bx3)) if on))
-        step_text = ("one fit epoch over the rank's %d rows (%d batches of %d incl. the ragged one: loss+grad+Adam each) + "
-                     % (N_ROWS, nb, BATCH) if do_fit else "") + \
+        step_text = ("one fit epoch over the rank's %d rows (%d batches of %d rows per rank incl. the ragged one: loss+grad+Adam each) + "
+                     % (N_ROWS, nb, rank_batch) if do_fit else "") + \
                     "sampling %d rows (counter-based prior draw inside the inverse kernel)" % N_ROWS
         if dp and do_fit:
             step_text += ("; N ranks: _engine.run_epoch, the call RealNVP.fit makes -- " +
@@ -747,22 +886,33 @@ def main():
         out = {
             "metric": "RealNVP samples/sec (fit+sample)", "value": rows_per_step * args.steps / dt,
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "timed_blocks": n_blocks,
+            "block_seconds": {"median": dt, "min": float(min(block_s)), "max": float(max(block_s))},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: RealNVP n=%d/GPU d=%d cond=%d L=%d hidden=%r; one step = %s"
                                    % (wl["label"], N_ROWS, D, CDIM, LAYERS, HIDDEN, step_text),
-                       "global_batch": BATCH * world if do_fit else None, "parallelism": "dp%d" % world,
+                       "global_batch": gbatch if do_fit else None, "rank_batch": rank_batch if do_fit else None,
+                       "batch_mode": ("global batch fixed (--global-batch): the reference's one batch_size shared out over the ranks"
+                                      if batch_mode == "global" else "per-rank batch fixed (default): the global batch grows with N"),
+                       "parallelism": "dp%d" % world,
                        "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
             "roofline": roof,
             "roofline_kernels": {
                 "sample (%s inverse, prior drawn in-kernel)" % flow_kernel: sample_entry,
                 "log_prob (%s forward)" % fwd_kernel: fwd_entry},
-            "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / args.steps * 1e-3),
+            "device_resident": {"fit_rows_per_s": None, "sample_rows_per_s": N_ROWS * world / (inv_ms / timed_steps * 1e-3),
                                 "note": "sample: kernel time only; fit: ms_per_step minus the sampling kernels' time"},
         }
         if do_fit:
-            out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / args.steps * 1e-3, 1e-9)
+            out["device_resident"]["fit_rows_per_s"] = N_ROWS * world / max(dt / args.steps - inv_ms / timed_steps * 1e-3, 1e-9)
+        if do_sample and not args.no_api_level:
+            _hip.profile_enable(64)
+            ref_stream = reference_stream_sampling(eng, C, dev)
+            _hip.profile_enable(0)
+            if ref_stream is not None:
+                out["roofline_kernels"]["sample with the reference's prior stream (mt19937 + Box-Muller on the device, then %s inverse)" % flow_kernel] = ref_stream
         params = eng.params.detach().cpu().numpy()
         if world == 1 and not force_dist and not args.no_api_level and args.workload == "c2":
             out["api_level"] = api_level(Xh, Ch, dev)
@@ -784,10 +934,15 @@ def main():
                                   "vs_oracle_f64": float(np.abs(lp - lp64).mean()),
                                   "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
                                   "target": 1e-5}
+        if dp_failure:
+            out["error"] = dp_failure
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
         dist.barrier()                      # rank 0 may still be timing the CPU baseline
         dist.destroy_process_group()
+    if dp_failure:
+        sys.stderr.write("bench.py: " + dp_failure + "\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

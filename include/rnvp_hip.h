@@ -104,7 +104,7 @@ typedef struct rnvp_shape {
 #define RNVP_OP_INVERSE  1
 #define RNVP_OP_TRAIN    2
 
-#define RNVP_HIP_VERSION 400     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
+#define RNVP_HIP_VERSION 500     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
                                     binding must refuse a library that reports another number                      */
 int         rnvp_version(void);
 const char *rnvp_status_string(int status);
@@ -234,7 +234,7 @@ int rnvp_loss_grad_zseed(void *stream, const rnvp_shape *shape,
  *   gz  [n_rows, d] = d loss / d z[r]        gld [n_rows] = d loss / d logdet[r]
  * it returns
  *   grad_out [rnvp_param_count]  d loss / d params        gx_out [n_rows, d]  d loss / d x[r]   (nullable)
- * (the gradient w.r.t. the conditions is not formed: the reference's callers pass data there).  Rows are batch rows:
+ * (the gradient w.r.t. the conditions is not formed here: rnvp_backward_cond below).  Rows are batch rows:
  * with row_index the inputs are gathered, gz / gld / gx_out are not.  With shape->L == 1 this is the backward of one
  * RealNVPLayer.f.  Same kernels, workspace (RNVP_OP_TRAIN) and determinism as rnvp_loss_grad.
  */
@@ -244,6 +244,41 @@ int rnvp_backward(void *stream, const rnvp_shape *shape,
                   int64_t n_rows, const float *gz, const float *gld,
                   float *grad_out, float *gx_out,
                   void *workspace, size_t workspace_bytes);
+
+/*
+ * rnvp_backward that ALSO forms the gradient with respect to the conditions.  In the reference C enters every layer through
+ * `torch.cat((X * mask, C), dim=1)` (realnvp.py:92) and receives a gradient whenever it requires one -- a learned condition
+ * encoder in a user's own training loop.
+ *   gc_out [n_rows, c]  d loss / d c[r]   (nullable; ignored when shape->c == 0)       the other arguments as rnvp_backward.
+ * Served by the any-shape 16-row MFMA kernel for every shape whose tile image fits a CU's LDS (RNVP_EUNSUPPORTED otherwise),
+ * whatever rnvp_shape::family says; workspace: rnvp_backward_cond_workspace_bytes(shape, n_rows).  Deterministic (no float
+ * atomics).
+ */
+size_t rnvp_backward_cond_workspace_bytes(const rnvp_shape *shape, int64_t max_rows);
+int rnvp_backward_cond(void *stream, const rnvp_shape *shape,
+                       const float *params, const uint8_t *masks,
+                       const float *x, const float *c, const int64_t *row_index,
+                       int64_t n_rows, const float *gz, const float *gld,
+                       float *grad_out, float *gx_out, float *gc_out,
+                       void *workspace, size_t workspace_bytes);
+
+/*
+ * Backward THROUGH THE INVERSE x = g(z, c) (rnvp_inverse): the reference's `RealNVPLayer.g` / `NormalizingFlow.sample` are
+ * ordinary autograd graphs (realnvp.py:120-129, nflow.py:141-145 -- the sampled tensor comes back with requires_grad), so
+ * reverse-KL and other sample-based losses differentiate through them.  Given
+ *   z [n_rows, d], c [n_rows, c]   the inputs of the inverse        gx [n_rows, d] = d loss / d x[r]
+ * it returns
+ *   grad_out [rnvp_param_count]  d loss / d params     gz_out [n_rows, d]  d loss / d z[r]   (nullable)
+ *   gc_out [n_rows, c]  d loss / d c[r]  (nullable)
+ * Per layer (applied L-1 .. 0, differentiated 0 .. L-1):  x_u = (y_u - t(y_m, c)) exp(-s(y_m, c))  gives
+ *   d/dt = -gx_u exp(-s),  d/ds = -gx_u x_u,  gy_u = gx_u exp(-s),  gy_m = gx_m + (d/d y_m through both nets).
+ * With shape->L == 1 this is the backward of one RealNVPLayer.g.  Kernel, workspace and determinism as rnvp_backward_cond.
+ */
+int rnvp_inverse_backward(void *stream, const rnvp_shape *shape,
+                          const float *params, const uint8_t *masks,
+                          const float *z, const float *c, int64_t n_rows, const float *gx,
+                          float *grad_out, float *gz_out, float *gc_out,
+                          void *workspace, size_t workspace_bytes);
 
 /*
  * torch.optim.Adam step over the flat parameter buffer (realnvp.py:205-207,251):

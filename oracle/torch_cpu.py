@@ -58,14 +58,18 @@ class EagerFlow(nn.Module):
             ld = ld + (S * (1 - m)).sum(dim=-1)
         return ld + self.prior.log_prob(x), x
 
-    def sample(self, C, n=None):
-        n = len(C) if C is not None else n
-        x = self.prior.sample((n,))
+    def inverse_rows(self, Z, C):
+        """x = g(z, c): the layers' inverses, last layer first (nflow.py:142-143, realnvp.py:120-128)"""
+        x = Z
         for m, nt, ns in reversed(list(zip(self.masks, self.nets_t, self.nets_s))):
             xc = torch.cat([x * m, C], dim=1) if C is not None else x * m
             T, S = nt(xc), ns(xc)
             x = ((x - T) * torch.exp(-S)) * (1 - m) + x * m
         return x
+
+    def sample(self, C, n=None):
+        n = len(C) if C is not None else n
+        return self.inverse_rows(self.prior.sample((n,)), C)
 
 
 def fit_epoch(flow, opt, X, C, batch_size):

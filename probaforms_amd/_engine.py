@@ -492,6 +492,17 @@ class FlowEngine:
         c = self._cond(c, x.shape[0])
         return FlowFunction.apply(self, x, c, *self.param_list)
 
+    def inverse_autograd(self, z, c):
+        """x = g(z, c) WITH an autograd graph (InverseFunction: backward = rnvp_inverse_backward)"""
+        self.sync_params()
+        c = self._cond(c, z.shape[0])
+        return InverseFunction.apply(self, z, c, *self.param_list)
+
+    def wants_graph(self, *tensors):
+        """grad mode is on and something that feeds the call requires a gradient"""
+        return torch.is_grad_enabled() and (any(torch.is_tensor(t) and t.requires_grad for t in tensors) or
+                                            any(p.requires_grad for p in self.param_list))
+
     def inverse(self, z, c, out=None):
         self.sync_params()
         n = self._rows(z, None)
@@ -615,19 +626,41 @@ class FlowEngine:
                         opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count, ws)
 
 
+def _cond_workspace(engine, rows):
+    """workspace of rnvp_backward_cond / rnvp_inverse_backward for `rows` rows (the any-shape 16-row kernel, whatever family
+    serves the flow otherwise); raises where that kernel cannot take the shape"""
+    nb = _hip.backward_cond_workspace_bytes(engine.shape, max(int(rows), 1))
+    if nb == 0:
+        raise RuntimeError("the gradient with respect to the conditions and the backward through g / sample run on the "
+                           "any-shape 16-row kernel, whose LDS tile image (76 KB) this flow's hidden sizes exceed")
+    return torch.empty(nb, dtype=torch.uint8, device=engine.device)
+
+
+def _split_param_grads(eng, gflat, needs, first):
+    grads, off = [], 0
+    for i, p in enumerate(eng.param_list):
+        k = p.numel()
+        grads.append(gflat[off:off + k].view(p.shape) if needs[first + i] else None)
+        off += k
+    return tuple(grads)
+
+
 class FlowFunction(torch.autograd.Function):
     """z, logdet = flow.f(x, c) as one autograd node.
 
     forward : rnvp_forward_logprob (the fused stack; L = 1 for a single RealNVPLayer)
     backward: rnvp_backward -- (d loss / d z, d loss / d logdet) -> d loss / d x and d loss / d every parameter, the
-              hand-derived backward of SURVEY.md 3.3 (the same kernels RealNVP.fit uses, seeded by the caller).
+              hand-derived backward of SURVEY.md 3.3 (the same kernels RealNVP.fit uses, seeded by the caller).  When the
+              CONDITIONS require a gradient (they enter through torch.cat((X * mask, C)) in the reference, realnvp.py:92: a
+              learned condition encoder) the call is rnvp_backward_cond, which also returns d loss / d c.
     The parameters are passed as inputs only so that autograd routes their gradients; the kernels read the engine's flat
-    buffer, of which every parameter is a view.  The conditions get no gradient (data in every caller of the reference)."""
+    buffer, of which every parameter is a view."""
 
     @staticmethod
     def forward(ctx, engine, x, c, *params):
         n = x.shape[0]
         x = x.detach().contiguous()
+        c = None if c is None else c.detach().contiguous()
         z = torch.empty_like(x)
         ld = torch.empty(n, dtype=torch.float32, device=x.device)
         if n > 0:
@@ -652,17 +685,58 @@ class FlowFunction(torch.autograd.Function):
         gld = torch.zeros(n, dtype=torch.float32, device=dev) if gld is None else gld.to(torch.float32).contiguous()
         gflat = torch.zeros(eng.P + (-eng.P) % 4, dtype=torch.float32, device=dev)
         gx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        if n > 0:
+        want_gc = c is not None and ctx.needs_input_grad[2]
+        gc = torch.empty_like(c) if want_gc else None
+        if n > 0 and want_gc:
+            _hip.backward_cond(eng.shape, eng.params, eng.masks, x, c, None, n, gz, gld, gflat[:eng.P], gx, gc,
+                               _cond_workspace(eng, n))
+        elif n > 0:
             _hip.backward(eng.shape, eng.params, eng.masks, x, c, None, n, gz, gld, gflat[:eng.P], gx,
                           eng.workspace(_hip.OP_TRAIN, n))
-        elif gx is not None:
-            gx.zero_()
-        grads, off = [], 0
-        for i, p in enumerate(eng.param_list):
-            k = p.numel()
-            grads.append(gflat[off:off + k].view(p.shape) if ctx.needs_input_grad[3 + i] else None)
-            off += k
-        return (None, gx, None) + tuple(grads)
+        else:
+            if gx is not None:
+                gx.zero_()
+        return (None, gx, gc) + _split_param_grads(eng, gflat, ctx.needs_input_grad, 3)
+
+
+class InverseFunction(torch.autograd.Function):
+    """x = flow.g(z, c) as one autograd node (realnvp.py:120-129; nflow.py:141-145 returns the sample WITH its graph).
+
+    forward : rnvp_inverse;   backward: rnvp_inverse_backward -- d loss / d x -> d loss / d z, d loss / d c and d loss / d every
+    parameter (reverse-KL and other sample-based losses written against the reference's classes)."""
+
+    @staticmethod
+    def forward(ctx, engine, z, c, *params):
+        n = z.shape[0]
+        z = z.detach().contiguous()
+        c = None if c is None else c.detach().contiguous()
+        x = torch.empty_like(z)
+        if n > 0:
+            _hip.inverse(engine.shape, engine.params, engine.masks, z, c, n, x, engine.workspace(_hip.OP_INVERSE, n))
+        ctx.engine, ctx.n = engine, n
+        ctx.save_for_backward(z, c if c is not None else z.new_empty(0))
+        ctx.has_c = c is not None
+        ctx.version = param_state(engine.param_list)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        eng, n = ctx.engine, ctx.n
+        z, c = ctx.saved_tensors
+        c = c if ctx.has_c else None
+        if param_state(eng.param_list) != ctx.version:
+            raise RuntimeError("the flow's parameters were modified in place between forward and backward "
+                               "(one of the variables needed for gradient computation has been modified)")
+        gx = torch.zeros_like(z) if gx is None else gx.to(torch.float32).contiguous()
+        gflat = torch.zeros(eng.P + (-eng.P) % 4, dtype=torch.float32, device=z.device)
+        gz = torch.empty_like(z) if ctx.needs_input_grad[1] else None
+        gc = torch.empty_like(c) if (c is not None and ctx.needs_input_grad[2]) else None
+        if n > 0:
+            _hip.inverse_backward(eng.shape, eng.params, eng.masks, z, c, n, gx, gflat[:eng.P], gz, gc, _cond_workspace(eng, n))
+        else:
+            if gz is not None:
+                gz.zero_()
+        return (None, gz, gc) + _split_param_grads(eng, gflat, ctx.needs_input_grad, 3)
 
 
 # ----------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import threading
 import torch
 
 MAX_HIDDEN = 8
-ABI_VERSION = 400          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
+ABI_VERSION = 500          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA, PATH_LMM = 0, 1, 2
@@ -136,6 +136,9 @@ _SIGNATURES = {
     "rnvp_loss_grad": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _SZ]),
     "rnvp_loss_grad_zseed": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_backward": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "rnvp_backward_cond_workspace_bytes": (_SZ, [_SP, _I64]),
+    "rnvp_backward_cond": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "rnvp_inverse_backward": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "rnvp_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64]),
     "rnvp_dp_finish_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _D, _I64, _VP]),
     "rnvp_train_step": (C.c_int, [_VP, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _F, _VP, _VP, _VP, _VP,
@@ -336,6 +339,28 @@ def backward(shape, params, masks, x, c, row_index, n_rows, gz, gld, grad_out, g
         _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
         int(n_rows), _ptr(gz, torch.float32, "gz"), _ptr(gld, torch.float32, "gld"),
         _ptr(grad_out, torch.float32, "grad_out"), _ptr(gx_out, torch.float32, "gx_out"), wp, wn))
+
+
+def backward_cond_workspace_bytes(shape, max_rows):
+    """bytes rnvp_backward_cond / rnvp_inverse_backward need; 0 when the shape's tile image does not fit the any-shape kernel"""
+    return int(lib().rnvp_backward_cond_workspace_bytes(C.byref(shape), int(max_rows)))
+
+
+def backward_cond(shape, params, masks, x, c, row_index, n_rows, gz, gld, grad_out, gx_out, gc_out, ws):
+    """rnvp_backward plus d loss / d c (gc_out [n_rows, c], nullable)"""
+    wp, wn = _ws(ws)
+    _call("rnvp_backward_cond", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(row_index, torch.int64, "row_index"),
+        int(n_rows), _ptr(gz, torch.float32, "gz"), _ptr(gld, torch.float32, "gld"),
+        _ptr(grad_out, torch.float32, "grad_out"), _ptr(gx_out, torch.float32, "gx_out"), _ptr(gc_out, torch.float32, "gc_out"), wp, wn))
+
+
+def inverse_backward(shape, params, masks, z, c, n_rows, gx, grad_out, gz_out, gc_out, ws):
+    """vector-Jacobian product of rnvp_inverse: d loss / d x -> (d loss / d params, d loss / d z, d loss / d c)"""
+    wp, wn = _ws(ws)
+    _call("rnvp_inverse_backward", (C.byref(shape), _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
+        _ptr(z, torch.float32, "z"), _ptr(c, torch.float32, "c"), int(n_rows), _ptr(gx, torch.float32, "gx"),
+        _ptr(grad_out, torch.float32, "grad_out"), _ptr(gz_out, torch.float32, "gz_out"), _ptr(gc_out, torch.float32, "gc_out"), wp, wn))
 
 
 def adam_step(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step):

@@ -255,6 +255,58 @@ int rnvp_backward(void *stream, const rnvp_shape *shape, const float *params, co
                          nullptr, workspace, workspace_bytes);
 }
 
+// rnvp_backward_cond / rnvp_inverse_backward: the any-shape 16-row kernel (rnvp_lmm.hip) is the one that carries d loss / d c
+// and the backward through the inverse; its transposed first-Linear fragments are packed with the condition columns (gcw)
+static int cond_kshape(const rnvp_shape *shape, bool want_gc, KShape *k) {
+    int rc = make_kshape(shape, k);
+    if (rc) return rc;
+    k->family = RNVP_FAMILY_LMM16;
+    k->gcw = (want_gc && k->c > 0) ? 1 : 0;
+    return lmm::use_lmm(*k, RNVP_OP_TRAIN) ? RNVP_OK : RNVP_EUNSUPPORTED;
+}
+
+size_t rnvp_backward_cond_workspace_bytes(const rnvp_shape *shape, int64_t max_rows) {
+    KShape k;
+    if (cond_kshape(shape, true, &k) != RNVP_OK) return 0;
+    return lmm::workspace_bytes(k, RNVP_OP_TRAIN, max_rows < 1 ? 1 : max_rows) + 256;
+}
+
+static int cond_backward(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks, const float *rows,
+                         const float *c, const int64_t *row_index, int64_t n_rows, Seeds sd, float *grad_out, void *workspace,
+                         size_t workspace_bytes) {
+    KShape k;
+    int rc = cond_kshape(shape, sd.gc != nullptr, &k);
+    if (rc) return rc;
+    if (n_rows < 0 || !grad_out) return RNVP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_rows == 0) {
+        RNVP_HIP_TRY(hipMemsetAsync(grad_out, 0, (size_t)2 * k.npn * k.L * sizeof(float), st));
+        return RNVP_OK;
+    }
+    if (!masks || bad_ptrs(k, params, masks, rows, c)) return RNVP_EINVAL;
+    if (k.c == 0) sd.gc = nullptr;
+    return lmm::loss_grad(st, k, params, masks, rows, c, row_index, n_rows, 0.0f, grad_out, nullptr, workspace, workspace_bytes, sd);
+}
+
+int rnvp_backward_cond(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                       const float *x, const float *c, const int64_t *row_index, int64_t n_rows,
+                       const float *gz, const float *gld, float *grad_out, float *gx_out, float *gc_out,
+                       void *workspace, size_t workspace_bytes) {
+    if ((!gz || !gld) && n_rows > 0) return RNVP_EINVAL;
+    Seeds sd;
+    sd.gz = gz; sd.gld = gld; sd.gx = gx_out; sd.gc = gc_out;
+    return cond_backward(stream, shape, params, masks, x, c, row_index, n_rows, sd, grad_out, workspace, workspace_bytes);
+}
+
+int rnvp_inverse_backward(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
+                          const float *z, const float *c, int64_t n_rows, const float *gx, float *grad_out,
+                          float *gz_out, float *gc_out, void *workspace, size_t workspace_bytes) {
+    if (!gx && n_rows > 0) return RNVP_EINVAL;
+    Seeds sd;
+    sd.gz = gx; sd.gx = gz_out; sd.gc = gc_out; sd.inv = 1;
+    return cond_backward(stream, shape, params, masks, z, c, nullptr, n_rows, sd, grad_out, workspace, workspace_bytes);
+}
+
 static int loss_grad_any(void *stream, const rnvp_shape *shape, const float *params, const uint8_t *masks,
                          const float *x, const float *c, const int64_t *row_index, int64_t n_rows, float inv_B,
                          Seeds sd, float *grad_out, float *loss_out, void *workspace, size_t workspace_bytes) {

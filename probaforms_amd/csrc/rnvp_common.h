@@ -25,6 +25,8 @@ struct KShape {
     int prec_auto;                     // the caller left the choice to the library (RNVP_PREC_AUTO)
     int small_latency;                 // rnvp_shape::small_calls == RNVP_SMALL_LATENCY
     int family;                        // rnvp_shape::family (RNVP_FAMILY_*)
+    int gcw;                           // internal (rnvp_backward_cond / rnvp_inverse_backward with gc_out): the transposed first-Linear
+                                       // fragments of the any-shape kernels cover the condition columns too (d loss / d c)
     int nin[kMaxLin], nout[kMaxLin];   // Linear k: [nout, nin]
     int woff[kMaxLin], boff[kMaxLin];  // float offsets inside one net's parameter block
     int npn;                           // parameters per net
@@ -45,6 +47,7 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     k->small_latency = s->small_calls == RNVP_SMALL_LATENCY;
     if (s->family < RNVP_FAMILY_AUTO || s->family > RNVP_FAMILY_LMM64) return RNVP_EINVAL;
     k->family = s->family;
+    k->gcw = 0;
     k->prec_auto = s->precision == RNVP_PREC_AUTO;
     // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) -- measured
     // 1.3-1.4x on every operation there.  In the d <= 16 geometry the split inputs cost 36 registers the f32 form does not need:
@@ -82,10 +85,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   gz  [n_rows, d]  d loss / d z instead of the fused prior's z / B      (rnvp_loss_grad_zseed, rnvp_backward)
 //   gld [n_rows]     d loss / d logdet per row instead of the uniform -1/B (rnvp_backward)
 //   gx  [n_rows, d]  OUT: d loss / d x of the batch rows                   (rnvp_backward)
+//   gc  [n_rows, c]  OUT: d loss / d c of the batch rows                   (rnvp_backward_cond, rnvp_inverse_backward; any-shape kernels)
+//   inv              backward THROUGH THE INVERSE x = g(z, c) (rnvp_inverse_backward; any-shape kernels): the rows handed in are
+//                    z, gz holds d loss / d x, gx receives d loss / d z; no loss term
 struct Seeds {
     const float *gz = nullptr;
     const float *gld = nullptr;
     float *gx = nullptr;
+    float *gc = nullptr;
+    int inv = 0;
 };
 
 // ---- generic (any-shape) path: rnvp_generic.hip ---------------------------------------

@@ -79,8 +79,8 @@ k_lmm_pack(KShape s, LGeo g, const float *__restrict__ params, const uint8_t *__
             if (o >= g.offT[k] && o < g.offT[k] + g.MTt[k] * g.KSt[k] * 64) {
                 block_decode(o - g.offT[k], g.MTt[k], g.KSt[k], &m, &ks, &lane);
                 const int out = 4 * ks + (lane >> 4), in = 16 * m + (lane & 15);
-                const int nin_eff = k == 0 ? s.d : nin;
-                if (out < nout && in < nin_eff) v = W[out * nin + in] * ((masks && k == 0) ? (float)masks[l * s.d + in] : 1.f);
+                const int nin_eff = k == 0 ? s.d + (s.gcw ? s.c : 0) : nin;
+                if (out < nout && in < nin_eff) v = W[out * nin + in] * ((masks && k == 0 && in < s.d) ? (float)masks[l * s.d + in] : 1.f);
                 break;
             }
         }
@@ -319,7 +319,8 @@ __device__ __forceinline__ void dump_tile(const float *img, int nfeat, int ntot,
 // one net, backward, for the tile: on entry GA holds d loss / d (net output) and ACT the net's hidden activations
 // (net_fwd<true>).  Last Linear to first: activation derivative, dump of the weight-gradient operands (pre-activation
 // gradient + the Linear's input with a ones column) into dn, input gradient through the W^T fragments; Linear 0's goes,
-// for the first s.d inputs only, ADDED into gin (the conditioning columns get no gradient).  Ends on a barrier.
+// for the first s.d inputs only, ADDED into gin (the condition columns get a gradient -- rows s.d .. s.d + s.c - 1 of gin -- only
+// when the shape was packed with gcw: rnvp_backward_cond / rnvp_inverse_backward).  Ends on a barrier.
 __device__ __forceinline__ void net_bwd(const float *__restrict__ pkn, const KShape &s, const LGeo &g, const float *in0, float *ACT,
                                         float *GA, float *GB, float *gin, float *__restrict__ dn, int lane, int wave) {
     const int q = lane >> 4, r = lane & 15, nh = s.nh;
@@ -347,7 +348,7 @@ __device__ __forceinline__ void net_bwd(const float *__restrict__ pkn, const KSh
         const float *inp = (k == 0) ? in0 : ACT + (aoff - nin) * RS;
         dump_tile(gcur, nout, 16 * g.MT[k], -1, dn + g.offP[k], lane, wave);
         dump_tile(inp, nin, 16 * g.PT[k], nin, dn + g.offA[k], lane, wave);
-        if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, s.d, gcur, gin, nullptr, -1, lane, wave);
+        if (k == 0) linear<true>(pkn + g.offT[0], g.MTt[0], g.KSt[0], nout, s.d + (s.gcw ? s.c : 0), gcur, gin, nullptr, -1, lane, wave);
         else linear<false>(pkn + g.offT[k], g.MTt[k], g.KSt[k], nout, nin, gcur, gprev, nullptr, -1, lane, wave);
         __syncthreads();
         float *tmp = gcur; gcur = gprev; gprev = tmp;
@@ -365,7 +366,9 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
     const int jq = q + 4 * wave, jstep = 4 * kW;           // this lane's features in the elementwise passes
     const float *__restrict__ gz = sd.gz;
     float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
-    float *GA = GIN + d * RS, *GB = GA + g.wmax * RS;
+    const int gcr = s.gcw ? cd : 0;                        // rows d .. d + gcr - 1 of GIN: d loss / d c, summed over layers and nets
+    const bool inv = sd.inv != 0;                          // backward through the inverse (Seeds)
+    float *GA = GIN + (d + gcr) * RS, *GB = GA + g.wmax * RS;
     float *RED = lds + g.lds_train / sizeof(float) - 2 * kW * 16;
     for (int e = tid; e < (int)(g.lds_train / sizeof(float)); e += 64 * kW) lds[e] = 0.f;     // see linear_mb: stale rows must be finite
     __syncthreads();
@@ -380,14 +383,24 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
         __syncthreads();
         float *xs = xsave + (size_t)tile * s.L * d * 16;
         float ld = 0.f;
-        for (int l = 0; l < s.L; ++l) {
+        for (int lp = 0; lp < s.L; ++lp) {
+            // inv: the rows are z; the inverse pass (layers L-1 .. 0, realnvp.py:120-128) leaves X_l, the input of f's layer l,
+            // behind it -- the same record the forward saves in front of the layer
+            const int l = inv ? s.L - 1 - lp : lp;
             const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
-            for (int j = jq; j < d; j += jstep) xs[(l * d + j) * 16 + r] = XC[j * RS + r];        // layer input, for the backward
+            if (!inv)
+                for (int j = jq; j < d; j += jstep) xs[(l * d + j) * 16 + r] = XC[j * RS + r];    // layer input, for the backward
             net_fwd<false>(pk, pn, s, g, XC, GA, GB, T, lane, wave);
             net_fwd<false>(pk + g.net_floats, pn + s.npn, s, g, XC, GA, GB, S, lane, wave);
             const uint8_t *m = masks + l * d;
-            for (int j = jq; j < d; j += jstep)
-                if (!m[j]) { const float sv = S[j * RS + r]; XC[j * RS + r] = fmaf(XC[j * RS + r], expf(sv), T[j * RS + r]); ld += sv; }
+            for (int j = jq; j < d; j += jstep) {
+                if (!m[j]) {
+                    const float sv = S[j * RS + r];
+                    if (inv) XC[j * RS + r] = (XC[j * RS + r] - T[j * RS + r]) * expf(-sv);
+                    else { XC[j * RS + r] = fmaf(XC[j * RS + r], expf(sv), T[j * RS + r]); ld += sv; }
+                }
+                if (inv) xs[(l * d + j) * 16 + r] = XC[j * RS + r];
+            }
             __syncthreads();
         }
         {   // loss terms and the seed of the backward
@@ -405,10 +418,12 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             }
             for (int j = jq; j < d; j += jstep)
                 GY[j * RS + r] = valid ? (gz ? gz[row * d + j] : XC[j * RS + r] * inv_B) : 0.f;
+            for (int j = jq; j < gcr; j += jstep) GIN[(d + j) * RS + r] = 0.f;
         }
-        const float gld = valid ? (sd.gld ? sd.gld[row] : -inv_B) : 0.f;      // rnvp_backward: the caller's d loss / d logdet
+        const float gld = inv ? 0.f : (valid ? (sd.gld ? sd.gld[row] : -inv_B) : 0.f);      // rnvp_backward: the caller's d loss / d logdet
         __syncthreads();
-        for (int l = s.L - 1; l >= 0; --l) {
+        for (int lp = s.L - 1; lp >= 0; --lp) {
+            const int l = inv ? s.L - 1 - lp : lp;          // inv: the inverse applied layer 0 last, so its backward starts there
             const float *pk = packed + (size_t)l * 2 * g.net_floats, *pn = params + (size_t)l * 2 * s.npn;
             const uint8_t *m = masks + l * d;
             float *dl = dump + ((size_t)tile * s.L + l) * 2 * g.dump_floats;
@@ -423,7 +438,9 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
                     float v = 0.f;
                     if (!m[j]) {
                         const float gy = GY[j * RS + r];
-                        v = net ? fmaf(gy * XC[j * RS + r], expf(S[j * RS + r]), gld) : gy;
+                        // inv: x_u = (y_u - t) e^{-s}  =>  d / d t = -gy e^{-s},  d / d s = -gy x_u   (XC holds x_u = X_l)
+                        if (inv) v = net ? -gy * XC[j * RS + r] : -gy * expf(-S[j * RS + r]);
+                        else v = net ? fmaf(gy * XC[j * RS + r], expf(S[j * RS + r]), gld) : gy;
                     }
                     GA[j * RS + r] = v;
                 }
@@ -432,12 +449,14 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             }
             for (int j = jq; j < d; j += jstep) {
                 const float gy = GY[j * RS + r];
-                GY[j * RS + r] = (m[j] ? gy : gy * expf(S[j * RS + r])) + GIN[j * RS + r];
+                GY[j * RS + r] = (m[j] ? gy : gy * expf(inv ? -S[j * RS + r] : S[j * RS + r])) + GIN[j * RS + r];
             }
             __syncthreads();
         }
-        if (sd.gx && valid)                                  // rnvp_backward: d loss / d x of the batch rows
+        if (sd.gx && valid)                                  // rnvp_backward: d loss / d x of the batch rows (inv: d loss / d z)
             for (int j = jq; j < d; j += jstep) sd.gx[row * d + j] = GY[j * RS + r];
+        if (sd.gc && valid)                                  // d loss / d c (shape packed with gcw)
+            for (int j = jq; j < gcr; j += jstep) sd.gc[row * cd + j] = GIN[(d + j) * RS + r];
     }
     if (tid == 0) losspart[blockIdx.x] = first_chunk ? wave_sum : losspart[blockIdx.x] + wave_sum;      // chunks run in order on one stream
 }
@@ -656,7 +675,7 @@ LGeo make_lgeo(const KShape &k) {
     for (int i = 0; i < g.nlin; ++i) {
         g.nin[i] = k.nin[i]; g.nout[i] = k.nout[i];
         g.MT[i] = (k.nout[i] + 15) / 16; g.KS[i] = ((k.nin[i] + 3) / 4 + 3) / 4 * 4;          // k-steps padded to groups of 4
-        g.MTt[i] = ((i == 0 ? k.d : k.nin[i]) + 15) / 16; g.KSt[i] = ((k.nout[i] + 3) / 4 + 3) / 4 * 4;
+        g.MTt[i] = ((i == 0 ? k.d + (k.gcw ? k.c : 0) : k.nin[i]) + 15) / 16; g.KSt[i] = ((k.nout[i] + 3) / 4 + 3) / 4 * 4;
         g.PT[i] = (k.nin[i] + 1 + 15) / 16;
         g.offF[i] = oW; oW += g.MT[i] * g.KS[i] * 64;
         g.offT[i] = oW; oW += g.MTt[i] * g.KSt[i] * 64;
@@ -673,7 +692,7 @@ LGeo make_lgeo(const KShape &k) {
     // + 16 slack rows: a padded k-group of the last buffer may read (and multiply by zero weights) up to 15 rows past it
     // ... then 2 x kW x 16 floats of cross-wave reduction scratch at the very end
     g.lds_flow = ((size_t)(3 * k.d + k.c + 2 * k.hmax + 16) * RS + 2 * kW * 16) * sizeof(float);
-    g.lds_train = ((size_t)(k.d + k.c + k.hs + 4 * k.d + 2 * g.wmax + 16) * RS + 2 * kW * 16) * sizeof(float);
+    g.lds_train = ((size_t)(k.d + k.c + k.hs + 4 * k.d + (k.gcw ? k.c : 0) + 2 * g.wmax + 16) * RS + 2 * kW * 16) * sizeof(float);
     return g;
 }
 
@@ -708,7 +727,7 @@ size_t workspace_bytes(const KShape &k, int op, int64_t max_rows) {
         b += align_up((size_t)ntiles * k.L * 2 * g.dump_floats * sizeof(float), 256);               // wgrad operands of one chunk
         b += align_up((size_t)ntiles * k.L * k.d * 16 * sizeof(float), 256);                        // layer inputs of one chunk
         b += align_up((size_t)kSplits * k.L * 2 * g.gnet_floats * sizeof(float), 256);              // split partials
-        if (use_train64(k, max_rows)) { const size_t b64 = train64_workspace_bytes(k, max_rows); if (b64 > b) b = b64; }
+        if (!k.gcw && use_train64(k, max_rows)) { const size_t b64 = train64_workspace_bytes(k, max_rows); if (b64 > b) b = b64; }
     }
     return b;
 }
@@ -761,7 +780,10 @@ int inverse(hipStream_t st, const KShape &k, const float *params, const uint8_t 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_t *masks, const float *x, const float *c,
               const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out, void *ws, size_t ws_bytes,
               Seeds sd) {
-    if (use_train64(k, n)) return loss_grad64(st, k, params, masks, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, sd);
+    if (sd.gc && !k.gcw) return RNVP_EINVAL;
+    // d loss / d c and the backward through the inverse live in the 16-row kernel only
+    if (!sd.gc && !sd.inv && !k.gcw && use_train64(k, n))
+        return loss_grad64(st, k, params, masks, x, c, row_index, n, inv_B, grad_out, loss_out, ws, ws_bytes, sd);
     if (!ws || ws_bytes < workspace_bytes(k, RNVP_OP_TRAIN, n)) return RNVP_EWORKSPACE;
     const LGeo g = make_lgeo(k);
     const int64_t cr = chunk_rows(k, g);
@@ -790,7 +812,8 @@ int loss_grad(hipStream_t st, const KShape &k, const float *params, const uint8_
             KernelTimer timer(st, RNVP_PROFILE_TRAIN);
             hipLaunchKernelGGL(k_lmm_train, dim3(G), dim3(64 * kW), g.lds_train, st, k, g, packed, params, masks, xc, cc,
                                row_index ? row_index + r0 : nullptr, rows, inv_B,
-                               Seeds{sd.gz ? sd.gz + r0 * k.d : nullptr, sd.gld ? sd.gld + r0 : nullptr, sd.gx ? sd.gx + r0 * k.d : nullptr},
+                               Seeds{sd.gz ? sd.gz + r0 * k.d : nullptr, sd.gld ? sd.gld + r0 : nullptr, sd.gx ? sd.gx + r0 * k.d : nullptr,
+                                     sd.gc ? sd.gc + r0 * k.c : nullptr, sd.inv},
                                dump, xsave, losspart, first ? 1 : 0);
         }
         RNVP_HIP_TRY(hipGetLastError());

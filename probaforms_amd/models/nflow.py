@@ -266,27 +266,29 @@ class NormalizingFlow(nn.Module):
             return None
         return torch.as_tensor(t, dtype=torch.float32).to(eng.device).contiguous()
 
-    def _wants_graph(self, X):
+    def _wants_graph(self, X, C=None):
         """as in the reference, log_prob / log_prob_samples carry an autograd graph whenever one can be recorded: grad mode
-        on and a parameter (or X) requiring grad.  Under torch.no_grad() -- or with frozen parameters -- the fused
+        on and a parameter (or X, or C) requiring grad.  Under torch.no_grad() -- or with frozen parameters -- the fused
         no-graph kernel runs instead (prior folded in, nothing saved for a backward)."""
         if not torch.is_grad_enabled():
             return False
-        return (torch.is_tensor(X) and X.requires_grad) or any(p.requires_grad for p in self.parameters())
+        return ((torch.is_tensor(X) and X.requires_grad) or (torch.is_tensor(C) and C.requires_grad)
+                or any(p.requires_grad for p in self.parameters()))
 
     def _log_prob_graph(self, X, C):
         """per-row log-density with a graph: (z, logdet) from the FlowFunction node (forward = the fused stack, backward
         = rnvp_backward), the prior's log_prob from torch -- any differentiable prior object works (nflow.py:115)"""
         eng = self.engine()
         Xd = X.to(eng.device, torch.float32) if torch.is_tensor(X) else self._on_device(X, eng)
-        z, ld = eng.forward_autograd(Xd.contiguous(), self._on_device(C, eng))
+        Cd = C.to(eng.device, torch.float32).contiguous() if torch.is_tensor(C) else self._on_device(C, eng)     # (keeps C's graph)
+        z, ld = eng.forward_autograd(Xd.contiguous(), Cd)
         return ld + self.prior.log_prob(z)
 
     # -- reference API -------------------------------------------------------------------------
     def log_prob(self, X, C):
         if self._layerwise():
             return self._layerwise_forward(X, C).mean()
-        if self._wants_graph(X):
+        if self._wants_graph(X, C):
             return self._log_prob_graph(X, C).mean()
         eng = self.engine()
         X, C = self._on_device(X, eng), self._on_device(C, eng)
@@ -299,7 +301,7 @@ class NormalizingFlow(nn.Module):
     def log_prob_samples(self, X, C=None):
         if self._layerwise():
             return self._layerwise_forward(X, C)
-        if self._wants_graph(X):
+        if self._wants_graph(X, C):
             return self._log_prob_graph(X, C)
         eng = self.engine()
         X, C = self._on_device(X, eng), self._on_device(C, eng)
@@ -322,10 +324,16 @@ class NormalizingFlow(nn.Module):
         else:
             n = len(C)
             C = self._on_device(C, eng)
-        if self._fused_prior() and not self.prior.host_rng:
+        # As in the reference (nflow.py:141-145), the sample carries an autograd graph whenever one can be recorded -- grad mode
+        # on and a parameter (or C) requiring grad: x = g(z, c) is then ONE node whose backward is rnvp_inverse_backward
+        # (reverse-KL / sample-based losses).  RealNVP.sample detaches, as realnvp.py:280 does, and takes the paths below.
+        graph = eng.wants_graph(C)
+        if self._fused_prior() and not self.prior.host_rng and not graph:
             return eng.sample(n, C, self.prior.next_seed())       # prior drawn inside the inverse kernel
         z = self.prior.sample((n,))
         z = torch.as_tensor(z, dtype=torch.float32).to(eng.device).contiguous()
+        if graph:
+            return eng.inverse_autograd(z, C)
         return eng.inverse(z, C, out=z)
 
     # -- host staging -------------------------------------------------

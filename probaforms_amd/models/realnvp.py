@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from .._engine import (FlatAdam, FlowFunction, PermutationPrefetcher, broadcast_, default_device, dist_info, fit_epochs,
+from .._engine import (FlatAdam, FlowFunction, InverseFunction, PermutationPrefetcher, broadcast_, default_device, dist_info, fit_epochs,
                        flatten_parameters, shard_bounds, is_flat, require_hip)
 from .interfaces import GenModel
 from .nflow import InvertibleLayer, NormalizingFlow, StandardNormalPrior
@@ -66,8 +66,8 @@ class RealNVPLayer(InvertibleLayer):
     `mask` is a {0,1} tensor of length var_size kept as a plain attribute (not in state_dict).
     `f`/`g` run the HIP kernels on this layer alone; inside a NormalizingFlow the whole stack
     is fused instead.  `f` is differentiable like the reference's (one autograd node whose backward
-    is the HIP backward, rnvp_backward with L = 1) whenever grad mode is on and a parameter or X
-    requires grad; `g` returns a tensor without a graph (sampling: the reference never differentiates it).
+    is the HIP backward, rnvp_backward with L = 1) whenever grad mode is on and a parameter, X or C
+    requires grad; so is `g` (backward = rnvp_inverse_backward).  Under torch.no_grad() both return plain tensors.
     """
 
     def __init__(self, var_size, cond_size, mask, hidden=(10,), activation='tanh'):
@@ -117,11 +117,9 @@ class RealNVPLayer(InvertibleLayer):
         return dev, X, C, shape, mask, self._layer_params(dev)[:P]
 
     def f(self, X, C=None):
-        wants_graph = torch.is_grad_enabled() and ((torch.is_tensor(X) and X.requires_grad) or
-                                                   any(p.requires_grad for p in self.parameters()))
-        if wants_graph:
+        if self._wants_graph(X, C):
             Xg = X if torch.is_tensor(X) else torch.as_tensor(X, dtype=torch.float32)
-            dev, _, C, shape, mask, params = self._prep(Xg.detach(), C)
+            dev, _, C, shape, mask, params = self._prep(Xg.detach(), C)           # (C keeps its graph: .to / .contiguous)
             view = _LayerView(self, shape, mask, params, dev)
             return FlowFunction.apply(view, Xg.to(dev, torch.float32).contiguous(), C, *view.param_list)
         dev, X, C, shape, mask, params = self._prep(X, C)
@@ -131,7 +129,16 @@ class RealNVPLayer(InvertibleLayer):
         _hip.forward_logprob(shape, params, mask, X, C, None, n, X_new, log_det, None, None, self._ws(shape, dev, 0, n))
         return X_new, log_det
 
+    def _wants_graph(self, X, C):
+        return torch.is_grad_enabled() and ((torch.is_tensor(X) and X.requires_grad) or (torch.is_tensor(C) and C.requires_grad)
+                                            or any(p.requires_grad for p in self.parameters()))
+
     def g(self, X, C=None):
+        if self._wants_graph(X, C):       # realnvp.py:120-129 is an autograd graph: one node, backward = rnvp_inverse_backward (L = 1)
+            Xg = X if torch.is_tensor(X) else torch.as_tensor(X, dtype=torch.float32)
+            dev, _, C, shape, mask, params = self._prep(Xg.detach(), C)
+            view = _LayerView(self, shape, mask, params, dev)
+            return InverseFunction.apply(view, Xg.to(dev, torch.float32).contiguous(), C, *view.param_list)
         dev, X, C, shape, mask, params = self._prep(X, C)
         X_new = torch.empty_like(X)
         _hip.inverse(shape, params, mask, X, C, X.shape[0], X_new, self._ws(shape, dev, 1, X.shape[0]))
@@ -266,7 +273,8 @@ class RealNVP(GenModel):
             return self.nf.sample_to_host(C)
         if type(C) != type(1):
             C = _to_device_f32(C, self.nf.engine().device)
-        X = self.nf.sample(C).cpu().detach().numpy()
+        with torch.no_grad():       # realnvp.py:280 detaches the sample at once: no graph is recorded in the first place
+            X = self.nf.sample(C).cpu().detach().numpy()
         return X
 
     def _sample_sharded(self, C, n, rank, world, gather):

@@ -143,7 +143,8 @@ def test_load_reference_weights_and_compare_logprob(name):
     np.testing.assert_allclose(y.detach().cpu().numpy(), g["G2_layer_out"][0], rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(ld.detach().cpu().numpy(), g["G2_layer_ld"][0], rtol=2e-6, atol=2e-6)
     xg = nf.layers[-1].g(torch.from_numpy(cs["Z"]), None if cs["C"] is None else torch.from_numpy(cs["C"]))
-    np.testing.assert_allclose(xg.cpu().numpy(), g["G3_layer_out"][0], rtol=2e-6, atol=2e-6)
+    assert xg.grad_fn is not None                                    # ... and so is layer.g (realnvp.py:120-129), since round 5
+    np.testing.assert_allclose(xg.detach().cpu().numpy(), g["G3_layer_out"][0], rtol=2e-6, atol=2e-6)
     # after a later .to()/.float() style re-allocation the engine re-flattens transparently
     nf.layers[0].nn_t[0].weight.data = nf.layers[0].nn_t[0].weight.data.clone()
     lp2 = nf.log_prob_samples(cs["X"], cs["C"]).detach().cpu().numpy()
@@ -225,7 +226,7 @@ def test_device_prior_sample_vs_oracle_draw(oracle32):
     torch.manual_seed(33)
     seed = StandardNormalPrior.next_seed()
     torch.manual_seed(33)
-    got = nf.sample(torch.from_numpy(C)).cpu().numpy()
+    got = nf.sample(torch.from_numpy(C)).detach().cpu().numpy()       # (a graph tensor, as in the reference)
     want = oracle32.sample(Shape.make(cs["L"], d, c, cs["hidden"], cs["act"]), cs["params"], oracle32.prior_normal(seed, 0, n, d),
                            C, cs["masks"])
     assert np.abs(got - want).mean() < 5e-6 * max(1.0, np.abs(want).mean())

@@ -1,0 +1,192 @@
+"""The differentiable seam around the hot path (round 5): what torch autograd forms in the reference when user code
+differentiates through the flow -- the gradient with respect to the CONDITIONS (C enters through torch.cat((X * mask, C)),
+/root/reference/probaforms/models/realnvp.py:92) and the backward THROUGH THE INVERSE (RealNVPLayer.g, realnvp.py:120-129;
+NormalizingFlow.sample, nflow.py:141-145) -- against torch autograd over the eager float64 restatement
+oracle/torch_cpu.py::EagerFlow on the same weights.  Bar: 3e-6 of the gradient's scale (the fixtures' bar for gradients).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-6
+
+# (id, L, d, c, hidden, activation, rows, masks)
+CASES = [
+    ("c2", 8, 16, 4, (128,), "tanh", 300, "alt"),             # BASELINE configs[1]
+    ("tm", 4, 5, 3, (10,), "tanh", 77, "alt"),                # the reference's own test shape
+    ("multi_hidden", 3, 6, 2, (16, 12), "tanh", 130, "alt"),
+    ("relu", 3, 6, 2, (24,), "relu", 64, "alt"),
+    ("user_masks", 3, 7, 3, (20,), "tanh", 65, "random"),
+    ("wide", 2, 40, 20, (64,), "tanh", 50, "alt"),            # d > 16, c > 16
+    ("one_cond", 5, 2, 1, (10,), "tanh", 33, "alt"),          # README example
+]
+
+
+def _build(L, d, c, hidden, act, masks, seed):
+    """the product flow and the eager float64 oracle on the same parameters"""
+    from oracle.torch_cpu import EagerFlow
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    if masks == "alt":
+        ms = [(torch.arange(d) + i) % 2 for i in range(L)]
+    else:
+        ms = []
+        for _ in range(L):
+            m = rng.integers(0, 2, size=d)
+            m[rng.integers(d)] = 1; m[(np.flatnonzero(m == 1)[0] + 1) % d] = 0       # neither all ones nor all zeros
+            ms.append(torch.from_numpy(m.astype(np.int64)))
+    layers = [RealNVPLayer(d, c, ms[i], hidden, act) for i in range(L)]
+    nf = NormalizingFlow(layers, StandardNormalPrior(d, "cuda"))
+    with torch.no_grad():       # the default init is small: spread the weights so that every term of the chain matters
+        for p in nf.parameters():         # (not the deep / wide shapes: eight layers of doubled scales overflow the flow)
+            p.mul_(2.0 if max(hidden) < 64 else 1.0)
+    nf.engine()
+    flat = torch.cat([p.detach().reshape(-1) for p in nf.parameters()]).cpu().double().numpy()
+    ref = EagerFlow(L, d, c, hidden, act).double()
+    ref.load_flat(flat)
+    ref.masks = [m.clone() for m in ms]
+    ref.prior = torch.distributions.MultivariateNormal(torch.zeros(d, dtype=torch.float64), torch.eye(d, dtype=torch.float64))
+    return nf, ref
+
+
+def _ref_param_grads(ref):
+    out = []
+    for t, s in zip(ref.nets_t, ref.nets_s):
+        out += [p.grad for p in list(t.parameters()) + list(s.parameters())]
+    return out
+
+
+def _close(got, want, what):
+    want = want.double().cpu(); got = got.double().cpu()
+    scale = max(float(want.abs().max()), 1e-30)
+    err = float((got - want).abs().max()) / scale
+    assert err < TOL, "%s: %.2e of scale" % (what, err)
+    return err
+
+
+def _check_params(nf, ref):
+    worst = 0.0
+    gs = _ref_param_grads(ref)
+    scale = max(float(g.abs().max()) for g in gs)
+    for p, g in zip(nf.parameters(), gs):
+        assert p.grad is not None
+        worst = max(worst, float((p.grad.double().cpu() - g).abs().max()) / scale)
+    assert worst < TOL, "parameter gradient: %.2e of scale" % worst
+
+
+@pytest.mark.parametrize("cid,L,d,c,hidden,act,n,masks", CASES, ids=[t[0] for t in CASES])
+def test_condition_gradient_through_log_prob(cid, L, d, c, hidden, act, n, masks):
+    """missing #2 of round 4: dC of a weighted per-row log-prob (plus d/dX and d/dparams from the same call)"""
+    nf, ref = _build(L, d, c, hidden, act, masks, 11)
+    g = torch.Generator().manual_seed(5)
+    X0 = torch.randn(n, d, generator=g); C0 = torch.randn(n, c, generator=g); w = torch.rand(n, generator=g) + 0.5
+    X = X0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True)
+    lp = nf.log_prob_samples(X, C)
+    assert lp.grad_fn is not None
+    (-(w.cuda() * lp).sum() / n).backward()
+    Xr = X0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True)
+    lpr, _ = ref.log_prob_rows(Xr, Cr)
+    (-(w.double() * lpr).sum() / n).backward()
+    assert float((lp.detach().cpu().double() - lpr.detach()).abs().max()) < 1e-5 + 3e-6 * float(lpr.detach().abs().max())
+    _close(C.grad, Cr.grad, "d loss / d C")
+    _close(X.grad, Xr.grad, "d loss / d X")
+    _check_params(nf, ref)
+    # C without a gradient keeps the cheaper call and returns None for it
+    for p in nf.parameters():
+        p.grad = None
+    C2 = C0.cuda()
+    (-nf.log_prob(X0.cuda(), C2)).backward()
+    assert C2.grad is None and all(p.grad is not None for p in nf.parameters())
+
+
+@pytest.mark.parametrize("cid,L,d,c,hidden,act,n,masks", CASES, ids=[t[0] for t in CASES])
+def test_backward_through_the_inverse(cid, L, d, c, hidden, act, n, masks):
+    """missing #3 of round 4: x = g(z, c) as an autograd node -- d loss / d z, d loss / d c, d loss / d params"""
+    nf, ref = _build(L, d, c, hidden, act, masks, 12)
+    g = torch.Generator().manual_seed(6)
+    Z0 = torch.randn(n, d, generator=g); C0 = torch.randn(n, c, generator=g); A = torch.randn(n, d, generator=g)
+    Z = Z0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True)
+    x = nf.engine().inverse_autograd(Z, C)
+    assert x.grad_fn is not None
+    ((A.cuda() * x).sum() / n + 0.05 * (x * x).sum() / n).backward()
+    Zr = Z0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True)
+    xr = ref.inverse_rows(Zr, Cr)
+    ((A.double() * xr).sum() / n + 0.05 * (xr * xr).sum() / n).backward()
+    assert float((x.detach().cpu().double() - xr.detach()).abs().max()) < 2e-5 * max(1.0, float(xr.abs().max()))
+    _close(Z.grad, Zr.grad, "d loss / d z")
+    _close(C.grad, Cr.grad, "d loss / d c")
+    _check_params(nf, ref)
+
+
+def test_nf_sample_and_layer_g_carry_a_graph_like_the_reference():
+    """nflow.py:141-145: the sample comes back with requires_grad; a reverse-KL style loss fills p.grad.  Under torch.no_grad()
+    (and in RealNVP.sample, which detaches as realnvp.py:280 does) nothing is recorded."""
+    nf, ref = _build(4, 5, 3, (10,), "tanh", "alt", 13)
+    n = 91
+    C0 = torch.randn(n, 3)
+    torch.manual_seed(21)
+    x = nf.sample(C0.cuda())
+    assert x.requires_grad and x.grad_fn is not None and x.shape == (n, 5)
+    loss = (x * x).mean() - nf.log_prob(x, C0.cuda())          # sample-based loss through BOTH directions
+    loss.backward()
+    torch.manual_seed(21)
+    z = nf.prior.sample((n,)).cpu().double()                   # the same prior draw
+    xr = ref.inverse_rows(z, C0.double())
+    lossr = (xr * xr).mean() - ref.log_prob_rows(xr, C0.double())[0].mean()
+    lossr.backward()
+    assert abs(float(loss) - float(lossr)) < 1e-5 * max(1.0, abs(float(lossr)))
+    _check_params(nf, ref)
+    with torch.no_grad():
+        assert not nf.sample(C0.cuda()).requires_grad
+    # one layer on its own
+    for p in nf.parameters():
+        p.grad = None
+    y = nf.layers[2].g(z.float().cuda(), C0.cuda())
+    assert y.grad_fn is not None
+    y.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in nf.layers[2].parameters())
+    assert all(p.grad is None for p in nf.layers[0].parameters())
+    m = ref.masks[2]; zc = torch.cat([z * m, C0.double()], 1)
+    yr = ((z - ref.nets_t[2](zc)) * torch.exp(-ref.nets_s[2](zc))) * (1 - m) + z * m
+    for q in ref.parameters():
+        q.grad = None
+    yr.sum().backward()
+    gs = [q.grad for q in list(ref.nets_t[2].parameters()) + list(ref.nets_s[2].parameters())]
+    scale = max(float(gq.abs().max()) for gq in gs)
+    for p, gq in zip(nf.layers[2].parameters(), gs):
+        assert float((p.grad.double().cpu() - gq).abs().max()) < TOL * scale
+
+
+def test_many_rows_cross_the_kernel_row_chunks_and_repeat_bitwise():
+    """70 001 rows: more than one row chunk of the 16-row kernel (65 536) and a ragged last tile; the same call twice gives the
+    same bits (no float atomics)"""
+    nf, ref = _build(4, 5, 3, (10,), "tanh", "alt", 14)
+    n = 70_001
+    g = torch.Generator().manual_seed(7)
+    Z0 = torch.randn(n, 5, generator=g); C0 = torch.randn(n, 3, generator=g)
+    outs = []
+    for _ in range(2):
+        for p in nf.parameters():
+            p.grad = None
+        Z = Z0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True)
+        x = nf.engine().inverse_autograd(Z, C)
+        (x * x).sum().div(n).backward()
+        outs.append((Z.grad.clone(), C.grad.clone(), torch.cat([p.grad.reshape(-1) for p in nf.parameters()])))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    Zr = Z0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True)
+    xr = ref.inverse_rows(Zr, Cr)
+    (xr * xr).sum().div(n).backward()
+    _close(outs[0][0], Zr.grad, "d loss / d z")
+    _close(outs[0][1], Cr.grad, "d loss / d c")
+    _check_params(nf, ref)
+
+
+def test_c_abi_entries_reject_what_they_cannot_serve():
+    from probaforms_amd import _hip
+    big = _hip.RnvpShape.make(2, 8, 2, (2048, 2048), "tanh", alt_masks=1)         # tile image beyond the 16-row kernel's LDS
+    assert _hip.backward_cond_workspace_bytes(big, 100) == 0
+    ok = _hip.RnvpShape.make(2, 8, 2, (32,), "tanh", alt_masks=1)
+    assert _hip.backward_cond_workspace_bytes(ok, 100) > 0
