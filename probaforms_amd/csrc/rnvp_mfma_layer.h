@@ -168,6 +168,30 @@ __device__ __forceinline__ void store_row(float *out, int64_t row, int d, bool f
 
 constexpr int kTS = 20;                  // row stride (floats) of a 16-wide LDS transposition tile
 
+// RNVP_NS_PAIRSYNC (net-split training launches): the per-layer exchange between a row tile's t wave and s wave -- the nets'
+// outputs in the forward, their input-gradient shares in the backward -- is a rendezvous of THOSE TWO waves (both on one SIMD)
+// through a pair of LDS sequence flags, not a barrier of all eight waves of the workgroup: the four pairs drift freely and
+// nobody pays the arrival skew between SIMDs sixteen times per row group.  The exchange records stay double buffered by layer
+// parity: a wave can be at most one exchange ahead of its partner.
+// Built, parity-green, measured (profiles/r05_ns_sync_ab.txt): C2 at 65 536 rows 0.2957-0.3000 ms against 0.2901-0.2957 with the
+// workgroup barrier (and the t-wave flush in both) -- the barrier's skew was not the cost; OFF.
+#ifndef RNVP_NS_PAIRSYNC
+#define RNVP_NS_PAIRSYNC 0
+#endif
+constexpr bool kNsPairSync = RNVP_NS_PAIRSYNC != 0;
+struct PairSync { int *own; const int *other; int seq; };
+__device__ __forceinline__ void pair_rendezvous(PairSync &ps, int lane) {
+    if constexpr (kNsPairSync) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's record has landed in LDS
+        ++ps.seq;
+        if (lane == 0) __hip_atomic_store(ps.own, ps.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ps.other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.seq) { }
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+}
+
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering the accesses.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -597,7 +621,7 @@ template <int NF, int CQ, int R, int PC, int MODE, int ACT, bool BX = false>
 __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
                                                  float *xown, const float *xother, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
-                                                 float *__restrict__ scr) {
+                                                 float *__restrict__ scr, PairSync &ps) {
     using D = FwdDims<NF, CQ>;
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4;
@@ -658,7 +682,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
         for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = own[rt][f];
-    __syncthreads();
+    pair_rendezvous(ps, lane);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
 #pragma unroll

@@ -87,6 +87,10 @@ constexpr int kFinRecMax = 1024;                  // floats of the largest half 
 constexpr int kFinParMax = 16 * 81;               // LDS copy of a workgroup's parameters: 16 x (d + cdim + 1) <= 16 x 81, d x 16 <= 1024
 constexpr int kFinPer = 3;                        // parameters per thread: ceil(16 x 81 / 512)
 
+#ifndef RNVP_FIN_INFLIGHT
+#define RNVP_FIN_INFLIGHT 8
+#endif
+constexpr int kFinInFlight = RNVP_FIN_INFLIGHT;
 __global__ void __launch_bounds__(kFinThreads)
 k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, const float *__restrict__ gpart, int G,
                const float *__restrict__ losspart, int n_loss, float inv_B, const float *loss_in, float *loss_out,
@@ -172,12 +176,13 @@ k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, c
         if (sub < nsub) {
             const f4 *src = reinterpret_cast<const f4 *>(gpart + (size_t)l * glayer_floats + rec_off) + col;
             int bb = sub;
-            for (; bb + 7 * nsub < G; bb += 8 * nsub) {
-                f4 v[8];
+            // kFinInFlight loads per thread before the first add: the partials come out of L2 / MALL / HBM at 1-2 us a round trip
+            for (; bb + (kFinInFlight - 1) * nsub < G; bb += kFinInFlight * nsub) {
+                f4 v[kFinInFlight];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(bb + u * nsub) * stride4);
+                for (int u = 0; u < kFinInFlight; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(bb + u * nsub) * stride4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+                for (int u = 0; u < kFinInFlight; ++u) acc += v[u];
             }
             for (; bb < G; bb += nsub) acc += __builtin_nontemporal_load(src + (size_t)bb * stride4);
         }
@@ -235,7 +240,7 @@ TrainPlan make_plan(const Geo &g, int L) {
     const int netblock = g.HT * (DM::NTI + DM::OTL) * 256;
     p.glayer_floats = 2 * netblock + DM::NT2 * 16;
     p.RMAX = TrainRows<NF, CQ>::value;
-    p.lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::template tb<TrainRows<NF, CQ>::value>()) * sizeof(float);
+    p.lds_bytes = ((size_t)kWaves * DM::SLOT + (size_t)kWaves * DM::template tb<TrainRows<NF, CQ>::value>()) * sizeof(float) + kSyncBytes;
     p.scratch_per_wave = (size_t)L * p.RMAX * 2 * NF * 64;
     return p;
 }

@@ -121,6 +121,22 @@ constexpr int kMaxGridTrain = RNVP_MAX_GRID_TRAIN;
 #define RNVP_NS_PRIO 0
 #endif
 constexpr int kNsPrio = RNVP_NS_PRIO;
+// RNVP_NS_TFLUSH (net-split launches, FT >= 2): the flush of the waves' LDS gradient slots into the workgroup's partial WITHOUT
+// workgroup barriers, done by the t-net waves for BOTH nets.  On every SIMD the t wave (older: it wins the issue arbitration)
+// runs ahead of its s partner and used to idle at the flush barriers while the s waves -- the kernel's critical path -- paid
+// the arrival skew of both barriers and the sum itself (profiles/r05_ns_prio_ab.txt: barrier1 41-48k + sum 15-21k + barrier2
+// 1-15k of 661k cycles on the s waves; 131-138k of barrier wait on the t waves).  Now the slots are two buffers of FT / 2 hidden
+// tiles used in turn: a wave that has written a window counts itself in (one LDS counter per net) and goes on; the t waves,
+// after their own window, wait for the window's eight arrivals, add the slots of both nets in slot order (the order of
+// arrival plays no part: bitwise as before) and write the partial, then count the window done; a wave checks that count
+// before it overwrites a buffer, two windows later.  The s waves never wait for a flush.
+#ifndef RNVP_NS_TFLUSH
+#define RNVP_NS_TFLUSH 1
+#endif
+constexpr bool kNsTFlush = RNVP_NS_TFLUSH != 0;
+constexpr size_t kSyncBytes = 128;                       // LDS behind a workgroup's buffers: 8 tile counters (RNVP_NS_PRIO 3), 3 flush counters, 8 pair flags
+struct FlushSync { int *arr; int *done; int win; };      // arr[0 / 1]: arrivals of the t / s waves; done: window shares summed; windows this wave finished
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int NF, int CQ> struct Dims {
     static constexpr int KS1 = NF + CQ;
@@ -208,7 +224,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                           float *gp_layer, bool first, Stamps &stp, float *xown,
                                           const float *xother, int tile_lo, int tile_hi,
                                           BwdPre<NF, CQ, R> &pre_ref, bool use_pre, const float *__restrict__ Wprev = nullptr,
-                                          const float *__restrict__ scr_prev = nullptr, int *prog = nullptr, int *prog_cnt = nullptr) {
+                                          const float *__restrict__ scr_prev = nullptr, int *prog = nullptr, int *prog_cnt = nullptr,
+                                          FlushSync *fs = nullptr, PairSync *ps = nullptr) {
     BwdPre<NF, CQ, R> *const pre = &pre_ref;       // (a reference + flag, not a nullable pointer: the record must stay in registers)
     // pre (tile split only): this layer's opening loads, made by the caller / the layer above; Wprev, scr_prev (nullable):
     // the layer below, whose opening loads are requested here before the input-gradient rendezvous
@@ -227,6 +244,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int ht_lo = TS ? tile_lo : 0, ht_hi = TS ? tile_hi : HT;
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
+    constexpr bool TF = kNsTFlush && NS == 1 && FT >= 2 && FT % 2 == 0 && WV == 4;      // t waves flush both nets, no barriers
+    constexpr int FT2 = FT / 2 > 0 ? FT / 2 : 1;
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
     float *slot = lds + wave * SLOT;
     float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging); W2C: R x 16 x GS
@@ -524,7 +543,17 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                 for (int o = 0; o < OTL; ++o) *reinterpret_cast<f4 *>(gd + (NTI + o) * 256) = gW2[o];
             } else if (!(kAblate & 2)) {
-                float *sb = slot + (size_t)(ht % FT) * TBLK + lane * 4;
+                int spos = ht % FT;
+                if constexpr (TF) {
+                    // window = FT / 2 tiles in buffer (window number & 1); its first tile: the sum of the window two back must
+                    // have read this buffer (four t-wave shares per window)
+                    if (ht % FT2 == 0 && fs->win >= 2) {
+                        while (__hip_atomic_load(fs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (fs->win - 1)) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                    }
+                    spos = (fs->win & 1) * FT2 + ht % FT2;
+                }
+                float *sb = slot + (size_t)spos * TBLK + lane * 4;
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) *reinterpret_cast<f4 *>(sb + nt * 256) = gW1[nt];
                 if constexpr (W2C) {
@@ -534,7 +563,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     for (int i = 0; i < 4; ++i) s4[i] = swap_add32(gW2[0][i], gW2[1][i]);
                     float2 kept;
                     kept.x = swap_add16(s4[0], s4[2]); kept.y = swap_add16(s4[1], s4[3]);
-                    *reinterpret_cast<float2 *>(slot + (size_t)(ht % FT) * TBLK + NTI * 256 + lane * 2) = kept;
+                    *reinterpret_cast<float2 *>(slot + (size_t)spos * TBLK + NTI * 256 + lane * 2) = kept;
                 } else {
 #pragma unroll
                     for (int o = 0; o < OTL; ++o) *reinterpret_cast<f4 *>(sb + (NTI + o) * 256) = gW2[o];
@@ -547,7 +576,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             }
             const bool last_tile = (ht + 1 == HT);
             STAMP_ADD(stp.p5, t0);
-            if (!TS && ((ht + 1) % FT == 0 || last_tile) && !(kAblate & 4)) {
+            if (!TS && ((ht + 1) % (TF ? FT2 : FT) == 0 || last_tile) && !(kAblate & 4)) {
                 if (last_tile && net == 1) {
                     // db2: sum g_out over the 16 rows of the tile(s); lanes r == 0 hold (q, reg) sums
 #pragma unroll
@@ -563,6 +592,45 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 // barrier, so that their memory latency (an L2 miss: the partials of all workgroups exceed the L2) overlaps the wait
                 // for the slowest wave instead of following it -- C4 spent 17 % of the kernel in this read-modify-write
                 // (profiles/r04_stamp_c4.txt)
+                if constexpr (TF) {
+                    const int w_t0 = (ht / FT2) * FT2, w_n4 = (ht + 1 - w_t0) * TBLK / 4;      // the window's first tile, its f4 count per net
+                    const int bufoff = (fs->win & 1) * FT2 * TBLK;
+                    lds_drain();                                               // this wave's slot (and db2) writes have landed
+                    if (lane == 0) __hip_atomic_fetch_add(fs->arr + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++fs->win;
+                    STAMP_ADD(stp.fb1, t0);
+                    if (role == 0) {
+                        // the t waves flush both nets: wait for the window's arrivals (the s waves are behind: this is the wait the
+                        // flush barrier used to be, minus the s waves' share of it)
+                        while (__hip_atomic_load(fs->arr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * fs->win ||
+                               __hip_atomic_load(fs->arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * fs->win) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                        STAMP_ADD(stp.bflush, t0);
+                        static_assert(FT2 * TBLK / 4 <= 256, "one f4 per t-wave thread and net");
+                        if (tid < w_n4) {
+#pragma unroll
+                            for (int n2 = 0; n2 < 2; ++n2) {
+                                f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)n2 * netblock + (size_t)w_t0 * TBLK) + tid;
+                                const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)n2 * WV * SLOT + bufoff) + tid;
+                                f4 v = s0[0];
+#pragma unroll
+                                for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4)];          // slot order: deterministic
+                                *dst = first ? v : v + *dst;
+                            }
+                        }
+                        if (last_tile && tid < NT2 * 16) {                    // db2 lives in the s waves' slots
+                            const int i = WV * SLOT + FT * TBLK + tid;
+                            float v = lds[i];
+#pragma unroll
+                            for (int w = 1; w < WV; ++w) v += lds[w * SLOT + i];
+                            float *p = gp_layer + 2 * (size_t)netblock + tid;
+                            *p = first ? v : *p + v;
+                        }
+                        lds_drain();                                           // the slot reads are done: the buffer may be rewritten
+                        if (lane == 0) __hip_atomic_fetch_add(fs->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    STAMP_ADD(stp.fsum, t0);
+                } else {
                 constexpr int FTH = NS ? 256 : WV * 64;                  // threads that add one net's slots
                 constexpr int KIT = (FT * TBLK / 4 + FTH - 1) / FTH;
                 const int fl_t0 = (ht / FT) * FT, fl_n4 = (ht + 1 - fl_t0) * TBLK / 4;
@@ -624,6 +692,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.fsum, t0);
                 if (!(kAblate & 128)) __syncthreads();
                 STAMP_ADD(stp.bflush, t0);
+                }
             }
 #pragma unroll
             for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = na1[k4];
@@ -693,7 +762,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
             for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = gi[rt][f];
-        __syncthreads();
+        pair_rendezvous(*ps, lane);
 #pragma unroll
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
@@ -728,8 +797,16 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     constexpr int SLOTN = DM::template slot<NS>(), TBN = DM::template tbn<R, NS>();
     float *tb = lds + NW * SLOTN + wave * TBN;
     float *xbuf = lds + NW * SLOTN + NW * TBN;                         // NS: 2 x NW x XW, double buffered by layer parity
-    int *prog = reinterpret_cast<int *>(xbuf + 2 * NW * XW);           // NS, RNVP_NS_PRIO 3: one tile counter per wave
+    int *prog = reinterpret_cast<int *>(xbuf + (NS ? 2 * NW * XW : 0));   // NS, RNVP_NS_PRIO 3: one tile counter per wave
     int prog_cnt = 0;
+    // RNVP_NS_TFLUSH: arrivals of the t / s waves and summed window shares, behind the tile counters
+    FlushSync fsync{prog + 8, prog + 10, 0};
+    PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
+    if constexpr (NS == 1) {
+        if (threadIdx.x < 3) prog[8 + threadIdx.x] = 0;
+        if (threadIdx.x < NW) prog[16 + threadIdx.x] = 0;
+        __syncthreads();
+    }
     if constexpr (NS == 1 && kNsPrio == 3) { if (threadIdx.x < NW) prog[threadIdx.x] = 0; }      // (the forward's barriers publish it)
     if constexpr (NS == 1 && kNsPrio == 1) { if (__builtin_amdgcn_readfirstlane(role)) __builtin_amdgcn_s_setprio(1); }
     const int64_t rows_per_wg = (int64_t)WV * R * 16;
@@ -762,8 +839,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr);
-                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync);
             } else {
                 if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
                 else layer_forward<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
@@ -806,8 +883,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
             BwdPre<NF, CQ, R> nopre;            // (tile-split kernel only)
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt);
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
@@ -1151,15 +1228,15 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
         lay->glayer_floats = p0.glayer_floats;
         if (k.act == RNVP_ACT_TANH)
             return launch_train_bx<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                                 kWaves * per_wave * sizeof(float), sd);
+                                                 kWaves * per_wave * sizeof(float) + kSyncBytes, sd);
         return launch_train_bx<NF, CQ, R, 1>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                             kWaves * per_wave * sizeof(float), sd);
+                                             kWaves * per_wave * sizeof(float) + kSyncBytes, sd);
     }
 #endif
     const size_t per_wave_ns = (size_t)DM::template slot<1>() + DM::template tbn<R, 1>();
     // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
     // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
-    const size_t lds_ns = (2 * kWaves * per_wave_ns + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float) + (kNsPrio == 3 ? 64 : 0);
+    const size_t lds_ns = (2 * kWaves * per_wave_ns + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float) + kSyncBytes;
     if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024) {
         lay->w2c = DM::template w2c<1>() ? 1 : 0;
         lay->glayer_floats = 2 * g.HT * DM::template tblk<1>() + DM::NT2 * 16;
@@ -1171,7 +1248,7 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     lay->w2c = DM::template w2c<0>() ? 1 : 0;
     lay->glayer_floats = p0.glayer_floats;
     if constexpr (kTrainWide && (NF == 4 || (NF == 8 && RNVP_TRAIN_WIDE8))) {       // d > 16: two 4-wave workgroups per CU become one 8-wave workgroup
-        const size_t lds_wide = kWideWaves * per_wave * sizeof(float);
+        const size_t lds_wide = kWideWaves * per_wave * sizeof(float) + kSyncBytes;
         if (ngroups > 256 && lds_wide <= 160 * 1024) {
             const int64_t rows_wide = (int64_t)kWideWaves * R * 16;
             const int64_t gw = (n + rows_wide - 1) / rows_wide;
@@ -1185,7 +1262,7 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
         }
     }
     return launch_train_ns<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                         kWaves * per_wave * sizeof(float), sd);
+                                         kWaves * per_wave * sizeof(float) + kSyncBytes, sd);
 }
 
 // rows the tile-split kernel takes for a geometry (launch_train below)
