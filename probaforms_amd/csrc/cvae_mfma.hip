@@ -45,7 +45,10 @@ using mfma::kTanhScale;
 #ifndef CVAE_FT
 #define CVAE_FT 8
 #endif
-constexpr int kWaves = 4, kR = CVAE_R, kMaxGrid = 512, kFT = CVAE_FT;
+#ifndef CVAE_WAVES
+#define CVAE_WAVES 4
+#endif
+constexpr int kWaves = CVAE_WAVES, kR = CVAE_R, kMaxGrid = 512, kFT = CVAE_FT;
 
 // CVAE_STAMP: diagnostic build that accumulates cycle-counter deltas per phase and printf()s them for two workgroups
 #ifdef CVAE_STAMP

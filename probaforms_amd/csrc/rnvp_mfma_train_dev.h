@@ -130,6 +130,12 @@ constexpr int kNsPrio = RNVP_NS_PRIO;
 // after their own window, wait for the window's eight arrivals, add the slots of both nets in slot order (the order of
 // arrival plays no part: bitwise as before) and write the partial, then count the window done; a wave checks that count
 // before it overwrites a buffer, two windows later.  The s waves never wait for a flush.
+// RNVP_BWD_READS_FIRST 1: measured SLOWER (profiles/r05_reads_first_ab.txt: C2 0.301-0.307 vs 0.294-0.300 ms, C4 1.105 vs 1.095): the
+// requests ahead of the products delay the products' issue by as much as they save at phase 4; hipcc's own placement ships
+#ifndef RNVP_BWD_READS_FIRST
+#define RNVP_BWD_READS_FIRST 0
+#endif
+constexpr bool kBwdReadsFirst = RNVP_BWD_READS_FIRST != 0;
 #ifndef RNVP_NS_TFLUSH
 #define RNVP_NS_TFLUSH 1
 #endif
@@ -470,6 +476,28 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.p2, t0);
 
                 // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
+                // RNVP_BWD_READS_FIRST: the transposed reads are REQUESTED ahead of these products (a wave's DS operations execute
+                // in order, so they see phase 2's writes) and their latency runs under the products' ~170 matrix cycles; left to
+                // itself hipcc issued most of them behind the products and phase 4 opened on an s_waitcnt per operand
+                float hT[RH][4], pT[RH][4];
+                float2 gB[W2C ? RH : 1][4];
+                auto read_transposed = [&]() {
+#pragma unroll
+                    for (int u = 0; u < RH; ++u)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            if (!(kAblate & 1)) {
+                                hT[u][ks] = bufH[(2 * u) * 16 * kTS + (4 * ks + q) * kTS + r];
+                                pT[u][ks] = bufH[(2 * u + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
+                            } else {
+                                hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
+                            }
+                            if constexpr (W2C)
+                                gB[u][ks] = *reinterpret_cast<const float2 *>(bufG + (NS == 0 ? net * R * 16 * GS : 0) +
+                                                                              ((r0 + u) * 16 + 4 * ks + q) * GS + 2 * (r & 3));
+                        }
+                };
+                if constexpr (kBwdReadsFirst) { read_transposed(); BWD_SCHED_BARRIER(); }
                 if constexpr (X4) {
 #pragma unroll
                     for (int rho = 0; rho < 4; ++rho)
@@ -486,22 +514,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             for (int u = 0; u < RH; ++u)
                                 gin[r0 + u][m] = mfma16(a1t[m][rho], gpv[u][rho], gin[r0 + u][m]);
                 }
-                float hT[RH][4], pT[RH][4];
-                float2 gB[W2C ? RH : 1][4];
-#pragma unroll
-                for (int u = 0; u < RH; ++u)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        if (!(kAblate & 1)) {
-                            hT[u][ks] = bufH[(2 * u) * 16 * kTS + (4 * ks + q) * kTS + r];
-                            pT[u][ks] = bufH[(2 * u + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
-                        } else {
-                            hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
-                        }
-                        if constexpr (W2C)
-                            gB[u][ks] = *reinterpret_cast<const float2 *>(bufG + (NS == 0 ? net * R * 16 * GS : 0) +
-                                                                          ((r0 + u) * 16 + 4 * ks + q) * GS + 2 * (r & 3));
-                    }
+                if constexpr (!kBwdReadsFirst) read_transposed();
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p3, t0);
 

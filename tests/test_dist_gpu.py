@@ -92,7 +92,24 @@ def test_bench_self_launches_two_ranks_and_prints_one_json_line():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["global_batch"] == 2 * 65536 and j["roofline"]["frac"] > 0
-    assert len(j["roofline_kernels"]) == 2 and all(v["frac"] > 0 for v in j["roofline_kernels"].values())
+    assert len(j["roofline_kernels"]) >= 2 and all(v["frac"] > 0 for v in j["roofline_kernels"].values())
+    assert j["config"]["rank_batch"] == 65536 and j["config"]["replicas_identical"] is True and j["timed_blocks"] >= 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_global_batch_mode_shares_one_batch_size_out_over_the_ranks():
+    """--global-batch 65536 (the reference's ONE batch_size, realnvp.py:237; SURVEY 8(d)/(e)'s headline): every rank takes
+    65536 / N rows of each step, the replicas stay bit-identical, the line says which regime it timed"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--global-batch", "65536", "--no-cpu-baseline", "--no-api-level"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 65536 and j["config"]["rank_batch"] == 32768
+    assert j["config"]["replicas_identical"] is True and j["config"]["batch_mode"].startswith("global batch fixed")
+    assert j["roofline"]["dispatch"]["rows"] == 32768
 
 
 @pytest.mark.timeout(900)
