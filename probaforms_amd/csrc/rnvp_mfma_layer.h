@@ -192,6 +192,14 @@ __device__ __forceinline__ void pair_rendezvous(PairSync &ps, int lane) {
     }
 }
 
+// RNVP_SAVE_H_TILES: hidden tiles per net whose activations the training kernel's forward phase saves for its backward
+// (rnvp_mfma_train_dev.h RNVP_SAVE_H); the other tiles are recomputed.  Saving all of them makes the forward phase HBM-write bound
+// at 65 536 rows (537 MB in ~60 us); the count balances the bytes against the matrix cycles they save.
+#ifndef RNVP_SAVE_H_TILES
+#define RNVP_SAVE_H_TILES 2
+#endif
+constexpr int kSaveHTiles = RNVP_SAVE_H_TILES;
+
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering the accesses.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -446,7 +454,9 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
                                              int ntiles, const float (&xr)[R][4],
                                              const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4],
                                              const f4 (*bin)[SplitDims<2, CQ>::NI1] = nullptr,
-                                             const TilePre<2, CQ> *pre = nullptr) {
+                                             const TilePre<2, CQ> *pre = nullptr, float *hs = nullptr) {
+    // hs (training, RNVP_SAVE_H): the tiles' hidden activations are stored -- [tile][row tile][lane] f4, the accumulator layout --
+    // for the backward, which then neither recomputes GEMM1 nor the activation
     constexpr int NF = 2;
     constexpr int K4 = G1Dims<NF, CQ, BX>::NA;
     const int q = lane >> 4;
@@ -521,6 +531,10 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
             for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (hs && t < kSaveHTiles) {
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)t * R + rt) * 256 + lane * 4) = hv[rt];
+        }
         gemm2(c, hv);                                  // phase B
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -528,6 +542,10 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
         f4 hv[R];
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(c.acc[rt]);
+        if (hs && last < kSaveHTiles) {
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)last * R + rt) * 256 + lane * 4) = hv[rt];
+        }
         gemm2(c, hv);
     };
     int t = 0;
@@ -621,7 +639,7 @@ template <int NF, int CQ, int R, int PC, int MODE, int ACT, bool BX = false>
 __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
                                                  float *xown, const float *xother, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
-                                                 float *__restrict__ scr, PairSync &ps) {
+                                                 float *__restrict__ scr, PairSync &ps, float *hs = nullptr) {
     using D = FwdDims<NF, CQ>;
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4;
@@ -636,7 +654,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (role == 0) {
-            run_tiles_x4<CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, outx, bin);
+            run_tiles_x4<CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, outx, bin, nullptr, hs);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -646,7 +664,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
                 own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[1];
             }
         } else {
-            run_tiles_x4<CQ, R, PC, 1, ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, outx, bin);
+            run_tiles_x4<CQ, R, PC, 1, ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, outx, bin, nullptr, hs);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];

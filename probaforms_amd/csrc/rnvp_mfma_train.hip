@@ -272,8 +272,19 @@ bool train_supported(const KShape &k) {
     return pl.lds_bytes <= 160 * 1024;
 }
 
+// RNVP_SAVE_H: the net-split launches of d <= 16 keep every hidden activation of the forward phase for the backward: per
+// workgroup L x 2 nets x 4 row owners x HT tiles x R row tiles of 1 KiB -- 4 h L bytes per row and net (8 KB per row for C2),
+// for at most 256 workgroups (the net-split launches are those with one workgroup per CU or fewer)
+static size_t hsave_bytes(const Geo &g, int L, const TrainPlan &pl, int64_t max_rows) {
+    if (!kSaveH || g.NF != 2) return 0;
+    const size_t per_wg_r1 = (size_t)L * 2 * kWaves * g.HT * 256 * sizeof(float);      // one row tile per wave: 64 rows per workgroup
+    // ceil(n / (64 R)) workgroups of R x per_wg_r1 bytes, whatever R the launch picks, for every n <= max_rows; a net-split launch
+    // never has more than 256 workgroups
+    const size_t need = (size_t)((max_rows + 63) / 64 + pl.RMAX) * per_wg_r1, cap = (size_t)256 * pl.RMAX * per_wg_r1;
+    return align_up(need < cap ? need : cap, 256);
+}
+
 size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
-    (void)max_rows;
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return 0;
@@ -281,6 +292,7 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
     b += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);          // partials
     b += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);                          // loss partials
     b += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);    // saved activations
+    b += hsave_bytes(g, k.L, pl, max_rows);                                                      // hidden activations (RNVP_SAVE_H)
     return b;
 }
 
@@ -316,6 +328,8 @@ static int step_impl(hipStream_t st, const KShape &k, const float *params, const
     float *losspart = reinterpret_cast<float *>(w);
     w += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);
     float *scratch = reinterpret_cast<float *>(w);
+    w += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);
+    if (hsave_bytes(g, k.L, pl, n) > 0) sd.hsave = reinterpret_cast<float *>(w);
     int rc = packed_valid ? RNVP_OK : pack_weights(st, k, g, params, packed);
     if (rc) return rc;
     int grid = 0;

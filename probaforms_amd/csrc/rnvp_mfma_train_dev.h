@@ -136,6 +136,18 @@ constexpr int kNsPrio = RNVP_NS_PRIO;
 #define RNVP_BWD_READS_FIRST 0
 #endif
 constexpr bool kBwdReadsFirst = RNVP_BWD_READS_FIRST != 0;
+// RNVP_SAVE_H (net-split launches of d <= 16): the forward phase stores every hidden tile's activations (16 B per lane and row
+// tile, the accumulator layout: 8 KB per row for C2) and the backward reads them back, one hidden tile ahead, instead of
+// recomputing GEMM1 + tanh -- 96 matrix + 96 transcendental cycles of the backward unit's ~590, paid for with HBM traffic the
+// MFMA-bound kernel leaves idle.
+// Built, parity-green (631 kernel tests), measured (profiles/r05_saveh_ab.txt), OFF: at 65 536 rows saving all eight tiles per net
+// (537 MB written in the ~60 us forward phase) makes the launch 0.357 ms against 0.293 recomputing; saving 1 / 2 / 3 / 4 tiles
+// (RNVP_SAVE_H_TILES; the others recomputed in the same loop) 0.326 / 0.337 / 0.356 / 0.365 -- every count loses; only launches
+// whose record fits the caches gain (16 960 rows: 0.157 vs 0.164).
+#ifndef RNVP_SAVE_H
+#define RNVP_SAVE_H 0
+#endif
+constexpr bool kSaveH = RNVP_SAVE_H != 0;
 #ifndef RNVP_NS_TFLUSH
 #define RNVP_NS_TFLUSH 1
 #endif
@@ -231,7 +243,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                           const float *xother, int tile_lo, int tile_hi,
                                           BwdPre<NF, CQ, R> &pre_ref, bool use_pre, const float *__restrict__ Wprev = nullptr,
                                           const float *__restrict__ scr_prev = nullptr, int *prog = nullptr, int *prog_cnt = nullptr,
-                                          FlushSync *fs = nullptr, PairSync *ps = nullptr) {
+                                          FlushSync *fs = nullptr, PairSync *ps = nullptr, const float *__restrict__ hs = nullptr) {
     BwdPre<NF, CQ, R> *const pre = &pre_ref;       // (a reference + flag, not a nullable pointer: the record must stay in registers)
     // pre (tile split only): this layer's opening loads, made by the caller / the layer above; Wprev, scr_prev (nullable):
     // the layer below, whose opening loads are requested here before the input-gradient rendezvous
@@ -250,6 +262,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int ht_lo = TS ? tile_lo : 0, ht_hi = TS ? tile_hi : HT;
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
+    constexpr bool SH = kSaveH && NS == 1 && NF == 2 && !BX;       // hidden activations come from the forward's record (hs)
     constexpr bool TF = kNsTFlush && NS == 1 && FT >= 2 && FT % 2 == 0 && WV == 4;      // t waves flush both nets, no barriers
     constexpr int FT2 = FT / 2 > 0 ? FT / 2 : 1;
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
@@ -386,8 +399,22 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
         for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)ht_lo * NGI + m) * 256);
         }
+        f4 hc[SH ? R : 1], hn[SH ? R : 1];
+        if constexpr (SH) {
+            if (ht_lo < kSaveHTiles) {
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hs + ((size_t)ht_lo * R + rt) * 256 + lane * 4);
+            }
+        }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
+            const bool sv = SH && ht < kSaveHTiles;            // this tile's activations come from the forward's record
+            if constexpr (SH) {
+                if (nx < kSaveHTiles) {
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hs + ((size_t)nx * R + rt) * 256 + lane * 4);
+                }
+            }
             int prog_mine = 0, prog_other = 0; (void)prog_mine; (void)prog_other;
             if constexpr (NS == 1 && kNsPrio == 2) {
                 if (__builtin_amdgcn_readfirstlane(role)) { if (__builtin_amdgcn_readfirstlane(ht) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
@@ -432,11 +459,13 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                         for (int u = 0; u < RH; ++u) gh[u] = mfma32(a2t[i], gob[r0 + u][NS ? 0 : net][i], gh[u]);
                 } else {
+                if (!sv) {
 #pragma unroll
                 for (int kk = 0; kk < KS1; ++kk)
 #pragma unroll
                     for (int u = 0; u < RH; ++u)
                         acc[u] = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), acc[u]);
+                }
                 if (NF >= 4) {
 #pragma unroll
                     for (int o = 0; o < OTL; ++o)
@@ -462,7 +491,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 wave_lds_fence();
 #pragma unroll
                 for (int u = 0; u < RH; ++u) {
-                    const f4 hv = act4<ACT>(acc[u]);
+                    f4 hv;
+                    if (sv) hv = hc[SH ? r0 + u : 0]; else hv = act4<ACT>(acc[u]);
                     gpv[u] = gh[u] * dact4<ACT>(hv);                                     // activation'
                     if (!(kAblate & 1)) {
                         *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
@@ -707,6 +737,10 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.bflush, t0);
                 }
             }
+            if constexpr (SH) {
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) hc[rt] = hn[rt];
+            }
 #pragma unroll
             for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = na1[k4];
             b1 = nb1;
@@ -814,6 +848,10 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     int prog_cnt = 0;
     // RNVP_NS_TFLUSH: arrivals of the t / s waves and summed window shares, behind the tile counters
     FlushSync fsync{prog + 8, prog + 10, 0};
+    // RNVP_SAVE_H: this wave's record of hidden activations: [layer][net][row owner][tile][row tile][lane] f4
+    constexpr bool SHB = kSaveH && NS == 1 && NF == 2 && !BX;
+    const size_t hs_layer = (size_t)2 * WV * g.HT * R * 256;
+    float *hs_wave = SHB ? sd.hsave + (size_t)blockIdx.x * L * hs_layer + ((size_t)role * WV + pw) * g.HT * R * 256 : nullptr;
     PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
     if constexpr (NS == 1) {
         if (threadIdx.x < 3) prog[8 + threadIdx.x] = 0;
@@ -852,8 +890,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync);
-                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
             } else {
                 if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
                 else layer_forward<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
@@ -896,8 +934,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
             BwdPre<NF, CQ, R> nopre;            // (tile-split kernel only)
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
