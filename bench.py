@@ -59,8 +59,8 @@ BATCH = 65_536
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # split-bf16 GEMM1 (precision 'bx3'): six bf16 products per f32 product on the dense bf16 MFMA peak (16x the f32 one)
 BX3_EFFECTIVE_TFLOPS = 16.0 * F32_MFMA_PEAK_TFLOPS / 6.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic_pmc.json")             # the C2 step (this command, default workload)
-TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r04_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic_pmc.json")             # the C2 step (this command, default workload)
+TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r05_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
 
 
 def mixed_bound_seconds_per_row(d, c, hidden, L, passes=1):
@@ -737,7 +737,8 @@ def main():
     # HIP events around the hot kernels, recorded by the library on the stream it launches on, for every
     # launch of the timed region
     MAX_BLOCKS = 64
-    _hip.profile_enable(MAX_BLOCKS * args.steps * (nb + 1) + 8)
+    _hip.profile_enable(args.steps * (nb + 1) + 8)          # one block's launches; read (and reset) after every block
+    prof = {"n_train": 0, "train_ms": 0.0, "n_inv": 0, "inv_ms": 0.0}
 
     def timed_block():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; the MAX over the ranks"""
@@ -753,6 +754,8 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if dp:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        a, b = _hip.profile_read(_hip.PROFILE_TRAIN); prof["n_train"] += a; prof["train_ms"] += b      # outside the clock
+        a, b = _hip.profile_read(_hip.PROFILE_INVERSE); prof["n_inv"] += a; prof["inv_ms"] += b
         return float(t.item())
 
     # A block of --steps steps can be far shorter than a second (20 steps of C2 = 0.11 s): the block is then repeated until about
@@ -786,8 +789,7 @@ def main():
             dp_failure = "the library's RCCL communicator spans %d of %d ranks (fell back to the per-batch loop)" % (rccl_ranks, world)
         elif not replicas_identical:
             dp_failure = "the ranks' parameters / last loss differ after the timed region"
-    n_train, train_ms = _hip.profile_read(_hip.PROFILE_TRAIN)
-    n_inv, inv_ms = _hip.profile_read(_hip.PROFILE_INVERSE)
+    n_train, train_ms, n_inv, inv_ms = prof["n_train"], prof["train_ms"], prof["n_inv"], prof["inv_ms"]
     # what the library launched for the timed region's last batch / sampling call (rnvp_last_dispatch: written by the launch
     # sites themselves): the kernel names, variants and arithmetic below are the library's statement, not a copy of its rules
     disp_train = _hip.last_dispatch(_hip.PROFILE_TRAIN) if do_fit else None          # the epoch's LAST batch: the ragged one

@@ -3,7 +3,7 @@
 command run without the profiler (gpurun_out/<tag>_bench_plain.json when present).  usage: python scripts/event_vs_rocprof.py <tag>"""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 out = os.path.join(ROOT, "gpurun_out")
 line = None
 for l in open(os.path.join(out, "%s_prof_bench.log" % tag), errors="replace"):

@@ -1,6 +1,6 @@
 # usage (GPU box, via gpurun): bash scripts/gpu_micro.sh <tag>  -- the microbenchmarks DESIGN.md leans on, output under gpurun_out/
 # Each scripts/micro/*.hip is built here (hipcc, gfx950) before it runs; a failed build or run fails the script loudly.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /root/repo; mkdir -p gpurun_out
 OUT=gpurun_out/${TAG}_micro_overlap.txt
 : > $OUT
