@@ -21,6 +21,7 @@ CASES = [
     ("user_masks", 3, 7, 3, (20,), "tanh", 65, "random"),
     ("wide", 2, 40, 20, (64,), "tanh", 50, "alt"),            # d > 16, c > 16
     ("one_cond", 5, 2, 1, (10,), "tanh", 33, "alt"),          # README example
+    ("no_cond", 4, 6, 0, (12,), "tanh", 40, "alt"),           # C = None: nothing to differentiate there, the rest unchanged
 ]
 
 
@@ -83,23 +84,24 @@ def test_condition_gradient_through_log_prob(cid, L, d, c, hidden, act, n, masks
     nf, ref = _build(L, d, c, hidden, act, masks, 11)
     g = torch.Generator().manual_seed(5)
     X0 = torch.randn(n, d, generator=g); C0 = torch.randn(n, c, generator=g); w = torch.rand(n, generator=g) + 0.5
-    X = X0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True)
+    X = X0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True) if c else None
     lp = nf.log_prob_samples(X, C)
     assert lp.grad_fn is not None
     (-(w.cuda() * lp).sum() / n).backward()
-    Xr = X0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True)
+    Xr = X0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True) if c else None
     lpr, _ = ref.log_prob_rows(Xr, Cr)
     (-(w.double() * lpr).sum() / n).backward()
     assert float((lp.detach().cpu().double() - lpr.detach()).abs().max()) < 1e-5 + 3e-6 * float(lpr.detach().abs().max())
-    _close(C.grad, Cr.grad, "d loss / d C")
+    if c:
+        _close(C.grad, Cr.grad, "d loss / d C")
     _close(X.grad, Xr.grad, "d loss / d X")
     _check_params(nf, ref)
     # C without a gradient keeps the cheaper call and returns None for it
     for p in nf.parameters():
         p.grad = None
-    C2 = C0.cuda()
+    C2 = C0.cuda() if c else None
     (-nf.log_prob(X0.cuda(), C2)).backward()
-    assert C2.grad is None and all(p.grad is not None for p in nf.parameters())
+    assert (C2 is None or C2.grad is None) and all(p.grad is not None for p in nf.parameters())
 
 
 @pytest.mark.parametrize("cid,L,d,c,hidden,act,n,masks", CASES, ids=[t[0] for t in CASES])
@@ -108,17 +110,24 @@ def test_backward_through_the_inverse(cid, L, d, c, hidden, act, n, masks):
     nf, ref = _build(L, d, c, hidden, act, masks, 12)
     g = torch.Generator().manual_seed(6)
     Z0 = torch.randn(n, d, generator=g); C0 = torch.randn(n, c, generator=g); A = torch.randn(n, d, generator=g)
-    Z = Z0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True)
+    Z = Z0.cuda().requires_grad_(True); C = C0.cuda().requires_grad_(True) if c else None
     x = nf.engine().inverse_autograd(Z, C)
     assert x.grad_fn is not None
     ((A.cuda() * x).sum() / n + 0.05 * (x * x).sum() / n).backward()
-    Zr = Z0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True)
+    Zr = Z0.double().requires_grad_(True); Cr = C0.double().requires_grad_(True) if c else None
     xr = ref.inverse_rows(Zr, Cr)
     ((A.double() * xr).sum() / n + 0.05 * (xr * xr).sum() / n).backward()
     assert float((x.detach().cpu().double() - xr.detach()).abs().max()) < 2e-5 * max(1.0, float(xr.abs().max()))
     _close(Z.grad, Zr.grad, "d loss / d z")
-    _close(C.grad, Cr.grad, "d loss / d c")
+    if c:
+        _close(C.grad, Cr.grad, "d loss / d c")
     _check_params(nf, ref)
+    # an empty batch: zero gradients, no launch
+    for p in nf.parameters():
+        p.grad = None
+    Ze = torch.zeros(0, d, device="cuda", requires_grad=True)
+    nf.engine().inverse_autograd(Ze, torch.zeros(0, c, device="cuda") if c else None).sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in nf.parameters())
 
 
 def test_nf_sample_and_layer_g_carry_a_graph_like_the_reference():
