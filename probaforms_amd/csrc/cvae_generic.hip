@@ -208,7 +208,7 @@ size_t cvae_workspace_bytes(const cvae_shape *shape, int64_t max_rows) {
     CvaeK k;
     if (make_cvae(shape, &k) != RNVP_OK) return 0;
     size_t b = generic_cvae_workspace(k);                       // any path may run (shape->family)
-    if (cvae_mfma::supported(shape)) { const size_t m = cvae_mfma::workspace_bytes(shape) + 256; if (m > b) b = m; }
+    if (cvae_mfma::supported(shape)) { const size_t m = cvae_mfma::workspace_bytes(shape, max_rows) + 256; if (m > b) b = m; }
     if (lmm::cvae_fits(k, RNVP_OP_TRAIN)) { const size_t m = lmm::cvae_workspace_bytes(k, max_rows) + 256; if (m > b) b = m; }
     return b;
 }

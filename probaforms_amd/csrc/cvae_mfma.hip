@@ -48,6 +48,15 @@ using mfma::kTanhScale;
 #ifndef CVAE_WAVES
 #define CVAE_WAVES 4
 #endif
+// CVAE_SAVE_H: the encoder's and the decoder's hidden activations are stored by the forward (16 B per lane, hidden tile and row
+// tile: 4 h bytes per row and net, 1 KB per row at C5 = 67 MB per 65 536-row step, which the 256 MB memory-side cache holds) and
+// read back, one hidden tile ahead, by the two backward loops instead of recomputing GEMM1 + tanh there: 5 + 2 of the 19 + 14
+// f32 MFMAs per unit and both tanh evaluations.  (The flow kernels' records are 8x larger per row -- eight layers -- and lose:
+// rnvp_mfma_train_dev.h RNVP_SAVE_H.)
+#ifndef CVAE_SAVE_H
+#define CVAE_SAVE_H 1
+#endif
+constexpr bool kSaveH = CVAE_SAVE_H != 0;
 constexpr int kWaves = CVAE_WAVES, kR = CVAE_R, kMaxGrid = 512, kFT = CVAE_FT;
 
 // CVAE_STAMP: diagnostic build that accumulates cycle-counter deltas per phase and printf()s them for two workgroups
@@ -186,7 +195,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 __global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, const float *__restrict__ c,
             const int64_t *__restrict__ row_index, const float *__restrict__ eps, int64_t n, float inv_B, float klw,
-            float *gpart, float *losspart, int do_grad) {
+            float *gpart, float *losspart, int do_grad, float *hsave) {
     constexpr int R = kR, RH = 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -200,6 +209,9 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const bool full = (g.d == 16) && (g.c == 4);
     float *gp = gpart + (size_t)blockIdx.x * g.gfloats;
+    // CVAE_SAVE_H: this wave's records [net][tile][row tile][lane] f4
+    float *hsE = hsave + ((size_t)blockIdx.x * kWaves + wave) * 2 * HT * R * 256 + lane * 4, *hsD = hsE + (size_t)HT * R * 256;
+    const bool sv = kSaveH && do_grad;
     float wave_sum = 0.f;
     bool first = true;
     const f4 bh = *reinterpret_cast<const f4 *>(wp + g.oBH + q * 4);
@@ -243,6 +255,7 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                     for (int kk = 0; kk < 4; ++kk) acc = mfma16(a10[kk], xr[rt][kk], acc);
                     acc = mfma16(a11[0], cr[rt][0], acc);
                     hv[rt] = tanh4(acc);
+                    if (sv) *reinterpret_cast<f4 *>(hsE + ((size_t)t * R + rt) * 256) = hv[rt];
                 }
 #pragma unroll
                 for (int rho = 0; rho < 4; ++rho)
@@ -278,6 +291,7 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                     f4 acc = mfma16(a1[0], z[rt], b1);
                     acc = mfma16(a1[1], cr[rt][0], acc);
                     hv[rt] = tanh4(acc);
+                    if (sv) *reinterpret_cast<f4 *>(hsD + ((size_t)t * R + rt) * 256) = hv[rt];
                 }
 #pragma unroll
                 for (int rho = 0; rho < 4; ++rho)
@@ -324,9 +338,19 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
             const float *pA1 = wp + g.oA1D + lane * 4, *pB1 = wp + g.oB1D + q * 4;
             const float *pA2T = wp + g.oA2DT + lane * 4, *pA1X = wp + g.oA1DX + lane * 4;
             f4 a1 = *opaque(pA1), b1 = *opaque(pB1), a2t = *opaque(pA2T), a1x = *opaque(pA1X);
+            f4 hc[kSaveH ? R : 1], hn[kSaveH ? R : 1];
+            if constexpr (kSaveH) {
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hsD + (size_t)rt * 256);
+            }
             for (int t = 0; t < HT; ++t) {
                 const int nx = t + 1 < HT ? t + 1 : t;
-                const f4 na1 = *opaque(pA1 + (size_t)nx * 256), nb1 = *opaque(pB1 + nx * 16);
+                f4 na1 = a1, nb1 = b1;
+                if constexpr (!kSaveH) { na1 = *opaque(pA1 + (size_t)nx * 256); nb1 = *opaque(pB1 + nx * 16); }
+                else {
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hsD + ((size_t)nx * R + rt) * 256);
+                }
                 const f4 na2t = *opaque(pA2T + (size_t)nx * 256), na1x = *opaque(pA1X + (size_t)nx * 256);
                 f4 gW1 = f4{0.f, 0.f, 0.f, 0.f}, gW2 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -336,9 +360,13 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
 #pragma unroll
                     for (int u = 0; u < RH; ++u) {
                         const int rt = r0 + u;
-                        f4 acc = mfma16(a1[0], z[rt], b1);
-                        acc = mfma16(a1[1], cr[rt][0], acc);
-                        const f4 hv = tanh4(acc);
+                        f4 hv;
+                        if constexpr (kSaveH) hv = hc[rt];
+                        else {
+                            f4 acc = mfma16(a1[0], z[rt], b1);
+                            acc = mfma16(a1[1], cr[rt][0], acc);
+                            hv = tanh4(acc);
+                        }
                         f4 gh = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int rho = 0; rho < 4; ++rho) gh = mfma16(a2t[rho], gx[rt][rho], gh);
@@ -391,6 +419,10 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                     CSTAMP_ADD(s_dfl, t0);
                 }
                 a1 = na1; b1 = nb1; a2t = na2t; a1x = na1x;
+                if constexpr (kSaveH) {
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) hc[rt] = hn[rt];
+                }
             }
         }
         CSTAMP_ADD(s_db, t0);
@@ -415,10 +447,21 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
         {
             const float *pA1 = wp + g.oA1E + lane * 4, *pB1 = wp + g.oB1E + q * 4, *pA2T = wp + g.oA2ET + lane * 4;
             f4 a10 = *opaque(pA1), a11 = *opaque(pA1 + 256), b1 = *opaque(pB1), a2t = *opaque(pA2T);
+            f4 hc[kSaveH ? R : 1], hn[kSaveH ? R : 1];
+            if constexpr (kSaveH) {
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hsE + (size_t)rt * 256);
+            }
             for (int t = 0; t < HT; ++t) {
                 const int nx = t + 1 < HT ? t + 1 : t;
-                const f4 na10 = *opaque(pA1 + (size_t)(2 * nx) * 256), na11 = *opaque(pA1 + (size_t)(2 * nx + 1) * 256);
-                const f4 nb1 = *opaque(pB1 + nx * 16), na2t = *opaque(pA2T + (size_t)nx * 256);
+                f4 na10 = a10, na11 = a11, nb1 = b1;
+                if constexpr (!kSaveH) {
+                    na10 = *opaque(pA1 + (size_t)(2 * nx) * 256); na11 = *opaque(pA1 + (size_t)(2 * nx + 1) * 256); nb1 = *opaque(pB1 + nx * 16);
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hsE + ((size_t)nx * R + rt) * 256);
+                }
+                const f4 na2t = *opaque(pA2T + (size_t)nx * 256);
                 f4 gW1a = f4{0.f, 0.f, 0.f, 0.f}, gW1b = f4{0.f, 0.f, 0.f, 0.f}, gW2 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r0 = 0; r0 < R; r0 += RH) {
@@ -426,11 +469,15 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
 #pragma unroll
                     for (int u = 0; u < RH; ++u) {
                         const int rt = r0 + u;
-                        f4 acc = b1;
+                        f4 hv;
+                        if constexpr (kSaveH) hv = hc[rt];
+                        else {
+                            f4 acc = b1;
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc = mfma16(a10[kk], xr[rt][kk], acc);
-                        acc = mfma16(a11[0], cr[rt][0], acc);
-                        const f4 hv = tanh4(acc);
+                            for (int kk = 0; kk < 4; ++kk) acc = mfma16(a10[kk], xr[rt][kk], acc);
+                            acc = mfma16(a11[0], cr[rt][0], acc);
+                            hv = tanh4(acc);
+                        }
                         f4 gh = mfma16(a2t[0], gmu[rt], f4{0.f, 0.f, 0.f, 0.f});
                         gh = mfma16(a2t[1], gls[rt], gh);
                         const f4 gpv = gh * (1.0f - hv * hv);
@@ -480,6 +527,10 @@ k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, con
                     CSTAMP_ADD(s_efl, t0);
                 }
                 a10 = na10; a11 = na11; b1 = nb1; a2t = na2t;
+                if constexpr (kSaveH) {
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt) hc[rt] = hn[rt];
+                }
             }
         }
         CSTAMP_ADD(s_eb, t0);
@@ -734,10 +785,20 @@ bool supported(const cvae_shape *s) {
            s->lat <= 4 && s->hidden[0] >= 1;
 }
 
-size_t workspace_bytes(const cvae_shape *s) {
+// CVAE_SAVE_H: per workgroup 2 nets x HT tiles x (waves x row tiles) KiB, for the workgroups max_rows rows need (at most kMaxGrid)
+static size_t hsave_bytes(const CG &g, int64_t max_rows) {
+    if (!kSaveH) return 0;
+    const int64_t rows_per_wg = (int64_t)kWaves * kR * 16;
+    int64_t wg = (max_rows + rows_per_wg - 1) / rows_per_wg;
+    if (wg < 1) wg = 1;
+    if (wg > kMaxGrid) wg = kMaxGrid;
+    return align_up((size_t)wg * kWaves * 2 * g.HT * kR * 256 * sizeof(float), 256);
+}
+
+size_t workspace_bytes(const cvae_shape *s, int64_t max_rows) {
     const CG g = make_cg(s);
     return align_up((size_t)g.packed_floats * 4, 256) + align_up((size_t)kMaxGrid * g.gfloats * 4, 256) +
-           align_up((size_t)kMaxGrid * kWaves * 4, 256);
+           align_up((size_t)kMaxGrid * kWaves * 4, 256) + hsave_bytes(g, max_rows);
 }
 
 // [pack] -> step kernel (per-workgroup partial gradients) -> k_cvae_finish (sum, scatter [, Adam [, re-pack]])
@@ -745,12 +806,13 @@ static int loss_grad_impl(hipStream_t st, const cvae_shape *s, const float *para
                           const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
                           float *loss_out, void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam,
                           bool packed_valid, bool pack_next) {
-    if (!ws || ws_bytes < workspace_bytes(s)) return RNVP_EWORKSPACE;
+    if (!ws || ws_bytes < workspace_bytes(s, n)) return RNVP_EWORKSPACE;
     const CG g = make_cg(s);
     char *w = static_cast<char *>(ws);
     float *packed = reinterpret_cast<float *>(w); w += align_up((size_t)g.packed_floats * 4, 256);
     float *gpart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * g.gfloats * 4, 256);
-    float *losspart = reinterpret_cast<float *>(w);
+    float *losspart = reinterpret_cast<float *>(w); w += align_up((size_t)kMaxGrid * kWaves * 4, 256);
+    float *hsave = reinterpret_cast<float *>(w);
     if (!packed_valid) {
         hipLaunchKernelGGL(k_pack, dim3((g.packed_floats + 255) / 256), dim3(256), 0, st, g, params, packed);
         RNVP_HIP_TRY(hipGetLastError());
@@ -765,7 +827,7 @@ static int loss_grad_impl(hipStream_t st, const cvae_shape *s, const float *para
     {
         KernelTimer timer(st, RNVP_PROFILE_TRAIN);
         hipLaunchKernelGGL(k_cvae_mfma, dim3(grid), dim3(kWaves * 64), lds_bytes(), st, g, packed, x, c, row_index, eps, n,
-                           inv_B, klw, gpart, losspart, grad_out ? 1 : 0);
+                           inv_B, klw, gpart, losspart, grad_out ? 1 : 0, hsave);
     }
     RNVP_HIP_TRY(hipGetLastError());
     const int mode = grad_out ? (kFinSum | (adam_p ? kFinAdam : 0) | (adam_p && pack_next ? kFinPack : 0)) : 0;

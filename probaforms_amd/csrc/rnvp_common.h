@@ -124,7 +124,7 @@ struct CvaeK {
 // ---- CVAE step on MFMA: cvae_mfma.hip (d <= 16, c <= 4, latent <= 4, one tanh hidden layer) ----
 namespace cvae_mfma {
 bool supported(const ::cvae_shape *s);
-size_t workspace_bytes(const ::cvae_shape *s);
+size_t workspace_bytes(const ::cvae_shape *s, int64_t max_rows);
 int loss_grad(hipStream_t st, const ::cvae_shape *s, const float *params, const float *x, const float *c,
               const int64_t *row_index, const float *eps, int64_t n, float inv_B, float klw, float *grad_out,
               float *loss_out, void *ws, size_t ws_bytes);
