@@ -152,8 +152,14 @@ constexpr bool kSaveH = RNVP_SAVE_H != 0;
 #define RNVP_NS_TFLUSH 1
 #endif
 constexpr bool kNsTFlush = RNVP_NS_TFLUSH != 0;
-constexpr size_t kSyncBytes = 128;                       // LDS behind a workgroup's buffers: 8 tile counters (RNVP_NS_PRIO 3), 3 flush counters, 8 pair flags
-struct FlushSync { int *arr; int *done; int win; };      // arr[0 / 1]: arrivals of the t / s waves; done: window shares summed; windows this wave finished
+// RNVP_WIDE_TFLUSH: the same for the eight-wave wide form (d in (16, 32], more than 256 workgroups' worth of rows: C3 at 65 536): there
+// the four older waves wait 24 % of the kernel at the flush barriers for the four younger ones (stamps in profiles/r05_wide_tflush_ab.txt)
+#ifndef RNVP_WIDE_TFLUSH
+#define RNVP_WIDE_TFLUSH 1
+#endif
+constexpr bool kWideTFlush = RNVP_WIDE_TFLUSH != 0;
+constexpr size_t kSyncBytes = 128;                       // LDS behind a workgroup's buffers: 8 tile counters (RNVP_NS_PRIO 3), 5 flush counters, 8 pair flags
+struct FlushSync { int *arr; int *done; int win; };      // arr[2 g + p]: arrivals of net group g (t / s waves) at windows of parity p; done: window shares summed; win: windows this wave finished
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int NF, int CQ> struct Dims {
@@ -263,7 +269,10 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
     constexpr bool SH = kSaveH && NS == 1 && NF == 2 && !BX;       // hidden activations come from the forward's record (hs)
-    constexpr bool TF = kNsTFlush && NS == 1 && FT >= 2 && FT % 2 == 0 && WV == 4;      // t waves flush both nets, no barriers
+    // barrier-free flush by the waves that run ahead: the t waves of a net-split launch (both nets), or -- RNVP_WIDE_TFLUSH -- waves
+    // 0..3 of the eight-wave wide form, the older wave of every SIMD (the net the pass is on; the younger four never wait)
+    constexpr bool TFW = kWideTFlush && NS == 0 && WV == 8 && FT >= 2 && FT % 2 == 0;
+    constexpr bool TF = (kNsTFlush && NS == 1 && FT >= 2 && FT % 2 == 0 && WV == 4) || TFW;
     constexpr int FT2 = FT / 2 > 0 ? FT / 2 : 1;
     const int netblock = HT * TBLK;                       // floats of one net's gradient block
     float *slot = lds + wave * SLOT;
@@ -639,30 +648,45 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     const int w_t0 = (ht / FT2) * FT2, w_n4 = (ht + 1 - w_t0) * TBLK / 4;      // the window's first tile, its f4 count per net
                     const int bufoff = (fs->win & 1) * FT2 * TBLK;
                     lds_drain();                                               // this wave's slot (and db2) writes have landed
-                    if (lane == 0) __hip_atomic_fetch_add(fs->arr + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // arrivals are counted per net group AND window parity: a wave may run a whole window ahead of a slower one, so a
+                    // single running count could reach "everybody arrived" on the fast waves' NEXT window; windows of one parity are
+                    // strictly ordered by the completion check above, which makes the per-parity count exact
+                    const int wpar = fs->win & 1, wneed = (fs->win >> 1) + 1;
+                    if (lane == 0) __hip_atomic_fetch_add(fs->arr + 2 * role + wpar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++fs->win;
                     STAMP_ADD(stp.fb1, t0);
-                    if (role == 0) {
-                        // the t waves flush both nets: wait for the window's arrivals (the s waves are behind: this is the wait the
-                        // flush barrier used to be, minus the s waves' share of it)
-                        while (__hip_atomic_load(fs->arr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * fs->win ||
-                               __hip_atomic_load(fs->arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * fs->win) __builtin_amdgcn_s_sleep(1);
+                    if (TFW ? wave < 4 : role == 0) {
+                        // a workgroup's second and later row groups ADD to its partial: the old values are requested ahead of the wait
+                        f4 oldv[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+                        if (!first && tid < w_n4) {
+#pragma unroll
+                            for (int n2 = 0; n2 < (TFW ? 1 : 2); ++n2)
+                                oldv[n2] = *(reinterpret_cast<const f4 *>(gp_layer + (size_t)(TFW ? net : n2) * netblock + (size_t)w_t0 * TBLK) + tid);
+                        }
+                        // the flushing waves wait for the window's arrivals (the others are behind: this is the wait the flush barrier
+                        // used to be, minus the late waves' share of it)
+                        if constexpr (TFW) {
+                            while (__hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WV * wneed) __builtin_amdgcn_s_sleep(1);
+                        } else {
+                            while (__hip_atomic_load(fs->arr + 2 + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed ||
+                                   __hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed) __builtin_amdgcn_s_sleep(1);
+                        }
                         asm volatile("" ::: "memory");
                         STAMP_ADD(stp.bflush, t0);
-                        static_assert(FT2 * TBLK / 4 <= 256, "one f4 per t-wave thread and net");
+                        static_assert(FT2 * TBLK / 4 <= 256, "one f4 per flushing thread and net");
                         if (tid < w_n4) {
 #pragma unroll
-                            for (int n2 = 0; n2 < 2; ++n2) {
-                                f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)n2 * netblock + (size_t)w_t0 * TBLK) + tid;
-                                const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)n2 * WV * SLOT + bufoff) + tid;
+                            for (int n2 = 0; n2 < (TFW ? 1 : 2); ++n2) {
+                                f4 *dst = reinterpret_cast<f4 *>(gp_layer + (size_t)(TFW ? net : n2) * netblock + (size_t)w_t0 * TBLK) + tid;
+                                const f4 *s0 = reinterpret_cast<const f4 *>(lds + (size_t)(TFW ? 0 : n2 * WV) * SLOT + bufoff) + tid;
                                 f4 v = s0[0];
 #pragma unroll
                                 for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4)];          // slot order: deterministic
-                                *dst = first ? v : v + *dst;
+                                *dst = first ? v : v + oldv[n2];
                             }
                         }
-                        if (last_tile && tid < NT2 * 16) {                    // db2 lives in the s waves' slots
-                            const int i = WV * SLOT + FT * TBLK + tid;
+                        if (last_tile && (!TFW || net == 1) && tid < NT2 * 16) {       // db2: in the slots of the waves that ran net s
+                            const int i = (TFW ? 0 : WV * SLOT) + FT * TBLK + tid;
                             float v = lds[i];
 #pragma unroll
                             for (int w = 1; w < WV; ++w) v += lds[w * SLOT + i];
@@ -847,14 +871,14 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     int *prog = reinterpret_cast<int *>(xbuf + (NS ? 2 * NW * XW : 0));   // NS, RNVP_NS_PRIO 3: one tile counter per wave
     int prog_cnt = 0;
     // RNVP_NS_TFLUSH: arrivals of the t / s waves and summed window shares, behind the tile counters
-    FlushSync fsync{prog + 8, prog + 10, 0};
+    FlushSync fsync{prog + 8, prog + 12, 0};
     // RNVP_SAVE_H: this wave's record of hidden activations: [layer][net][row owner][tile][row tile][lane] f4
     constexpr bool SHB = kSaveH && NS == 1 && NF == 2 && !BX;
     const size_t hs_layer = (size_t)2 * WV * g.HT * R * 256;
     float *hs_wave = SHB ? sd.hsave + (size_t)blockIdx.x * L * hs_layer + ((size_t)role * WV + pw) * g.HT * R * 256 : nullptr;
     PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
-    if constexpr (NS == 1) {
-        if (threadIdx.x < 3) prog[8 + threadIdx.x] = 0;
+    if constexpr (NS == 1 || (kWideTFlush && NS == 0 && WV == 8)) {
+        if (threadIdx.x < 5) prog[8 + threadIdx.x] = 0;
         if (threadIdx.x < NW) prog[16 + threadIdx.x] = 0;
         __syncthreads();
     }
