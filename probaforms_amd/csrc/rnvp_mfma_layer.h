@@ -196,7 +196,7 @@ __device__ __forceinline__ void pair_rendezvous(PairSync &ps, int lane) {
 // (rnvp_mfma_train_dev.h RNVP_SAVE_H); the other tiles are recomputed.  Saving all of them makes the forward phase HBM-write bound
 // at 65 536 rows (537 MB in ~60 us); the count balances the bytes against the matrix cycles they save.
 #ifndef RNVP_SAVE_H_TILES
-#define RNVP_SAVE_H_TILES 2
+#define RNVP_SAVE_H_TILES (1 << 20)
 #endif
 constexpr int kSaveHTiles = RNVP_SAVE_H_TILES;
 

@@ -277,7 +277,8 @@ bool train_supported(const KShape &k) {
 // for at most 256 workgroups (the net-split launches are those with one workgroup per CU or fewer)
 static size_t hsave_bytes(const Geo &g, int L, const TrainPlan &pl, int64_t max_rows) {
     if (!kSaveH || g.NF != 2) return 0;
-    const size_t per_wg_r1 = (size_t)L * 2 * kWaves * g.HT * 256 * sizeof(float);      // one row tile per wave: 64 rows per workgroup
+    const int LS = kSaveHLayers < L ? kSaveHLayers : L;                                  // the layers that keep their activations
+    const size_t per_wg_r1 = (size_t)LS * 2 * kWaves * g.HT * 256 * sizeof(float);     // one row tile per wave: 64 rows per workgroup
     // ceil(n / (64 R)) workgroups of R x per_wg_r1 bytes, whatever R the launch picks, for every n <= max_rows; a net-split launch
     // never has more than 256 workgroups
     const size_t need = (size_t)((max_rows + 63) / 64 + pl.RMAX) * per_wg_r1, cap = (size_t)256 * pl.RMAX * per_wg_r1;

@@ -143,11 +143,18 @@ constexpr bool kBwdReadsFirst = RNVP_BWD_READS_FIRST != 0;
 // Built, parity-green (631 kernel tests), measured (profiles/r05_saveh_ab.txt), OFF: at 65 536 rows saving all eight tiles per net
 // (537 MB written in the ~60 us forward phase) makes the launch 0.357 ms against 0.293 recomputing; saving 1 / 2 / 3 / 4 tiles
 // (RNVP_SAVE_H_TILES; the others recomputed in the same loop) 0.326 / 0.337 / 0.356 / 0.365 -- every count loses; only launches
-// whose record fits the caches gain (16 960 rows: 0.157 vs 0.164).
+// whose record fits the caches gain (16 960 rows: 0.157 vs 0.164); whole layers saved instead (the last 1 / 2 / 3 / 4 of 8,
+// RNVP_SAVE_H_LAYERS: one clean code path per layer) 0.310 / 0.311 / 0.318 / 0.335 against 0.299.
 #ifndef RNVP_SAVE_H
 #define RNVP_SAVE_H 0
 #endif
 constexpr bool kSaveH = RNVP_SAVE_H != 0;
+// RNVP_SAVE_H_LAYERS: only the LAST so many layers keep their activations (whole layers: one code path per layer instance) -- the
+// backward starts with exactly those, moments after the forward wrote them, and the record (1 KB per row and layer) stays cache sized
+#ifndef RNVP_SAVE_H_LAYERS
+#define RNVP_SAVE_H_LAYERS 2
+#endif
+constexpr int kSaveHLayers = RNVP_SAVE_H_LAYERS;
 #ifndef RNVP_NS_TFLUSH
 #define RNVP_NS_TFLUSH 1
 #endif
@@ -240,7 +247,7 @@ __device__ __forceinline__ void load_bwd_pre(const float *__restrict__ W, const 
     for (int m = 0; m < NGI; ++m) p.a1t[m] = *opaque(pA1T + ((size_t)ht_lo * NGI + m) * 256);
 }
 
-template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false, int WV = kWaves>
+template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false, int WV = kWaves, bool SHT = false>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
@@ -268,7 +275,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int ht_lo = TS ? tile_lo : 0, ht_hi = TS ? tile_hi : HT;
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
-    constexpr bool SH = kSaveH && NS == 1 && NF == 2 && !BX;       // hidden activations come from the forward's record (hs)
+    constexpr bool SH = SHT && kSaveH && NS == 1 && NF == 2 && !BX;       // hidden activations come from the forward's record (hs): this LAYER's
     // barrier-free flush by the waves that run ahead: the t waves of a net-split launch (both nets), or -- RNVP_WIDE_TFLUSH -- waves
     // 0..3 of the eight-wave wide form, the older wave of every SIMD (the net the pass is on; the younger four never wait)
     constexpr bool TFW = kWideTFlush && NS == 0 && WV == 8 && FT >= 2 && FT % 2 == 0;
@@ -410,19 +417,17 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         }
         f4 hc[SH ? R : 1], hn[SH ? R : 1];
         if constexpr (SH) {
-            if (ht_lo < kSaveHTiles) {
+            {
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hs + ((size_t)ht_lo * R + rt) * 256 + lane * 4);
             }
         }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
-            const bool sv = SH && ht < kSaveHTiles;            // this tile's activations come from the forward's record
+            constexpr bool sv = SH;                            // the layer's activations come from the forward's record
             if constexpr (SH) {
-                if (nx < kSaveHTiles) {
 #pragma unroll
-                    for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hs + ((size_t)nx * R + rt) * 256 + lane * 4);
-                }
+                for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hs + ((size_t)nx * R + rt) * 256 + lane * 4);
             }
             int prog_mine = 0, prog_other = 0; (void)prog_mine; (void)prog_other;
             if constexpr (NS == 1 && kNsPrio == 2) {
@@ -435,9 +440,15 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 prog_other = reinterpret_cast<volatile int *>(prog)[uw ^ 4];
             }
             f4 na1[NA1], na2t[NA2], na1t[NGI], nb1;
+            if constexpr (!SH) {
 #pragma unroll
-            for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * NA1 + k4) * 256);
-            nb1 = *opaque(pB1 + nx * 16);
+                for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * NA1 + k4) * 256);
+                nb1 = *opaque(pB1 + nx * 16);
+            } else {
+#pragma unroll
+                for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = f4{0.f, 0.f, 0.f, 0.f};
+                nb1 = f4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int o = 0; o < NA2; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * NA2 + o) * 256);
 #pragma unroll
@@ -468,7 +479,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                         for (int u = 0; u < RH; ++u) gh[u] = mfma32(a2t[i], gob[r0 + u][NS ? 0 : net][i], gh[u]);
                 } else {
-                if (!sv) {
+                if constexpr (!sv) {
 #pragma unroll
                 for (int kk = 0; kk < KS1; ++kk)
 #pragma unroll
@@ -501,7 +512,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                 for (int u = 0; u < RH; ++u) {
                     f4 hv;
-                    if (sv) hv = hc[SH ? r0 + u : 0]; else hv = act4<ACT>(acc[u]);
+                    if constexpr (sv) hv = hc[SH ? r0 + u : 0]; else hv = act4<ACT>(acc[u]);
                     gpv[u] = gh[u] * dact4<ACT>(hv);                                     // activation'
                     if (!(kAblate & 1)) {
                         *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
@@ -875,7 +886,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     // RNVP_SAVE_H: this wave's record of hidden activations: [layer][net][row owner][tile][row tile][lane] f4
     constexpr bool SHB = kSaveH && NS == 1 && NF == 2 && !BX;
     const size_t hs_layer = (size_t)2 * WV * g.HT * R * 256;
-    float *hs_wave = SHB ? sd.hsave + (size_t)blockIdx.x * L * hs_layer + ((size_t)role * WV + pw) * g.HT * R * 256 : nullptr;
+    const int sh_l0 = L - (kSaveHLayers < L ? kSaveHLayers : L);        // layers sh_l0 .. L-1 keep their activations
+    float *hs_wave = SHB ? sd.hsave + (size_t)blockIdx.x * (L - sh_l0) * hs_layer + ((size_t)role * WV + pw) * g.HT * R * 256 : nullptr;
     PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
     if constexpr (NS == 1 || (kWideTFlush && NS == 0 && WV == 8)) {
         if (threadIdx.x < 5) prog[8 + threadIdx.x] = 0;
@@ -914,8 +926,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
-                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, (SHB && l >= sh_l0) ? hs_wave + (size_t)(l - sh_l0) * hs_layer : nullptr);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, (SHB && l >= sh_l0) ? hs_wave + (size_t)(l - sh_l0) * hs_layer : nullptr);
             } else {
                 if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
                 else layer_forward<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
@@ -958,8 +970,14 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
             BwdPre<NF, CQ, R> nopre;            // (tile-split kernel only)
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, SHB ? hs_wave + (size_t)l * hs_layer : nullptr);
+            if (SHB && l >= sh_l0) {
+                const float *hsl = hs_wave + (size_t)(l - sh_l0) * hs_layer;
+                if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV, SHB>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, hsl);
+                else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV, SHB>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, hsl);
+            } else {
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
+            }
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
