@@ -265,3 +265,48 @@ def test_kernel_selection_policy_is_host_logic():
     assert _hip.cvae_kernel_path(Cv(10, 5, 10, (700, 700), "relu")) == _hip.PATH_GENERIC
     bad = Cv(4, 2, 3, (7, 9), "relu"); bad.family = 7
     assert _hip.cvae_kernel_path(bad) not in (_hip.PATH_MFMA, _hip.PATH_LMM, _hip.PATH_GENERIC)       # RNVP_EINVAL
+
+
+def test_permutation_prefetcher_host_only_keeps_what_was_submitted_and_close_drops_the_rest():
+    """ADVICE round 4 (low / medium): host_only() must not throw away futures start() already submitted, and close() leaves nothing
+    behind; the permutations are the serial DataLoader's whichever path produced them"""
+    n, epochs = 70_000, 5
+    torch.manual_seed(17)
+    want = [_engine.loader_permutation(n) for _ in range(epochs)]
+    torch.manual_seed(17)
+    pf = _engine.PermutationPrefetcher(n, epochs, workers=2, lookahead=1, device=None).start()
+    submitted = dict(pf.futs)
+    assert submitted and pf.dev_epochs == 0
+    pf.host_only()
+    assert all(pf.futs.get(e) is f for e, f in submitted.items())            # the same future objects: nothing resubmitted
+    got = [pf.get(e) for e in range(epochs)]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    pf.close()
+    assert not pf.futs and not pf._early and pf._ws is None
+
+
+def test_library_write_counts_die_with_their_storage():
+    """the per-storage count of the library's raw-pointer writes must not outlive the storage (a later
+    allocation at the same address would inherit it: a false "parameters modified")"""
+    import gc
+    t = torch.zeros(1024)
+    key = t.untyped_storage().data_ptr()
+    _engine.note_param_write(t); _engine.note_param_write(t)
+    assert _engine._STORAGE_WRITES[key] == 2
+    p = torch.nn.Parameter(t)
+    assert _engine.param_state([p])[0][2] == 2
+    del p, t
+    gc.collect()
+    assert key not in _engine._STORAGE_WRITES and key not in _engine._STORAGE_WATCHED
+
+
+def test_bench_batch_geometry_of_both_regimes():
+    """bench.py's two batch regimes: the per-rank share of every global batch tiles the rank's rows exactly"""
+    rows, world = 1_000_000, 8
+    for gbatch, rank_batch, nb in ((65_536, 8_192, 123), (65_536 * world, 65_536, 16)):
+        gb = _engine.batch_bounds(rows * world, gbatch)
+        assert len(gb) == nb
+        for rank in range(world):
+            shares = [_engine.shard_bounds(s, e, rank, world) for (s, e) in gb]
+            assert shares[0][1] - shares[0][0] == rank_batch
+            assert sum(hi - lo for lo, hi in shares) == rows
