@@ -350,7 +350,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
                                           const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           f4 (&out)[R][FwdDims<NF, CQ>::NT2],
                                           const f4 (*bin)[SplitDims<NF, CQ>::NI1] = nullptr,
-                                          const TilePre<NF, CQ> *pre = nullptr) {
+                                          const TilePre<NF, CQ> *pre = nullptr, float *hs = nullptr) {
     using D = FwdDims<NF, CQ>;
     constexpr int K4 = G1Dims<NF, CQ, BX>::NA, OTL = D::OTL;
     const int q = lane >> 4;
@@ -429,6 +429,10 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
             for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (hs && t < kSaveHTiles) {                   // (training: the backward reads the activations back, see run_tiles_x4)
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)t * R + rt) * 256 + lane * 4) = hv[rt];
+        }
         gemm2(c, hv);                                  // phase B
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -436,6 +440,10 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
         f4 hv[R];
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(c.acc[rt]);
+        if (hs && last < kSaveHTiles) {
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)last * R + rt) * 256 + lane * 4) = hv[rt];
+        }
         gemm2(c, hv);
     };
     int t = 0;
@@ -735,7 +743,7 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
                                                  int nt, float *red, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
                                                  float *__restrict__ scr, const float *__restrict__ Wnext,
-                                                 TilePre<NF, CQ> &pre, bool use_pre) {
+                                                 TilePre<NF, CQ> &pre, bool use_pre, float *hs = nullptr) {
     // pre: this layer's opening fragments, loaded by the caller / the previous layer; Wnext (nullable): the layer that
     // follows in this pass -- its opening fragments are requested here, before the rendezvous
     using D = FwdDims<NF, CQ>;
@@ -762,8 +770,8 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (nt > 0) {
-            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr);
-            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr);
+            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr, hs);
+            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr, hs);
             if (use_pre && Wnext) load_tile_pre<NF, CQ>(Wnext, g, lane, net * g.HT + tile0, nt, pre);
         }
 #pragma unroll
@@ -782,8 +790,8 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = f4{0.f, 0.f, 0.f, 0.f};
         if (nt > 0) {
-            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr);
-            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr);
+            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr, hs);
+            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr, hs);
             if (use_pre && Wnext) load_tile_pre<NF, CQ>(Wnext, g, lane, net * g.HT + tile0, nt, pre);
         }
 #pragma unroll

@@ -276,13 +276,24 @@ bool train_supported(const KShape &k) {
 // workgroup L x 2 nets x 4 row owners x HT tiles x R row tiles of 1 KiB -- 4 h L bytes per row and net (8 KB per row for C2),
 // for at most 256 workgroups (the net-split launches are those with one workgroup per CU or fewer)
 static size_t hsave_bytes(const Geo &g, int L, const TrainPlan &pl, int64_t max_rows) {
-    if (!kSaveH || g.NF != 2) return 0;
-    const int LS = kSaveHLayers < L ? kSaveHLayers : L;                                  // the layers that keep their activations
-    const size_t per_wg_r1 = (size_t)LS * 2 * kWaves * g.HT * 256 * sizeof(float);     // one row tile per wave: 64 rows per workgroup
-    // ceil(n / (64 R)) workgroups of R x per_wg_r1 bytes, whatever R the launch picks, for every n <= max_rows; a net-split launch
-    // never has more than 256 workgroups
-    const size_t need = (size_t)((max_rows + 63) / 64 + pl.RMAX) * per_wg_r1, cap = (size_t)256 * pl.RMAX * per_wg_r1;
-    return align_up(need < cap ? need : cap, 256);
+    size_t need = 0;
+    if (kSaveH && g.NF == 2) {
+        const int LS = kSaveHLayers < L ? kSaveHLayers : L;                                  // the layers that keep their activations
+        const size_t per_wg_r1 = (size_t)LS * 2 * kWaves * g.HT * 256 * sizeof(float);     // one row tile per wave: 64 rows per workgroup
+        // ceil(n / (64 R)) workgroups of R x per_wg_r1 bytes, whatever R the launch picks, for every n <= max_rows; a net-split launch
+        // never has more than 256 workgroups
+        const size_t a = (size_t)((max_rows + 63) / 64 + pl.RMAX) * per_wg_r1, cap = (size_t)256 * pl.RMAX * per_wg_r1;
+        need = a < cap ? a : cap;
+    }
+    if (kTsSaveH) {
+        // tile-split step (RNVP_TS_SAVE_H): a workgroup of 16 R rows keeps, per wave, its ceil(HT / 4) tiles of every layer: 1 KiB
+        // per tile and row tile -- 4 h L bytes per row and net; at most ts_max_rows rows ever run there
+        const int tps = (g.HT + kTsSlices - 1) / kTsSlices;
+        const int64_t rows = max_rows < ts_max_rows(g) ? max_rows : ts_max_rows(g);
+        const size_t b = (size_t)((rows + 15) / 16 + 2) * kTsWaves * L * tps * 256 * sizeof(float);
+        if (b > need) need = b;
+    }
+    return align_up(need, 256);
 }
 
 size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {

@@ -155,6 +155,16 @@ constexpr bool kSaveH = RNVP_SAVE_H != 0;
 #define RNVP_SAVE_H_LAYERS 2
 #endif
 constexpr int kSaveHLayers = RNVP_SAVE_H_LAYERS;
+// RNVP_TS_SAVE_H: the tile-split step (batches of at most 8 192 rows: latency chains, records that stay in the caches) keeps ALL its
+// hidden activations -- each wave the tiles it owns -- and its backward drops GEMM1 + activation from every tile step's dependent chain.
+// Built, parity-green (694 tests), measured (profiles/r05_ts_saveh_ab.txt), OFF: it pays where the record is tiny and the net wide
+// (32 / 1 024 rows: C3 -9 % / -10 %, C4 -6 % / -8 %, C2 0 / -2 %) and loses from 4 096 rows on (C3 +9 %, C2 +1.5 %; 8 192 rows: C2 +3 %,
+// C3 +1.5 %) -- the BASELINE sizes that run this kernel (C2 at the reference's batch 32, the 8 192-row shards of the 8-GPU regime) gain
+// nothing, so the second set of kernel instances a per-size switch would need is not worth its build time.
+#ifndef RNVP_TS_SAVE_H
+#define RNVP_TS_SAVE_H 0
+#endif
+constexpr bool kTsSaveH = RNVP_TS_SAVE_H != 0;
 #ifndef RNVP_NS_TFLUSH
 #define RNVP_NS_TFLUSH 1
 #endif
@@ -275,7 +285,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int ht_lo = TS ? tile_lo : 0, ht_hi = TS ? tile_hi : HT;
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
-    constexpr bool SH = SHT && kSaveH && NS == 1 && NF == 2 && !BX;       // hidden activations come from the forward's record (hs): this LAYER's
+    constexpr bool SH = SHT && !BX;       // this layer's hidden activations come from the forward's record (hs), not from a recompute
     // barrier-free flush by the waves that run ahead: the t waves of a net-split launch (both nets), or -- RNVP_WIDE_TFLUSH -- waves
     // 0..3 of the eight-wave wide form, the older wave of every SIMD (the net the pass is on; the younger four never wait)
     constexpr bool TFW = kWideTFlush && NS == 0 && WV == 8 && FT >= 2 && FT % 2 == 0;
@@ -419,7 +429,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         if constexpr (SH) {
             {
 #pragma unroll
-                for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hs + ((size_t)ht_lo * R + rt) * 256 + lane * 4);
+                for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hs + (size_t)rt * 256 + lane * 4);
             }
         }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
@@ -427,7 +437,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
             constexpr bool sv = SH;                            // the layer's activations come from the forward's record
             if constexpr (SH) {
 #pragma unroll
-                for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hs + ((size_t)nx * R + rt) * 256 + lane * 4);
+                for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hs + ((size_t)(nx - ht_lo) * R + rt) * 256 + lane * 4);
             }
             int prog_mine = 0, prog_other = 0; (void)prog_mine; (void)prog_other;
             if constexpr (NS == 1 && kNsPrio == 2) {
@@ -1102,13 +1112,17 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
     constexpr bool PRE = NF <= 4;
     TilePre<NF, CQ> pre;
     if (PRE && tile_hi > tile_lo) load_tile_pre<NF, CQ>(wp, g, lane, (wave >> 2) * g.HT + tile_lo, tile_hi - tile_lo, pre);
+    // RNVP_TS_SAVE_H: this wave's record [layer][its tiles][row tile][lane] f4
+    const size_t hs_layer = (size_t)tps * R * 256;
+    float *hs_wave = (kTsSaveH && sd.hsave) ? sd.hsave + ((size_t)blockIdx.x * kTsWaves + wave) * L * hs_layer : nullptr;
     for (int l = 0; l < L; ++l) {
         const float *W = wp + (size_t)l * g.layer_floats;
         const float *Wn = l + 1 < L ? W + g.layer_floats : nullptr;
         float *scr = scratch + (size_t)l * R * 2 * NF * 64;
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
-        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE);
-        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE);
+        float *hsl = kTsSaveH ? hs_wave + (size_t)l * hs_layer : nullptr;
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE, hsl);
+        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE, hsl);
     }
     __syncthreads();        // wave 0's scratch records; the rendezvous buffers change hands
     float wave_sum = 0.f;
@@ -1150,8 +1164,9 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
         const float *Wp = l > 0 ? W - g.layer_floats : nullptr;
         const float *sp = l > 0 ? scr - (size_t)R * 2 * NF * 64 : nullptr;
-        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp);
-        else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp);
+        const float *hsl = kTsSaveH ? hs_wave + (size_t)l * hs_layer : nullptr;
+        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT, false, kWaves, kTsSaveH>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp, nullptr, nullptr, nullptr, nullptr, hsl);
+        else layer_bwd<NF, CQ, R, 0, 2, ACT, false, kWaves, kTsSaveH>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp, nullptr, nullptr, nullptr, nullptr, hsl);
     }
     if (sd.gx && wave == 0) {                   // rnvp_backward: d loss / d x (every wave holds the same sums)
         const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
