@@ -367,11 +367,12 @@ class NormalizingFlow(nn.Module):
             Cd = C.to(dev, torch.float32).contiguous() if on_dev else None
             Cn = None if on_dev else (C.detach().numpy() if torch.is_tensor(C) else np.asarray(C))
         rows = self.pipelined_rows(n)
-        if rows and Cn is not None and Cn.dtype == np.float32 and Cn.flags.c_contiguous:
-            # float32 conditions need no cast: ONE pageable upload through the runtime's own staging (tens of GB/s on these hosts)
-            # instead of a single-threaded numpy copy into pinned memory per chunk -- that copy, not the GPU, bounded the call
-            # (16 MB of conditions: 1.6 ms of host time against 1.1 ms of kernels for sample(1M) at C2)
-            Cd = torch.from_numpy(Cn).to(dev)
+        if rows and Cn is not None and Cn.dtype.kind in "fiub" and Cn.flags.c_contiguous:
+            # ONE pageable upload through the runtime's own staging (tens of GB/s on these hosts) and the float32 cast ON THE DEVICE
+            # (the same round-to-nearest as the host cast; what RealNVP.fit does with X and C) instead of a single-threaded numpy
+            # copy / cast into pinned memory per chunk -- that copy, not the GPU, bounded the call (16 MB of float32 conditions:
+            # 1.6 ms of host time against 1.1 ms of kernels for sample(1M) at C2; float64 input twice that)
+            Cd = torch.from_numpy(Cn).to(dev).to(torch.float32)
             Cn = None
         if rows == 0:
             if Cn is not None:
