@@ -790,9 +790,40 @@ def main():
         elif not replicas_identical:
             dp_failure = "the ranks' parameters / last loss differ after the timed region"
     n_train, train_ms, n_inv, inv_ms = prof["n_train"], prof["train_ms"], prof["n_inv"], prof["inv_ms"]
+    disp_last_timed = _hip.last_dispatch(_hip.PROFILE_TRAIN) if do_fit else None     # (read before the secondary regime below launches anything)
+    # N > 1, default regime: the OTHER regime -- the reference's one global batch_size of 65 536 shared out over the ranks (SURVEY.md
+    # 8(d)/(e)) -- is timed as well, after the clock stopped and outside `value`: a few fit epochs of N x 16 steps on the same
+    # resident rows, so that one scaling run yields both curves
+    other_regime = None
+    if world > 1 and do_fit and batch_mode == "per_rank":
+        g2 = BATCH
+        gb2 = _engine.batch_bounds(N_ROWS * world, g2)
+        sh2 = [_engine.shard_bounds(s, e, rank, world) for (s, e) in gb2]
+        take2 = min(sum(hi - lo for lo, hi in sh2), N_ROWS)
+        pos2 = torch.cat([torch.arange(lo, hi, device=dev) for lo, hi in sh2])[:take2]
+        pg2 = torch.zeros(N_ROWS * world, dtype=torch.int64, device=dev)
+        pg2[pos2] = torch.randperm(N_ROWS, device=dev)[:take2]
+        losses2 = torch.zeros(len(gb2), device=dev)
+        k2 = max(1, min(3, args.steps))
+        _hip.profile_read(_hip.PROFILE_TRAIN)
+        _engine.run_epoch(eng, opt, comm, X, C, pg2, gb2, g2, rank, world, losses2)           # warm-up (workspace for the new batch size)
+        torch.cuda.synchronize(); dist.barrier()
+        _hip.profile_read(_hip.PROFILE_TRAIN)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            _engine.run_epoch(eng, opt, comm, X, C, pg2, gb2, g2, rank, world, losses2)
+        torch.cuda.synchronize(); dist.barrier()
+        t2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        nk2, ms2 = _hip.profile_read(_hip.PROFILE_TRAIN)
+        other_regime = {"regime": "global batch %d shared out over %d ranks (%d rows per rank and step), fit epochs only, after the timed region"
+                                  % (g2, world, sh2[0][1] - sh2[0][0]),
+                        "steps_per_epoch": len(gb2), "epochs_timed": k2, "ms_per_fit_epoch": float(t2.item()) / k2 * 1e3,
+                        "us_per_step": float(t2.item()) / k2 / len(gb2) * 1e6, "fit_rows_per_s": N_ROWS * world * k2 / float(t2.item()),
+                        "training_kernel_us": ms2 / max(nk2, 1) * 1e3, "final_loss": float(losses2[-1].item())}
     # what the library launched for the timed region's last batch / sampling call (rnvp_last_dispatch: written by the launch
     # sites themselves): the kernel names, variants and arithmetic below are the library's statement, not a copy of its rules
-    disp_train = _hip.last_dispatch(_hip.PROFILE_TRAIN) if do_fit else None          # the epoch's LAST batch: the ragged one
+    disp_train = disp_last_timed                                                       # the epoch's LAST batch: the ragged one
     disp_inv = _hip.last_dispatch(_hip.PROFILE_INVERSE) if do_sample else None
     if do_fit:
         # ... so the dispatch of a FULL batch is read from one more, untimed, gradient call of that size (same launch rules;
@@ -897,7 +928,7 @@ def main():
                        "global_batch": gbatch if do_fit else None, "rank_batch": rank_batch if do_fit else None,
                        "batch_mode": ("global batch fixed (--global-batch): the reference's one batch_size shared out over the ranks"
                                       if batch_mode == "global" else "per-rank batch fixed (default): the global batch grows with N"),
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "global_batch_65536_regime": other_regime,
                        "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
                        "kernel_path": "mfma" if path == _hip.PATH_MFMA else "generic", "final_loss": final_loss},
             "roofline": roof,

@@ -94,6 +94,8 @@ def test_bench_self_launches_two_ranks_and_prints_one_json_line():
     assert j["config"]["global_batch"] == 2 * 65536 and j["roofline"]["frac"] > 0
     assert len(j["roofline_kernels"]) >= 2 and all(v["frac"] > 0 for v in j["roofline_kernels"].values())
     assert j["config"]["rank_batch"] == 65536 and j["config"]["replicas_identical"] is True and j["timed_blocks"] >= 1
+    o = j["config"]["global_batch_65536_regime"]            # the other regime is timed too, outside `value`
+    assert o["steps_per_epoch"] == 31 and o["ms_per_fit_epoch"] > 0 and np.isfinite(o["final_loss"])
 
 
 @pytest.mark.timeout(900)
