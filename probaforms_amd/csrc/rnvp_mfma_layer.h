@@ -179,13 +179,27 @@ constexpr int kTS = 20;                  // row stride (floats) of a 16-wide LDS
 #define RNVP_NS_PAIRSYNC 0
 #endif
 constexpr bool kNsPairSync = RNVP_NS_PAIRSYNC != 0;
-struct PairSync { int *own; const int *other; int seq; };
+// Every spin on an LDS counter is bounded: a wait that outlives 2^22 naps (seconds; the longest legitimate one is a few
+// microseconds) is a protocol error.  The wave then poisons the workgroup's loss partial with a NaN -- the step's loss comes out
+// NaN, which every caller notices -- and ENDS instead of hanging the device.  (`__builtin_trap()` there cost the C2 kernel 2.5 % and
+// the wide C3 kernel 6.5 % of its time through register allocation alone; `s_endpgm` costs nothing: profiles/r05_spin_bound_ab.txt.)
+struct Poison { float *loss; int *flag; };          // this workgroup's loss partials (global) and its LDS error flag
+__device__ __forceinline__ void spin_nap(int &spins, const Poison &po) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) {
+        if (po.flag) __hip_atomic_store(po.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // waves that still finish write NaN too
+        if (po.loss) *po.loss = __builtin_nanf("");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_endpgm" ::: "memory");
+    }
+}
+struct PairSync { int *own; const int *other; int seq; Poison poison; };
 __device__ __forceinline__ void pair_rendezvous(PairSync &ps, int lane) {
     if constexpr (kNsPairSync) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's record has landed in LDS
         ++ps.seq;
         if (lane == 0) __hip_atomic_store(ps.own, ps.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(ps.other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.seq) { }
+        int spins = 0;
+        while (__hip_atomic_load(ps.other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.seq) spin_nap(spins, ps.poison);
         asm volatile("" ::: "memory");
     } else {
         __syncthreads();

@@ -176,7 +176,7 @@ constexpr bool kNsTFlush = RNVP_NS_TFLUSH != 0;
 #endif
 constexpr bool kWideTFlush = RNVP_WIDE_TFLUSH != 0;
 constexpr size_t kSyncBytes = 128;                       // LDS behind a workgroup's buffers: 8 tile counters (RNVP_NS_PRIO 3), 5 flush counters, 8 pair flags
-struct FlushSync { int *arr; int *done; int win; };      // arr[2 g + p]: arrivals of net group g (t / s waves) at windows of parity p; done: window shares summed; win: windows this wave finished
+struct FlushSync { int *arr; int *done; int win; Poison poison; };      // arr[2 g + p]: arrivals of net group g (t / s waves) at windows of parity p; done: window shares summed; win: windows this wave finished
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int NF, int CQ> struct Dims {
@@ -621,7 +621,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     // window = FT / 2 tiles in buffer (window number & 1); its first tile: the sum of the window two back must
                     // have read this buffer (four t-wave shares per window)
                     if (ht % FT2 == 0 && fs->win >= 2) {
-                        while (__hip_atomic_load(fs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (fs->win - 1)) __builtin_amdgcn_s_sleep(1);
+                        int spins = 0;
+                        while (__hip_atomic_load(fs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (fs->win - 1)) spin_nap(spins, fs->poison);
                         asm volatile("" ::: "memory");
                     }
                     spos = (fs->win & 1) * FT2 + ht % FT2;
@@ -673,6 +674,9 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     // single running count could reach "everybody arrived" on the fast waves' NEXT window; windows of one parity are
                     // strictly ordered by the completion check above, which makes the per-parity count exact
                     const int wpar = fs->win & 1, wneed = (fs->win >> 1) + 1;
+#ifdef RNVP_SPIN_TEST      // developer build: wave 5 of workgroup 0 "forgets" one arrival -> the flushing waves' bounded wait must end the kernel
+                    if (!(blockIdx.x == 0 && wave == 5 && fs->win == 3))
+#endif
                     if (lane == 0) __hip_atomic_fetch_add(fs->arr + 2 * role + wpar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++fs->win;
                     STAMP_ADD(stp.fb1, t0);
@@ -686,11 +690,12 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         }
                         // the flushing waves wait for the window's arrivals (the others are behind: this is the wait the flush barrier
                         // used to be, minus the late waves' share of it)
+                        int spins = 0;
                         if constexpr (TFW) {
-                            while (__hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WV * wneed) __builtin_amdgcn_s_sleep(1);
+                            while (__hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WV * wneed) spin_nap(spins, fs->poison);
                         } else {
                             while (__hip_atomic_load(fs->arr + 2 + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed ||
-                                   __hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed) __builtin_amdgcn_s_sleep(1);
+                                   __hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed) spin_nap(spins, fs->poison);
                         }
                         asm volatile("" ::: "memory");
                         STAMP_ADD(stp.bflush, t0);
@@ -892,15 +897,16 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     int *prog = reinterpret_cast<int *>(xbuf + (NS ? 2 * NW * XW : 0));   // NS, RNVP_NS_PRIO 3: one tile counter per wave
     int prog_cnt = 0;
     // RNVP_NS_TFLUSH: arrivals of the t / s waves and summed window shares, behind the tile counters
-    FlushSync fsync{prog + 8, prog + 12, 0};
+    const Poison poison{losspart + (size_t)blockIdx.x * kWaves, prog + 13};      // (bounded spins: rnvp_mfma_layer.h spin_nap)
+    FlushSync fsync{prog + 8, prog + 12, 0, poison};
     // RNVP_SAVE_H: this wave's record of hidden activations: [layer][net][row owner][tile][row tile][lane] f4
     constexpr bool SHB = kSaveH && NS == 1 && NF == 2 && !BX;
     const size_t hs_layer = (size_t)2 * WV * g.HT * R * 256;
     const int sh_l0 = L - (kSaveHLayers < L ? kSaveHLayers : L);        // layers sh_l0 .. L-1 keep their activations
     float *hs_wave = SHB ? sd.hsave + (size_t)blockIdx.x * (L - sh_l0) * hs_layer + ((size_t)role * WV + pw) * g.HT * R * 256 : nullptr;
-    PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
+    PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0, poison};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
     if constexpr (NS == 1 || (kWideTFlush && NS == 0 && WV == 8)) {
-        if (threadIdx.x < 5) prog[8 + threadIdx.x] = 0;
+        if (threadIdx.x < 6) prog[8 + threadIdx.x] = 0;
         if (threadIdx.x < NW) prog[16 + threadIdx.x] = 0;
         __syncthreads();
     }
@@ -991,6 +997,9 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
+    }
+    if constexpr (NS == 1 || (kWideTFlush && NS == 0 && WV == 8)) {       // a wave of this workgroup gave up a bounded wait: the loss says so
+        if (__hip_atomic_load(prog + 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) wave_sum = __builtin_nanf("");
     }
     if constexpr (WV > kWaves) {        // k_mfma_reduce adds kWaves loss partials per workgroup: fold the owners' sums, fixed order
         __syncthreads();
