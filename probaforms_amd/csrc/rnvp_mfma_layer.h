@@ -184,12 +184,9 @@ constexpr bool kNsPairSync = RNVP_NS_PAIRSYNC != 0;
 // NaN, which every caller notices -- and ENDS instead of hanging the device.  (`__builtin_trap()` there cost the C2 kernel 2.5 % and
 // the wide C3 kernel 6.5 % of its time through register allocation alone; `s_endpgm` costs nothing: profiles/r05_spin_bound_ab.txt.)
 struct Poison { float *loss; int *flag; };          // this workgroup's loss partials (global) and its LDS error flag
-#ifndef RNVP_SPIN_BOUND
-#define RNVP_SPIN_BOUND 1
-#endif
 __device__ __forceinline__ void spin_nap(int &spins, const Poison &po) {
     __builtin_amdgcn_s_sleep(1);
-    if (RNVP_SPIN_BOUND && ++spins > (1 << 22)) {
+    if (++spins > (1 << 22)) {
         if (po.flag) __hip_atomic_store(po.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // waves that still finish write NaN too
         if (po.loss) *po.loss = __builtin_nanf("");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_endpgm" ::: "memory");
