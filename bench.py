@@ -14,6 +14,14 @@ its own 1M rows (weak scaling): per batch each rank computes the gradient of its
 global batch of N x 65 536, the flat [gradient | loss] buffer is all-reduced over RCCL, every rank applies
 the same Adam step; sampling shards the global N x 1M rows with no collective.
 
+Batch regimes with N > 1: by default every rank's share of a step stays 65 536 rows (--per-rank-batch; the global batch grows with N);
+--global-batch 65536 shares the reference's ONE batch_size (realnvp.py:237; SURVEY.md 8(d)/(e)'s headline) out over the ranks -- 8 192 rows
+per rank at 8 GPUs.  A default run with N > 1 also times the global-batch regime after the timed region
+(config.global_batch_65536_regime), and exits with code 3 (line still printed, with "error") if the library's RCCL communicator
+does not span all ranks or the replicas' parameters differ afterwards.
+Timing: exactly --steps steps between barrier + synchronize form a block; when a block is shorter than a second it is repeated up to
+about one second and the MEDIAN block is reported (timed_blocks, block_seconds).
+
 With --gpus N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks (child processes
 of `python -m torch.distributed.run`; nothing in the parent touches the GPU) and relays their output.
 
@@ -24,7 +32,8 @@ of `python -m torch.distributed.run`; nothing in the parent touches the GPU) and
   cpu_baseline    -- the reference's CPU path (oracle/torch_cpu.py: eager PyTorch CPU ops in the reference's order,
                      validated against the reference in the build container) on the host cores of rank 0's box, on a
                      bounded sample of the same workload; cpu_baseline_c_oracle: the scalar C oracle on all cores;
-  api_level       -- numpy in -> numpy out rates of RealNVP.fit / .sample on the same data (N = 1 only);
+  api_level       -- numpy in -> numpy out rates of RealNVP.fit / .sample on the same data (N = 1 only); combined_rows_per_s = one fit
+                     epoch + one sample(1M) with the REFERENCE-EXACT prior stream: the number to read beside `value`;
   logprob_mae     -- second half of the metric: per-row log-prob of the HIP path against the oracle;
   secondary_configs -- measured after the timed region, never `value` (N = 1, workload c2 only): the CVAE of configs[4], the C2 flow at
                      the reference's default batch size, the reference's default networks, the C2 arrays through a flow with two
