@@ -20,7 +20,7 @@ per rank at 8 GPUs.  A default run with N > 1 also times the global-batch regime
 (config.global_batch_65536_regime), and exits with code 3 (line still printed, with "error") if the library's RCCL communicator
 does not span all ranks or the replicas' parameters differ afterwards.
 Timing: exactly --steps steps between barrier + synchronize form a block; when a block is shorter than a second it is repeated up to
-about one second and the MEDIAN block is reported (timed_blocks, block_seconds).
+about six seconds (the driver's GPU-busy sampler has a ~5 s period) and the MEDIAN block is reported (timed_blocks, block_seconds).
 
 With --gpus N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks (child processes
 of `python -m torch.distributed.run`; nothing in the parent touches the GPU) and relays their output.
@@ -745,7 +745,8 @@ def main():
     torch.cuda.synchronize()
     # HIP events around the hot kernels, recorded by the library on the stream it launches on, for every
     # launch of the timed region
-    MAX_BLOCKS = 64
+    MAX_BLOCKS = 512
+    TIMED_SECONDS = 6.0                                     # of GPU work between the first and the last clock reading (the driver's GPU-busy sampler has a ~5 s period)
     _hip.profile_enable(args.steps * (nb + 1) + 8)          # one block's launches; read (and reset) after every block
     prof = {"n_train": 0, "train_ms": 0.0, "n_inv": 0, "inv_ms": 0.0}
 
@@ -767,11 +768,11 @@ def main():
         a, b = _hip.profile_read(_hip.PROFILE_INVERSE); prof["n_inv"] += a; prof["inv_ms"] += b
         return float(t.item())
 
-    # A block of --steps steps can be far shorter than a second (20 steps of C2 = 0.11 s): the block is then repeated until about
-    # one second of GPU work has been timed and the MEDIAN block is reported (`steps` stays as passed, `timed_blocks` says how
-    # many).  Every rank derives the count from the same max-reduced first block.
+    # A block of --steps steps can be far shorter than the driver can see (20 steps of C2 = 0.11 s): the block is then repeated until
+    # about TIMED_SECONDS of GPU work have been timed and the MEDIAN block is reported (`steps` stays as passed, `timed_blocks` says
+    # how many).  Every rank derives the count from the same max-reduced first block.
     block_s = [timed_block()]
-    n_blocks = max(1, min(MAX_BLOCKS, int(np.ceil(1.0 / max(block_s[0], 1e-6)))))
+    n_blocks = max(1, min(MAX_BLOCKS, int(np.ceil(TIMED_SECONDS / max(block_s[0], 1e-6)))))
     for _ in range(n_blocks - 1):
         block_s.append(timed_block())
     dt = float(np.median(block_s))
@@ -963,19 +964,36 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Xh, Ch)
             if args.workload == "c2":
                 out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(Xh, Ch, params)
-            # second half of BASELINE.json's metric: per-row log-prob MAE of the HIP path against the
-            # CPU restatement of the reference (float32 oracle, and its float64 referee) on the
-            # trained weights, 4096 rows
-            from oracle import Oracle, Shape
-            rows = 4096
-            lp = nf.log_prob_samples(X[:rows], C[:rows]).detach().cpu().numpy()
-            sh = Shape.make(LAYERS, D, CDIM, HIDDEN, "tanh")
-            _, lp32, _ = Oracle(32).log_prob(sh, params, Xh[:rows], Ch[:rows])
-            _, lp64, _ = Oracle(64).log_prob(sh, params, Xh[:rows], Ch[:rows])
-            out["logprob_mae"] = {"vs_oracle_f32": float(np.abs(lp - lp32).mean()),
-                                  "vs_oracle_f64": float(np.abs(lp - lp64).mean()),
-                                  "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
-                                  "target": 1e-5}
+        # second half of BASELINE.json's metric (every workload, whatever else is switched off): per-row log-prob MAE of
+        # the HIP path against the CPU restatement of the reference (float32 oracle, and its float64 referee) on the
+        # weights the run ends with (trained where the workload fits, the random init for c4), 4096 rows
+        from oracle import Oracle, Shape
+        rows = 4096
+        lp = nf.log_prob_samples(X[:rows], C[:rows]).detach().cpu().numpy()
+        sh = Shape.make(LAYERS, D, CDIM, HIDDEN, "tanh")
+        _, lp32, _ = Oracle(32).log_prob(sh, params, Xh[:rows], Ch[:rows])
+        _, lp64, _ = Oracle(64).log_prob(sh, params, Xh[:rows], Ch[:rows])
+        out["logprob_mae"] = {"vs_oracle_f32": float(np.abs(lp - lp32).mean()),
+                              "vs_oracle_f64": float(np.abs(lp - lp64).mean()),
+                              "oracle_f32_vs_f64": float(np.abs(lp32 - lp64).mean()), "rows": rows,
+                              "mean_abs_logp": float(np.abs(lp64).mean()),
+                              # north_star: 1e-5.  For the d >= 32 shapes |log p| runs to several hundred, one float32 ulp there is
+                              # 3e-5 ... 6e-5, and the float32 oracle ITSELF sits 1.2e-5 from its float64 referee (oracle_f32_vs_f64):
+                              # the tests' bar for those shapes is 3e-5 AND no further from float64 than 3x the reference's own distance
+                              "target": 1e-5 if args.workload == "c2" else 3e-5}
+        # the two batch regimes, where nobody can miss them: `value` is measured in `batch_regime`; the other one is reported beside
+        # it (N > 1: timed after the clock stopped; N = 1: what ONE rank of an 8-GPU job executes per step, secondary_configs)
+        out["batch_regime"] = ("weak batch: %d rows per rank and step, the global batch grows with N" % rank_batch if batch_mode == "per_rank"
+                               else "strong batch: the reference's ONE global batch of %d rows shared out over the %d ranks" % (gbatch, world)) if do_fit else None
+        if other_regime is not None:
+            out["strong_batch_regime_global_65536"] = other_regime
+        d8 = out.get("secondary_configs", {}).get("dp8_rank_steps")
+        if d8:
+            out["strong_batch_8gpu_projection"] = {
+                "eight_rank_steps_over_one_gpu_step": {k: v["eight_rank_steps_over_one_gpu_step"] for k, v in d8.items() if isinstance(v, dict)},
+                "note": "global batch 65536 over 8 ranks = 8192 rows per rank: 8 x (rows/s of one rank's step, measured on this GPU through "
+                        "rnvp_fit_epoch_dp on a one-rank RCCL communicator) / (rows/s of the one-GPU 65536-row step); the cross-GPU all-reduce "
+                        "latency comes on top -- north_star's >= 6x is NOT projected in this regime, the weak-batch regime keeps the one-GPU step"}
         if dp_failure:
             out["error"] = dp_failure
         os.write(json_fd, (json.dumps(out) + "\n").encode())

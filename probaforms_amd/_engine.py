@@ -633,7 +633,11 @@ def _cond_workspace(engine, rows):
     if nb == 0:
         raise RuntimeError("the gradient with respect to the conditions and the backward through g / sample run on the "
                            "any-shape 16-row kernel, whose LDS tile image (76 KB) this flow's hidden sizes exceed")
-    return torch.empty(nb, dtype=torch.uint8, device=engine.device)
+    # kept on the engine like the other operations' workspaces (grown, never shrunk): a user's training loop calls this every step
+    ws = getattr(engine, "_ws_cond", None)
+    if ws is None:
+        ws = engine._ws_cond = _Workspace(engine.device)
+    return ws.get(nb)
 
 
 def _split_param_grads(eng, gflat, needs, first):
@@ -856,6 +860,23 @@ def run_epoch(engine, opt, comm, X, C, perm, bounds, batch_size, rank, world, lo
         engine.finish_dp_step(opt, losses[k:k + 1])
 
 
+PROTOCOL_NAN_BITS = 0x7fc0dead       # csrc/rnvp_mfma_layer.h kProtocolNaN
+
+
+def check_losses(host):
+    """Raise if a batch loss is the library's protocol-error NaN: a wave of the training kernel gave up a bounded wait
+    (csrc/rnvp_mfma_layer.h spin_nap).  The step's finish kernel then applied no Adam update -- the parameters hold their
+    last good values -- and wrote this payload instead of a loss.  A NaN that training itself produced (a diverged fit)
+    passes through, as it does in the reference."""
+    if host.numel() and bool(torch.isnan(host).any()):
+        bits = host.detach().contiguous().view(torch.int32)
+        if bool((bits == PROTOCOL_NAN_BITS).any()):
+            raise RuntimeError("probaforms_amd: a training launch ended on a synchronisation time-out inside the kernel "
+                               "(protocol error); the optimizer step was skipped and the parameters are unchanged since the "
+                               "last good batch")
+    return host
+
+
 def fit_epochs(engine, opt, X, C, batch_size, n_epochs, loss_history, epoch_hook=None, prior=None, perms=None):
     """The batch loop of RealNVP.fit (realnvp.py:235-262) on device-resident X [n,d], C [n,c].
 
@@ -929,7 +950,7 @@ def _fit_epochs_loop(engine, opt, X, C, batch_size, n_epochs, loss_history, epoc
         return d, ev
 
     def read_back(epoch, losses):
-        host = losses.cpu()
+        host = check_losses(losses.cpu())
         loss_history.extend(host.unbind(0))
         if epoch_hook is not None:
             epoch_hook(epoch, host)                      # the epoch's per-batch losses, in batch order

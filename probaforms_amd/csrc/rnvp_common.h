@@ -94,7 +94,6 @@ struct Seeds {
     float *gx = nullptr;
     float *gc = nullptr;
     int inv = 0;
-    float *hsave = nullptr;      // register-chained training kernels (RNVP_SAVE_H): hidden activations saved by the forward phase
 };
 
 // ---- generic (any-shape) path: rnvp_generic.hip ---------------------------------------

@@ -95,7 +95,8 @@ bool supported(const KShape &k);            // forward / inverse
 bool train_supported(const KShape &k);      // fused forward + backward
 bool backward_rows_ok(const KShape &k, int64_t n);      // rnvp_backward (per-row seeds, d loss / d x) of n rows runs here
 size_t train_workspace_bytes(const KShape &k, int64_t max_rows);
-int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed);
+// err (nullable): the training step's error word, cleared by the same launch
+int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed, int *err = nullptr);
 size_t workspace_bytes(const KShape &k, int op, int64_t max_rows);
 int forward(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
             const int64_t *row_index, int64_t n, float *z_out, float *logdet_out, float *logp_out,

@@ -28,7 +28,8 @@ constexpr int kMaxGrid = 2048;
 // parameters (76 k .. 450 k floats: a few microseconds); inside rnvp_fit_epoch* only once per call -- from then on the
 // training step's finish kernel re-packs what it updates.
 __global__ void __launch_bounds__(256)
-k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restrict__ packed) {
+k_pack_weights(KShape k, Geo g, const float *__restrict__ params, float *__restrict__ packed, int *err) {
+    if (err && blockIdx.x == 0 && threadIdx.x == 0) *err = 0;       // the training step's error word (rnvp_mfma_layer.h spin_nap)
     const int per = g.layer_floats;
     const int64_t total = (int64_t)per * k.L;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -289,11 +290,11 @@ int dispatch_flow(hipStream_t st, const KShape &k, const Geo &g, const float *pa
 
 }  // namespace
 
-int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed) {
+int pack_weights(hipStream_t st, const KShape &k, const Geo &g, const float *params, float *packed, int *err) {
     const int64_t total = (int64_t)g.layer_floats * k.L;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, st, k, g, params, packed);
+    hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, st, k, g, params, packed, err);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }

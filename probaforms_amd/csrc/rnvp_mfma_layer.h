@@ -62,19 +62,6 @@ using f2 = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ f4 tanh4(f4 u) {
     if (RNVP_ABLATE & 8) return u * 0.5f;
-#ifdef RNVP_TANH_SCALAR
-    f4 h;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float e = __builtin_amdgcn_exp2f(u[i]);
-        float ep1, hv;
-        asm("v_add_f32 %0, 1.0, %1" : "=v"(ep1) : "v"(e));
-        const float rr = __builtin_amdgcn_rcpf(ep1);
-        asm("v_fma_f32 %0, %1, -2.0, 1.0" : "=v"(hv) : "v"(rr));
-        h[i] = hv;
-    }
-    return h;
-#endif
     f2 e0, e1;
     e0[0] = __builtin_amdgcn_exp2f(u[0]); e0[1] = __builtin_amdgcn_exp2f(u[1]);
     e1[0] = __builtin_amdgcn_exp2f(u[2]); e1[1] = __builtin_amdgcn_exp2f(u[3]);
@@ -168,52 +155,24 @@ __device__ __forceinline__ void store_row(float *out, int64_t row, int d, bool f
 
 constexpr int kTS = 20;                  // row stride (floats) of a 16-wide LDS transposition tile
 
-// RNVP_NS_PAIRSYNC (net-split training launches): the per-layer exchange between a row tile's t wave and s wave -- the nets'
-// outputs in the forward, their input-gradient shares in the backward -- is a rendezvous of THOSE TWO waves (both on one SIMD)
-// through a pair of LDS sequence flags, not a barrier of all eight waves of the workgroup: the four pairs drift freely and
-// nobody pays the arrival skew between SIMDs sixteen times per row group.  The exchange records stay double buffered by layer
-// parity: a wave can be at most one exchange ahead of its partner.
-// Built, parity-green, measured (profiles/r05_ns_sync_ab.txt): C2 at 65 536 rows 0.2957-0.3000 ms against 0.2901-0.2957 with the
-// workgroup barrier (and the t-wave flush in both) -- the barrier's skew was not the cost; OFF.
-#ifndef RNVP_NS_PAIRSYNC
-#define RNVP_NS_PAIRSYNC 0
-#endif
-constexpr bool kNsPairSync = RNVP_NS_PAIRSYNC != 0;
 // Every spin on an LDS counter is bounded: a wait that outlives 2^22 naps (seconds; the longest legitimate one is a few
-// microseconds) is a protocol error.  The wave then poisons the workgroup's loss partial with a NaN -- the step's loss comes out
-// NaN, which every caller notices -- and ENDS instead of hanging the device.  (`__builtin_trap()` there cost the C2 kernel 2.5 % and
+// microseconds) is a protocol error.  The wave then raises the step's ERROR WORD in the workspace (global memory, behind the loss
+// partials; cleared by the pack kernel at the head of every call) and poisons the workgroup's loss partial with a NaN, and ENDS
+// instead of hanging the device.  The workgroup's gradient partial is then incomplete: k_train_finish sees the error word,
+// applies NO Adam step and NO re-pack -- the parameters keep their last good values -- and reports the loss kProtocolNaN, a NaN
+// with a payload no arithmetic produces, which RealNVP.fit turns into a RuntimeError (_engine.check_losses).  (`__builtin_trap()` there cost the C2 kernel 2.5 % and
 // the wide C3 kernel 6.5 % of its time through register allocation alone; `s_endpgm` costs nothing: profiles/r05_spin_bound_ab.txt.)
-struct Poison { float *loss; int *flag; };          // this workgroup's loss partials (global) and its LDS error flag
+constexpr unsigned kProtocolNaN = 0x7fc0deadu;
+struct Poison { float *loss; int *flag; int *err; };          // this workgroup's loss partials (global), its LDS error flag, the step's error word (global)
 __device__ __forceinline__ void spin_nap(int &spins, const Poison &po) {
     __builtin_amdgcn_s_sleep(1);
     if (++spins > (1 << 22)) {
         if (po.flag) __hip_atomic_store(po.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // waves that still finish write NaN too
+        if (po.err) __hip_atomic_store(po.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (po.loss) *po.loss = __builtin_nanf("");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_endpgm" ::: "memory");
     }
 }
-struct PairSync { int *own; const int *other; int seq; Poison poison; };
-__device__ __forceinline__ void pair_rendezvous(PairSync &ps, int lane) {
-    if constexpr (kNsPairSync) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's record has landed in LDS
-        ++ps.seq;
-        if (lane == 0) __hip_atomic_store(ps.own, ps.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        int spins = 0;
-        while (__hip_atomic_load(ps.other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.seq) spin_nap(spins, ps.poison);
-        asm volatile("" ::: "memory");
-    } else {
-        __syncthreads();
-    }
-}
-
-// RNVP_SAVE_H_TILES: hidden tiles per net whose activations the training kernel's forward phase saves for its backward
-// (rnvp_mfma_train_dev.h RNVP_SAVE_H); the other tiles are recomputed.  Saving all of them makes the forward phase HBM-write bound
-// at 65 536 rows (537 MB in ~60 us); the count balances the bytes against the matrix cycles they save.
-#ifndef RNVP_SAVE_H_TILES
-#define RNVP_SAVE_H_TILES (1 << 20)
-#endif
-constexpr int kSaveHTiles = RNVP_SAVE_H_TILES;
-
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering the accesses.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -364,7 +323,7 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
                                           const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           f4 (&out)[R][FwdDims<NF, CQ>::NT2],
                                           const f4 (*bin)[SplitDims<NF, CQ>::NI1] = nullptr,
-                                          const TilePre<NF, CQ> *pre = nullptr, float *hs = nullptr) {
+                                          const TilePre<NF, CQ> *pre = nullptr) {
     using D = FwdDims<NF, CQ>;
     constexpr int K4 = G1Dims<NF, CQ, BX>::NA, OTL = D::OTL;
     const int q = lane >> 4;
@@ -443,10 +402,6 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
             for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (hs && t < kSaveHTiles) {                   // (training: the backward reads the activations back, see run_tiles_x4)
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)t * R + rt) * 256 + lane * 4) = hv[rt];
-        }
         gemm2(c, hv);                                  // phase B
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -454,10 +409,6 @@ __device__ __forceinline__ void run_tiles(const float *__restrict__ W, const Geo
         f4 hv[R];
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(c.acc[rt]);
-        if (hs && last < kSaveHTiles) {
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)last * R + rt) * 256 + lane * 4) = hv[rt];
-        }
         gemm2(c, hv);
     };
     int t = 0;
@@ -476,9 +427,7 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
                                              int ntiles, const float (&xr)[R][4],
                                              const float (&cr)[R][CQ > 0 ? CQ : 1], f4 (&outx)[R][4],
                                              const f4 (*bin)[SplitDims<2, CQ>::NI1] = nullptr,
-                                             const TilePre<2, CQ> *pre = nullptr, float *hs = nullptr) {
-    // hs (training, RNVP_SAVE_H): the tiles' hidden activations are stored -- [tile][row tile][lane] f4, the accumulator layout --
-    // for the backward, which then neither recomputes GEMM1 nor the activation
+                                             const TilePre<2, CQ> *pre = nullptr) {
     constexpr int NF = 2;
     constexpr int K4 = G1Dims<NF, CQ, BX>::NA;
     const int q = lane >> 4;
@@ -553,10 +502,6 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
             for (int u = 0; u < RB; ++u) hv[r0 + u] = act4<ACT>(c.acc[r0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (hs && t < kSaveHTiles) {
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)t * R + rt) * 256 + lane * 4) = hv[rt];
-        }
         gemm2(c, hv);                                  // phase B
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -564,10 +509,6 @@ __device__ __forceinline__ void run_tiles_x4(const float *__restrict__ W, const 
         f4 hv[R];
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) hv[rt] = act4<ACT>(c.acc[rt]);
-        if (hs && last < kSaveHTiles) {
-#pragma unroll
-            for (int rt = 0; rt < R; ++rt) *reinterpret_cast<f4 *>(hs + ((size_t)last * R + rt) * 256 + lane * 4) = hv[rt];
-        }
         gemm2(c, hv);
     };
     int t = 0;
@@ -661,7 +602,7 @@ template <int NF, int CQ, int R, int PC, int MODE, int ACT, bool BX = false>
 __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, const Geo &g, int lane, int role,
                                                  float *xown, const float *xother, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
-                                                 float *__restrict__ scr, PairSync &ps, float *hs = nullptr) {
+                                                 float *__restrict__ scr) {
     using D = FwdDims<NF, CQ>;
     constexpr int OTL = D::OTL, NT2 = D::NT2;
     const int q = lane >> 4;
@@ -676,7 +617,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (role == 0) {
-            run_tiles_x4<CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, outx, bin, nullptr, hs);
+            run_tiles_x4<CQ, R, PC, 0, ACT, BX>(W, g, lane, 0, g.HT, xr, cr, outx, bin);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -686,7 +627,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
                 own[rt][1] = swap_add16(s4[1], s4[3]) + bias2[1];
             }
         } else {
-            run_tiles_x4<CQ, R, PC, 1, ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, outx, bin, nullptr, hs);
+            run_tiles_x4<CQ, R, PC, 1, ACT, BX>(W, g, lane, g.HT, g.HT, xr, cr, outx, bin);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
                 float s4[4];
@@ -722,7 +663,7 @@ __device__ __forceinline__ void layer_forward_ns(const float *__restrict__ W, co
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
         for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = own[rt][f];
-    pair_rendezvous(ps, lane);
+    __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
 #pragma unroll
@@ -757,7 +698,7 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
                                                  int nt, float *red, float (&xr)[R][2 * NF],
                                                  const float (&cr)[R][CQ > 0 ? CQ : 1], float (&ld)[R],
                                                  float *__restrict__ scr, const float *__restrict__ Wnext,
-                                                 TilePre<NF, CQ> &pre, bool use_pre, float *hs = nullptr) {
+                                                 TilePre<NF, CQ> &pre, bool use_pre) {
     // pre: this layer's opening fragments, loaded by the caller / the previous layer; Wnext (nullable): the layer that
     // follows in this pass -- its opening fragments are requested here, before the rendezvous
     using D = FwdDims<NF, CQ>;
@@ -784,8 +725,8 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) outx[rt][u] = f4{0.f, 0.f, 0.f, 0.f};
         if (nt > 0) {
-            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr, hs);
-            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr, hs);
+            if (net == 0) run_tiles_x4<CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr);
+            else run_tiles_x4<CQ, R, PC, 1, ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, outx, nullptr, use_pre ? &pre : nullptr);
             if (use_pre && Wnext) load_tile_pre<NF, CQ>(Wnext, g, lane, net * g.HT + tile0, nt, pre);
         }
 #pragma unroll
@@ -804,8 +745,8 @@ __device__ __forceinline__ void layer_forward_ts(const float *__restrict__ W, co
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) out[rt][ot] = f4{0.f, 0.f, 0.f, 0.f};
         if (nt > 0) {
-            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr, hs);
-            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr, hs);
+            if (net == 0) run_tiles<NF, CQ, R, PC, 0, ACT>(W, g, lane, tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr);
+            else run_tiles<NF, CQ, R, PC, (NF >= 4 ? OTL : 0), ACT>(W, g, lane, g.HT + tile0, nt, xr, cr, out, nullptr, use_pre ? &pre : nullptr);
             if (use_pre && Wnext) load_tile_pre<NF, CQ>(Wnext, g, lane, net * g.HT + tile0, nt, pre);
         }
 #pragma unroll

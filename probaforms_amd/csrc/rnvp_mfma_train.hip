@@ -94,21 +94,27 @@ constexpr int kFinInFlight = RNVP_FIN_INFLIGHT;
 __global__ void __launch_bounds__(kFinThreads)
 k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, const float *__restrict__ gpart, int G,
                const float *__restrict__ losspart, int n_loss, float inv_B, const float *loss_in, float *loss_out,
-               float *grad, float *params, float *adam_m, float *adam_v, AdamK adam, float *packed) {
+               float *grad, float *params, float *adam_m, float *adam_v, AdamK adam, float *packed, const int *err) {
     __shared__ __attribute__((aligned(16))) float rec[kFinRecMax];
     __shared__ f4 red[kFinThreads];
     __shared__ float pw[kFinParMax];
     const int t = threadIdx.x, b = blockIdx.x;
     const int HT = g.HT, nrec = k.L * 2 * HT;
+    // a wave of the training launch gave up a bounded wait (spin_nap): its workgroup's partial is incomplete.  No Adam step, no
+    // re-pack -- the parameters keep their last good values -- and the loss says so (kProtocolNaN)
+    // (data parallel: ANY rank's error reaches every rank through the all-reduced loss -- NaN + x keeps the NaN's payload)
+    const bool bad = (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ||
+                     (!(mode & kFinSum) && loss_in && __float_as_uint(loss_in[0]) == kProtocolNaN);
+    if (bad) mode &= ~(kFinAdam | kFinPack);
     if (b == 2 * nrec + k.L) {              // the loss: partials added in a fixed order (one wave), or read out of the message
         if (t < 64 && loss_out) {
             if (mode & kFinSum) {
                 float a = 0.f;
                 for (int i = t; i < n_loss; i += 64) a += losspart[i];
                 for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-                if (t == 0) loss_out[0] = -a * inv_B;
+                if (t == 0) loss_out[0] = bad ? __uint_as_float(kProtocolNaN) : -a * inv_B;
             } else if (t == 0 && loss_in) {
-                loss_out[0] = loss_in[0];
+                loss_out[0] = bad ? __uint_as_float(kProtocolNaN) : loss_in[0];
             }
         }
         return;
@@ -272,49 +278,24 @@ bool train_supported(const KShape &k) {
     return pl.lds_bytes <= 160 * 1024;
 }
 
-// RNVP_SAVE_H: the net-split launches of d <= 16 keep every hidden activation of the forward phase for the backward: per
-// workgroup L x 2 nets x 4 row owners x HT tiles x R row tiles of 1 KiB -- 4 h L bytes per row and net (8 KB per row for C2),
-// for at most 256 workgroups (the net-split launches are those with one workgroup per CU or fewer)
-static size_t hsave_bytes(const Geo &g, int L, const TrainPlan &pl, int64_t max_rows) {
-    size_t need = 0;
-    if (kSaveH && g.NF == 2) {
-        const int LS = kSaveHLayers < L ? kSaveHLayers : L;                                  // the layers that keep their activations
-        const size_t per_wg_r1 = (size_t)LS * 2 * kWaves * g.HT * 256 * sizeof(float);     // one row tile per wave: 64 rows per workgroup
-        // ceil(n / (64 R)) workgroups of R x per_wg_r1 bytes, whatever R the launch picks, for every n <= max_rows; a net-split launch
-        // never has more than 256 workgroups
-        const size_t a = (size_t)((max_rows + 63) / 64 + pl.RMAX) * per_wg_r1, cap = (size_t)256 * pl.RMAX * per_wg_r1;
-        need = a < cap ? a : cap;
-    }
-    if (kTsSaveH) {
-        // tile-split step (RNVP_TS_SAVE_H): a workgroup of 16 R rows keeps, per wave, its ceil(HT / 4) tiles of every layer: 1 KiB
-        // per tile and row tile -- 4 h L bytes per row and net; at most ts_max_rows rows ever run there
-        const int tps = (g.HT + kTsSlices - 1) / kTsSlices;
-        const int64_t rows = max_rows < ts_max_rows(g) ? max_rows : ts_max_rows(g);
-        const size_t b = (size_t)((rows + 15) / 16 + 2) * kTsWaves * L * tps * 256 * sizeof(float);
-        if (b > need) need = b;
-    }
-    return align_up(need, 256);
-}
-
 size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return 0;
     size_t b = align_up((size_t)g.layer_floats * k.L * sizeof(float), 256);                    // packed weights
     b += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);          // partials
-    b += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);                          // loss partials
+    b += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256) + 256;                    // loss partials, the error word
     b += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);    // saved activations
-    b += hsave_bytes(g, k.L, pl, max_rows);                                                      // hidden activations (RNVP_SAVE_H)
     return b;
 }
 
 static int launch_finish(hipStream_t st, const KShape &k, const Geo &g, int glayer_floats, int w2c, int mode, const float *gpart,
                          int G, const float *losspart, float inv_B, const float *loss_in, float *loss_out, float *grad,
-                         float *params, float *adam_m, float *adam_v, const AdamK &adam, float *packed) {
+                         float *params, float *adam_m, float *adam_v, const AdamK &adam, float *packed, const int *err) {
     const int NTI = (g.KS1 + 1 + 3) / 4;
     const unsigned blocks = (unsigned)(2 * k.L * 2 * g.HT + k.L + 1);       // two per gradient record, one per layer (b2), the loss
     hipLaunchKernelGGL(k_train_finish, dim3(blocks), dim3(kFinThreads), 0, st, k, g, NTI, glayer_floats, w2c, mode, gpart, G, losspart,
-                       G * kWaves, inv_B, loss_in, loss_out, grad, params, adam_m, adam_v, adam, packed);
+                       G * kWaves, inv_B, loss_in, loss_out, grad, params, adam_m, adam_v, adam, packed, err);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
 }
@@ -338,11 +319,9 @@ static int step_impl(hipStream_t st, const KShape &k, const float *params, const
     float *gpart = reinterpret_cast<float *>(w);
     w += align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);
     float *losspart = reinterpret_cast<float *>(w);
-    w += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256);
+    w += align_up((size_t)kMaxGridTrain * kWaves * sizeof(float), 256) + 256;
     float *scratch = reinterpret_cast<float *>(w);
-    w += align_up((size_t)kMaxGridTrain * kWaves * pl.scratch_per_wave * sizeof(float), 256);
-    if (hsave_bytes(g, k.L, pl, n) > 0) sd.hsave = reinterpret_cast<float *>(w);
-    int rc = packed_valid ? RNVP_OK : pack_weights(st, k, g, params, packed);
+    int rc = packed_valid ? RNVP_OK : pack_weights(st, k, g, params, packed, error_word(losspart));
     if (rc) return rc;
     int grid = 0;
     PartialLayout lay{pl.glayer_floats, 0};
@@ -354,7 +333,7 @@ static int step_impl(hipStream_t st, const KShape &k, const float *params, const
     if (rc) return rc;
     const int mode = kFinSum | (adam_p ? kFinAdam : 0) | (adam_p && pack_next ? kFinPack : 0);
     rc = launch_finish(st, k, g, lay.glayer_floats, lay.w2c, mode, gpart, grid, losspart, inv_B, nullptr, loss_out, grad_out, adam_p,
-                       adam_m, adam_v, adam, packed);
+                       adam_m, adam_v, adam, packed, error_word(losspart));
     if (rc) return rc;
     note_launches(RNVP_PROFILE_TRAIN, packed_valid ? 2 : 3);       // [pack,] hot kernel, finish
     return RNVP_OK;
@@ -386,8 +365,11 @@ int adam_pack(hipStream_t st, const KShape &k, float *params, float *grad, const
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     TrainPlan pl;
     if (!plan_for(g, k.L, &pl)) return RNVP_EUNSUPPORTED;
+    // the workspace layout of step_impl: packed fragments, partials, loss partials (+ the error word this rank's training launch raises)
+    char *w = static_cast<char *>(ws) + align_up((size_t)g.layer_floats * k.L * sizeof(float), 256) +
+              align_up((size_t)kMaxGridTrain * pl.glayer_floats * k.L * sizeof(float), 256);
     return launch_finish(st, k, g, pl.glayer_floats, 0, kFinAdam | kFinPack, nullptr, 0, nullptr, 0.f, loss_in, loss_out, grad, params,
-                         exp_avg, exp_avg_sq, adam, static_cast<float *>(ws));
+                         exp_avg, exp_avg_sq, adam, static_cast<float *>(ws), error_word(reinterpret_cast<float *>(w)));
 }
 
 }  // namespace mfma

@@ -66,61 +66,29 @@ constexpr int kAblate = RNVP_ABLATE;
 #define STAMP(var) do { } while (0)
 #define STAMP_ADD(acc, t0) do { } while (0)
 #endif
-// RNVP_NO_BWD_SCHED_BARRIER: developer A/B switch (lets hipcc schedule the backward phases freely)
-#ifdef RNVP_NO_BWD_SCHED_BARRIER
-#define BWD_SCHED_BARRIER() do { } while (0)
-#else
 #define BWD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
 struct Stamps { unsigned long long fwd, bsetup, bloop, bflush, btail, ld, p1, p2, p3, p4, p5, fb1, fsum; };
 
 #ifndef RNVP_TRAIN_WAVES
 #define RNVP_TRAIN_WAVES 4
 #endif
-// RNVP_TRAIN_BX: the row-parallel training launches (every batch the tile-split kernel does not take) use the split-GEMM1
-// form k_mfma_train_bx
-#ifndef RNVP_TRAIN_BX
-#define RNVP_TRAIN_BX 0
-#endif
-constexpr bool kTrainBx = RNVP_TRAIN_BX != 0;
-// RNVP_W2C_NO_NS: the compact 4x4x1 form of dW2 (Dims::w2c) also where a wave runs both nets one after the other
-#ifndef RNVP_W2C_NO_NS
-#define RNVP_W2C_NO_NS 1
-#endif
-constexpr bool kW2cNoNs = RNVP_W2C_NO_NS != 0;
+// the compact 4x4x1 form of dW2 (Dims::w2c) also where a wave runs both nets one after the other
+constexpr bool kW2cNoNs = true;
 // RNVP_TRAIN_WIDE: k_mfma_train_wide for d in (16, 32] when a batch needs more than 256 four-wave workgroups
 #ifndef RNVP_TRAIN_WIDE
 #define RNVP_TRAIN_WIDE 1
-#endif
-// RNVP_TRAIN_WIDE8: the wide form for d in (32, 64] as well
-#ifndef RNVP_TRAIN_WIDE8
-#define RNVP_TRAIN_WIDE8 0
 #endif
 constexpr bool kTrainWide = RNVP_TRAIN_WIDE != 0;
 #ifndef RNVP_TRAIN_BXF
 #define RNVP_TRAIN_BXF 1
 #endif
 constexpr bool kTrainBxF = RNVP_TRAIN_BXF != 0;
-// RNVP_TRAIN_BX_NS_FIRST: batches that give at most one workgroup per CU keep the net-split f32-backward kernel (two waves
-// per SIMD) and the one-wave split-GEMM1 form takes only the larger ones
-#ifndef RNVP_TRAIN_BX_NS_FIRST
-#define RNVP_TRAIN_BX_NS_FIRST 1
-#endif
-constexpr bool kTrainBxNsFirst = RNVP_TRAIN_BX_NS_FIRST != 0;
-constexpr bool kTrainSplit = kTrainBx || kTrainBxF;      // the packed block carries the split fragments
+constexpr bool kTrainSplit = kTrainBxF;                 // the packed block carries the split fragments
 constexpr int kWaves = RNVP_TRAIN_WAVES;    // waves per workgroup
 #ifndef RNVP_MAX_GRID_TRAIN
 #define RNVP_MAX_GRID_TRAIN 512
 #endif
 constexpr int kMaxGridTrain = RNVP_MAX_GRID_TRAIN;
-// RNVP_NS_PRIO: issue priority of the net-split wave pairs (the two waves of a SIMD).  Equal priorities are arbitrated by
-// age, so the s-net waves 4..7 lose every contended slot and the t-net waves wait for them at each barrier (profiles/r03_stamp_c2.txt).
-// 0: leave it to age; 1: static priority for the s waves; 2: the s waves raise theirs on odd hidden tiles; 3: the wave that is
-// behind its partner (tile counters in LDS) gets the priority
-#ifndef RNVP_NS_PRIO
-#define RNVP_NS_PRIO 0
-#endif
-constexpr int kNsPrio = RNVP_NS_PRIO;
 // RNVP_NS_TFLUSH (net-split launches, FT >= 2): the flush of the waves' LDS gradient slots into the workgroup's partial WITHOUT
 // workgroup barriers, done by the t-net waves for BOTH nets.  On every SIMD the t wave (older: it wins the issue arbitration)
 // runs ahead of its s partner and used to idle at the flush barriers while the s waves -- the kernel's critical path -- paid
@@ -130,41 +98,6 @@ constexpr int kNsPrio = RNVP_NS_PRIO;
 // after their own window, wait for the window's eight arrivals, add the slots of both nets in slot order (the order of
 // arrival plays no part: bitwise as before) and write the partial, then count the window done; a wave checks that count
 // before it overwrites a buffer, two windows later.  The s waves never wait for a flush.
-// RNVP_BWD_READS_FIRST 1: measured SLOWER (profiles/r05_reads_first_ab.txt: C2 0.301-0.307 vs 0.294-0.300 ms, C4 1.105 vs 1.095): the
-// requests ahead of the products delay the products' issue by as much as they save at phase 4; hipcc's own placement ships
-#ifndef RNVP_BWD_READS_FIRST
-#define RNVP_BWD_READS_FIRST 0
-#endif
-constexpr bool kBwdReadsFirst = RNVP_BWD_READS_FIRST != 0;
-// RNVP_SAVE_H (net-split launches of d <= 16): the forward phase stores every hidden tile's activations (16 B per lane and row
-// tile, the accumulator layout: 8 KB per row for C2) and the backward reads them back, one hidden tile ahead, instead of
-// recomputing GEMM1 + tanh -- 96 matrix + 96 transcendental cycles of the backward unit's ~590, paid for with HBM traffic the
-// MFMA-bound kernel leaves idle.
-// Built, parity-green (631 kernel tests), measured (profiles/r05_saveh_ab.txt), OFF: at 65 536 rows saving all eight tiles per net
-// (537 MB written in the ~60 us forward phase) makes the launch 0.357 ms against 0.293 recomputing; saving 1 / 2 / 3 / 4 tiles
-// (RNVP_SAVE_H_TILES; the others recomputed in the same loop) 0.326 / 0.337 / 0.356 / 0.365 -- every count loses; only launches
-// whose record fits the caches gain (16 960 rows: 0.157 vs 0.164); whole layers saved instead (the last 1 / 2 / 3 / 4 of 8,
-// RNVP_SAVE_H_LAYERS: one clean code path per layer) 0.310 / 0.311 / 0.318 / 0.335 against 0.299.
-#ifndef RNVP_SAVE_H
-#define RNVP_SAVE_H 0
-#endif
-constexpr bool kSaveH = RNVP_SAVE_H != 0;
-// RNVP_SAVE_H_LAYERS: only the LAST so many layers keep their activations (whole layers: one code path per layer instance) -- the
-// backward starts with exactly those, moments after the forward wrote them, and the record (1 KB per row and layer) stays cache sized
-#ifndef RNVP_SAVE_H_LAYERS
-#define RNVP_SAVE_H_LAYERS 2
-#endif
-constexpr int kSaveHLayers = RNVP_SAVE_H_LAYERS;
-// RNVP_TS_SAVE_H: the tile-split step (batches of at most 8 192 rows: latency chains, records that stay in the caches) keeps ALL its
-// hidden activations -- each wave the tiles it owns -- and its backward drops GEMM1 + activation from every tile step's dependent chain.
-// Built, parity-green (694 tests), measured (profiles/r05_ts_saveh_ab.txt), OFF: it pays where the record is tiny and the net wide
-// (32 / 1 024 rows: C3 -9 % / -10 %, C4 -6 % / -8 %, C2 0 / -2 %) and loses from 4 096 rows on (C3 +9 %, C2 +1.5 %; 8 192 rows: C2 +3 %,
-// C3 +1.5 %) -- the BASELINE sizes that run this kernel (C2 at the reference's batch 32, the 8 192-row shards of the 8-GPU regime) gain
-// nothing, so the second set of kernel instances a per-size switch would need is not worth its build time.
-#ifndef RNVP_TS_SAVE_H
-#define RNVP_TS_SAVE_H 0
-#endif
-constexpr bool kTsSaveH = RNVP_TS_SAVE_H != 0;
 #ifndef RNVP_NS_TFLUSH
 #define RNVP_NS_TFLUSH 1
 #endif
@@ -175,7 +108,9 @@ constexpr bool kNsTFlush = RNVP_NS_TFLUSH != 0;
 #define RNVP_WIDE_TFLUSH 1
 #endif
 constexpr bool kWideTFlush = RNVP_WIDE_TFLUSH != 0;
-constexpr size_t kSyncBytes = 128;                       // LDS behind a workgroup's buffers: 8 tile counters (RNVP_NS_PRIO 3), 5 flush counters, 8 pair flags
+constexpr size_t kSyncBytes = 128;                       // LDS behind a workgroup's buffers: the flush counters (FlushSync) and the error flag of the bounded spins
+// the step's error word: one int behind the kMaxGridTrain x kWaves loss partials of the workspace (spin_nap, k_train_finish)
+__host__ __device__ __forceinline__ int *error_word(float *losspart) { return reinterpret_cast<int *>(losspart + (size_t)kMaxGridTrain * kWaves); }
 struct FlushSync { int *arr; int *done; int win; Poison poison; };      // arr[2 g + p]: arrivals of net group g (t / s waves) at windows of parity p; done: window shares summed; win: windows this wave finished
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -257,7 +192,7 @@ __device__ __forceinline__ void load_bwd_pre(const float *__restrict__ W, const 
     for (int m = 0; m < NGI; ++m) p.a1t[m] = *opaque(pA1T + ((size_t)ht_lo * NGI + m) * 256);
 }
 
-template <int NF, int CQ, int R, int PC, int NS, int ACT, bool BX = false, int WV = kWaves, bool SHT = false>
+template <int NF, int CQ, int R, int PC, int NS, int ACT, int WV = kWaves>
 __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo &g, int lane, int wave,
                                           float (&xr)[R][2 * NF], const float (&cr)[R][CQ > 0 ? CQ : 1],
                                           float (&gy)[R][2 * NF], const float (&gld)[R],
@@ -265,8 +200,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                           float *gp_layer, bool first, Stamps &stp, float *xown,
                                           const float *xother, int tile_lo, int tile_hi,
                                           BwdPre<NF, CQ, R> &pre_ref, bool use_pre, const float *__restrict__ Wprev = nullptr,
-                                          const float *__restrict__ scr_prev = nullptr, int *prog = nullptr, int *prog_cnt = nullptr,
-                                          FlushSync *fs = nullptr, PairSync *ps = nullptr, const float *__restrict__ hs = nullptr) {
+                                          const float *__restrict__ scr_prev = nullptr, FlushSync *fs = nullptr) {
     BwdPre<NF, CQ, R> *const pre = &pre_ref;       // (a reference + flag, not a nullable pointer: the record must stay in registers)
     // pre (tile split only): this layer's opening loads, made by the caller / the layer above; Wprev, scr_prev (nullable):
     // the layer below, whose opening loads are requested here before the input-gradient rendezvous
@@ -285,7 +219,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     const int ht_lo = TS ? tile_lo : 0, ht_hi = TS ? tile_hi : HT;
     constexpr bool W2C = D::template w2c<NS>();
     constexpr int FT = D::FT, SLOT = D::template slot<NS>(), TBLK = D::template tblk<NS>(), GS = D::GS;
-    constexpr bool SH = SHT && !BX;       // this layer's hidden activations come from the forward's record (hs), not from a recompute
     // barrier-free flush by the waves that run ahead: the t waves of a net-split launch (both nets), or -- RNVP_WIDE_TFLUSH -- waves
     // 0..3 of the eight-wave wide form, the older wave of every SIMD (the net the pass is on; the younger four never wait)
     constexpr bool TFW = kWideTFlush && NS == 0 && WV == 8 && FT >= 2 && FT % 2 == 0;
@@ -296,15 +229,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     float *bufG = tb;                                     // NT2 tiles of 16 x kTS (g_out^T staging); W2C: R x 16 x GS
     float *bufI = tb + (W2C ? D::template gimg<NS>(R) : NT2 * 16 * kTS);   // 16 x SIN
     float *bufH = bufI + 16 * SIN;                        // 2R tiles of 16 x kTS: (h, g_pre) per row tile
-    // BX: GEMM1 (recompute) and g_h = W2^T g_out on split-bf16 MFMA (rnvp_split.h).  Their B operands are split once per
-    // layer and row tile: `bin` from the conditioning features and conditions (the layer leaves them unchanged, so the
-    // registers restored below are not needed for it), `gob` from g_out of each net (NS: this wave's net only).
-    constexpr int NI1 = SplitDims<NF, CQ>::NI1, NI2 = SplitDims<NF, CQ>::NI2;
-    constexpr int NA1 = BX ? NI1 : K4, NA2 = BX ? NI2 : OTL;      // f4 fragments per tile of GEMM1 / of W2^T
-    constexpr int NGB = NS ? 1 : 2;
-    f4 bin[BX ? R : 1][NI1], gob[BX ? R : 1][NGB][NI2];
-    if constexpr (BX) build_bin<NF, CQ, PC, R>(xr, cr, bin);
-
     // 1. restore the layer input, form g_out = [g_t | g_s] and the gradient of the pass-through part
     f4 go[R][NT2];
 #pragma unroll
@@ -329,22 +253,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         gb2[ot] = go[0][ot];
 #pragma unroll
         for (int rt = 1; rt < R; ++rt) gb2[ot] += go[rt][ot];
-    }
-    if constexpr (BX) {
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt)
-#pragma unroll
-            for (int nb = 0; nb < NGB; ++nb) {
-                float v[NF];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    float vt, vs;
-                    if (NF >= 4) { vt = go[rt][f >> 2][f & 3]; vs = go[rt][(NF >= 4 ? OTL : 0) + (f >> 2)][f & 3]; }
-                    else { vt = go[rt][0][f & 1]; vs = go[rt][0][2 + (f & 1)]; }
-                    v[f] = NS ? (role ? vs : vt) : (nb ? vs : vt);
-                }
-                split::build_b<NF>(v, gob[rt][nb]);
-            }
     }
     // 2. row-contraction operands: g_out^T and [in | 1]^T through the wave's LDS tiles
     float goT[R][NT2][4], inT[R][NTI][4];
@@ -398,69 +306,41 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
     //    fragments of the next tile are in flight for a whole iteration.
     auto net_pass = [&](auto net_c) {
         constexpr int net = decltype(net_c)::value;
-        const float *pA1 = W + (BX ? g.oA1S : g.oA1) + ((size_t)net * HT * NA1 * 64 + lane) * 4;
+        const float *pA1 = W + g.oA1 + ((size_t)net * HT * K4 * 64 + lane) * 4;
         const float *pB1 = W + g.oB1 + ((size_t)net * HT * 4 + q) * 4;
-        const float *pA2T = W + (BX ? g.oA2TS : g.oA2T) + ((size_t)net * HT * NA2 * 64 + lane) * 4;
+        const float *pA2T = W + g.oA2T + ((size_t)net * HT * OTL * 64 + lane) * 4;
         const float *pA1T = W + (X4 ? g.oA1X : g.oA1T) + ((size_t)net * HT * NGI * 64 + lane) * 4;
-        f4 a1[NA1], a2t[NA2], a1t[NGI], b1;
+        f4 a1[K4], a2t[OTL], a1t[NGI], b1;
         bool have = false;
-        if constexpr (TS && !BX) {
+        if constexpr (TS) {
             if (use_pre) {          // loaded ahead (BwdPre)
                 have = true;
 #pragma unroll
-                for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = pre->a1[k4];
+                for (int k4 = 0; k4 < K4; ++k4) a1[k4] = pre->a1[k4];
                 b1 = pre->b1;
 #pragma unroll
-                for (int o = 0; o < NA2; ++o) a2t[o] = pre->a2t[o];
+                for (int o = 0; o < OTL; ++o) a2t[o] = pre->a2t[o];
 #pragma unroll
                 for (int m = 0; m < NGI; ++m) a1t[m] = pre->a1t[m];
             }
         }
         if (!have) {
 #pragma unroll
-        for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)ht_lo * NA1 + k4) * 256);
+        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *reinterpret_cast<const f4 *>(pA1 + ((size_t)ht_lo * K4 + k4) * 256);
         b1 = *reinterpret_cast<const f4 *>(pB1 + ht_lo * 16);
 #pragma unroll
-        for (int o = 0; o < NA2; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)ht_lo * NA2 + o) * 256);
+        for (int o = 0; o < OTL; ++o) a2t[o] = *reinterpret_cast<const f4 *>(pA2T + ((size_t)ht_lo * OTL + o) * 256);
 #pragma unroll
         for (int m = 0; m < NGI; ++m) a1t[m] = *reinterpret_cast<const f4 *>(pA1T + ((size_t)ht_lo * NGI + m) * 256);
         }
-        f4 hc[SH ? R : 1], hn[SH ? R : 1];
-        if constexpr (SH) {
-            {
-#pragma unroll
-                for (int rt = 0; rt < R; ++rt) hc[rt] = *reinterpret_cast<const f4 *>(hs + (size_t)rt * 256 + lane * 4);
-            }
-        }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
-            constexpr bool sv = SH;                            // the layer's activations come from the forward's record
-            if constexpr (SH) {
+            f4 na1[K4], na2t[OTL], na1t[NGI], nb1;
 #pragma unroll
-                for (int rt = 0; rt < R; ++rt) hn[rt] = *opaque(hs + ((size_t)(nx - ht_lo) * R + rt) * 256 + lane * 4);
-            }
-            int prog_mine = 0, prog_other = 0; (void)prog_mine; (void)prog_other;
-            if constexpr (NS == 1 && kNsPrio == 2) {
-                if (__builtin_amdgcn_readfirstlane(role)) { if (__builtin_amdgcn_readfirstlane(ht) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-            }
-            if constexpr (NS == 1 && kNsPrio == 3) {
-                prog_mine = ++*prog_cnt;
-                const int uw = __builtin_amdgcn_readfirstlane(wave);
-                reinterpret_cast<volatile int *>(prog)[uw] = prog_mine;
-                prog_other = reinterpret_cast<volatile int *>(prog)[uw ^ 4];
-            }
-            f4 na1[NA1], na2t[NA2], na1t[NGI], nb1;
-            if constexpr (!SH) {
+            for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
+            nb1 = *opaque(pB1 + nx * 16);
 #pragma unroll
-                for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * NA1 + k4) * 256);
-                nb1 = *opaque(pB1 + nx * 16);
-            } else {
-#pragma unroll
-                for (int k4 = 0; k4 < NA1; ++k4) na1[k4] = f4{0.f, 0.f, 0.f, 0.f};
-                nb1 = f4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int o = 0; o < NA2; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * NA2 + o) * 256);
+            for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
 #pragma unroll
             for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
             BWD_SCHED_BARRIER();
@@ -479,23 +359,11 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 f4 acc[RH], gh[RH];
 #pragma unroll
                 for (int u = 0; u < RH; ++u) { acc[u] = b1; gh[u] = f4{0.f, 0.f, 0.f, 0.f}; }
-                if constexpr (BX) {
-#pragma unroll
-                    for (int i = 0; i < NI1; ++i)
-#pragma unroll
-                        for (int u = 0; u < RH; ++u) acc[u] = mfma32(a1[i], bin[r0 + u][i], acc[u]);
-#pragma unroll
-                    for (int i = 0; i < NI2; ++i)
-#pragma unroll
-                        for (int u = 0; u < RH; ++u) gh[u] = mfma32(a2t[i], gob[r0 + u][NS ? 0 : net][i], gh[u]);
-                } else {
-                if constexpr (!sv) {
 #pragma unroll
                 for (int kk = 0; kk < KS1; ++kk)
 #pragma unroll
                     for (int u = 0; u < RH; ++u)
                         acc[u] = mfma16(a1[kk >> 2][kk & 3], in_op<NF, CQ, PC, R>(xr, cr, r0 + u, kk), acc[u]);
-                }
                 if (NF >= 4) {
 #pragma unroll
                     for (int o = 0; o < OTL; ++o)
@@ -511,7 +379,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         for (int u = 0; u < RH; ++u)
                             gh[u] = mfma16(a2t[0][2 * net + v], go[r0 + u][0][2 * net + v], gh[u]);
                 }
-                }
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p1, t0);
 
@@ -521,8 +388,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 wave_lds_fence();
 #pragma unroll
                 for (int u = 0; u < RH; ++u) {
-                    f4 hv;
-                    if constexpr (sv) hv = hc[SH ? r0 + u : 0]; else hv = act4<ACT>(acc[u]);
+                    const f4 hv = act4<ACT>(acc[u]);
                     gpv[u] = gh[u] * dact4<ACT>(hv);                                     // activation'
                     if (!(kAblate & 1)) {
                         *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
@@ -535,10 +401,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p2, t0);
 
-                // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip
-                // RNVP_BWD_READS_FIRST: the transposed reads are REQUESTED ahead of these products (a wave's DS operations execute
-                // in order, so they see phase 2's writes) and their latency runs under the products' ~170 matrix cycles; left to
-                // itself hipcc issued most of them behind the products and phase 4 opened on an s_waitcnt per operand
+                // phase 3 (MFMA): g_in += W1^T g_pre  -- covers the LDS round trip of the transposed reads that follow it in
+                // program order (requesting them AHEAD of the products measured +2 %: profiles/r05_reads_first_ab.txt)
                 float hT[RH][4], pT[RH][4];
                 float2 gB[W2C ? RH : 1][4];
                 auto read_transposed = [&]() {
@@ -557,7 +421,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                                                               ((r0 + u) * 16 + 4 * ks + q) * GS + 2 * (r & 3));
                         }
                 };
-                if constexpr (kBwdReadsFirst) { read_transposed(); BWD_SCHED_BARRIER(); }
                 if constexpr (X4) {
 #pragma unroll
                     for (int rho = 0; rho < 4; ++rho)
@@ -574,7 +437,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             for (int u = 0; u < RH; ++u)
                                 gin[r0 + u][m] = mfma16(a1t[m][rho], gpv[u][rho], gin[r0 + u][m]);
                 }
-                if constexpr (!kBwdReadsFirst) read_transposed();
+                read_transposed();
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p3, t0);
 
@@ -604,10 +467,6 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p4, t0);
             }
-            if constexpr (NS == 1 && kNsPrio == 3) {      // ahead of the partner (as of this tile's start): yield
-                if (__builtin_amdgcn_readfirstlane(prog_mine) > __builtin_amdgcn_readfirstlane(prog_other)) __builtin_amdgcn_s_setprio(0);
-                else __builtin_amdgcn_s_setprio(1);
-            }
             // this wave's share of dW1|db1 and dW2 for hidden tile ht -> its own LDS slot
             if constexpr (TS) {      // the only share there is: straight to the gradient record
                 float *gd = gp_layer + (size_t)net * netblock + (size_t)ht * TBLK + lane * 4;
@@ -622,7 +481,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     // have read this buffer (four t-wave shares per window)
                     if (ht % FT2 == 0 && fs->win >= 2) {
                         int spins = 0;
-                        while (__hip_atomic_load(fs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (fs->win - 1)) spin_nap(spins, fs->poison);
+                        while (__hip_atomic_load(fs->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (fs->win - 1)) spin_nap(spins, fs->poison);
                         asm volatile("" ::: "memory");
                     }
                     spos = (fs->win & 1) * FT2 + ht % FT2;
@@ -677,7 +536,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #ifdef RNVP_SPIN_TEST      // developer build: wave 5 of workgroup 0 "forgets" one arrival -> the flushing waves' bounded wait must end the kernel
                     if (!(blockIdx.x == 0 && wave == 5 && fs->win == 3))
 #endif
-                    if (lane == 0) __hip_atomic_fetch_add(fs->arr + 2 * role + wpar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lane == 0) __hip_atomic_fetch_add(fs->arr + 2 * role + wpar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++fs->win;
                     STAMP_ADD(stp.fb1, t0);
                     if (TFW ? wave < 4 : role == 0) {
@@ -692,10 +551,10 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                         // used to be, minus the late waves' share of it)
                         int spins = 0;
                         if constexpr (TFW) {
-                            while (__hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WV * wneed) spin_nap(spins, fs->poison);
+                            while (__hip_atomic_load(fs->arr + wpar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < WV * wneed) spin_nap(spins, fs->poison);
                         } else {
-                            while (__hip_atomic_load(fs->arr + 2 + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed ||
-                                   __hip_atomic_load(fs->arr + wpar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed) spin_nap(spins, fs->poison);
+                            while (__hip_atomic_load(fs->arr + 2 + wpar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed ||
+                                   __hip_atomic_load(fs->arr + wpar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * wneed) spin_nap(spins, fs->poison);
                         }
                         asm volatile("" ::: "memory");
                         STAMP_ADD(stp.bflush, t0);
@@ -720,7 +579,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             *p = first ? v : *p + v;
                         }
                         lds_drain();                                           // the slot reads are done: the buffer may be rewritten
-                        if (lane == 0) __hip_atomic_fetch_add(fs->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0) __hip_atomic_fetch_add(fs->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     STAMP_ADD(stp.fsum, t0);
                 } else {
@@ -787,15 +646,11 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.bflush, t0);
                 }
             }
-            if constexpr (SH) {
 #pragma unroll
-                for (int rt = 0; rt < R; ++rt) hc[rt] = hn[rt];
-            }
-#pragma unroll
-            for (int k4 = 0; k4 < NA1; ++k4) a1[k4] = na1[k4];
+            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
             b1 = nb1;
 #pragma unroll
-            for (int o = 0; o < NA2; ++o) a2t[o] = na2t[o];
+            for (int o = 0; o < OTL; ++o) a2t[o] = na2t[o];
 #pragma unroll
             for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
         }
@@ -859,7 +714,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
             for (int f = 0; f < NF; ++f) xown[(rt * NF + f) * 64 + lane] = gi[rt][f];
-        pair_rendezvous(*ps, lane);
+        __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < R; ++rt)
 #pragma unroll
@@ -877,7 +732,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 }
 
 // WV: waves of the workgroup that own row tiles (4; 8 in the wide form k_mfma_train_wide, NS == 0 only)
-template <int NF, int CQ, int R, int NS, int ACT, bool BX, bool BXF = BX, int WV = kWaves>
+template <int NF, int CQ, int R, int NS, int ACT, bool BXF, int WV = kWaves>
 __device__ __forceinline__ void train_body(const float *__restrict__ wp, const Geo &g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
@@ -894,24 +749,14 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
     constexpr int SLOTN = DM::template slot<NS>(), TBN = DM::template tbn<R, NS>();
     float *tb = lds + NW * SLOTN + wave * TBN;
     float *xbuf = lds + NW * SLOTN + NW * TBN;                         // NS: 2 x NW x XW, double buffered by layer parity
-    int *prog = reinterpret_cast<int *>(xbuf + (NS ? 2 * NW * XW : 0));   // NS, RNVP_NS_PRIO 3: one tile counter per wave
-    int prog_cnt = 0;
-    // RNVP_NS_TFLUSH: arrivals of the t / s waves and summed window shares, behind the tile counters
-    const Poison poison{losspart + (size_t)blockIdx.x * kWaves, prog + 13};      // (bounded spins: rnvp_mfma_layer.h spin_nap)
-    FlushSync fsync{prog + 8, prog + 12, 0, poison};
-    // RNVP_SAVE_H: this wave's record of hidden activations: [layer][net][row owner][tile][row tile][lane] f4
-    constexpr bool SHB = kSaveH && NS == 1 && NF == 2 && !BX;
-    const size_t hs_layer = (size_t)2 * WV * g.HT * R * 256;
-    const int sh_l0 = L - (kSaveHLayers < L ? kSaveHLayers : L);        // layers sh_l0 .. L-1 keep their activations
-    float *hs_wave = SHB ? sd.hsave + (size_t)blockIdx.x * (L - sh_l0) * hs_layer + ((size_t)role * WV + pw) * g.HT * R * 256 : nullptr;
-    PairSync psync{prog + 16 + wave, prog + 16 + (wave ^ WV), 0, poison};        // RNVP_NS_PAIRSYNC: this wave's flag, its partner's
+    // the flush counters (FlushSync) and the error flag of the bounded spins (rnvp_mfma_layer.h spin_nap), behind the exchange records
+    int *sync = reinterpret_cast<int *>(xbuf + (NS ? 2 * NW * XW : 0));
+    const Poison poison{losspart + (size_t)blockIdx.x * kWaves, sync + 13, error_word(losspart)};
+    FlushSync fsync{sync + 8, sync + 12, 0, poison};
     if constexpr (NS == 1 || (kWideTFlush && NS == 0 && WV == 8)) {
-        if (threadIdx.x < 6) prog[8 + threadIdx.x] = 0;
-        if (threadIdx.x < NW) prog[16 + threadIdx.x] = 0;
+        if (threadIdx.x < 6) sync[8 + threadIdx.x] = 0;
         __syncthreads();
     }
-    if constexpr (NS == 1 && kNsPrio == 3) { if (threadIdx.x < NW) prog[threadIdx.x] = 0; }      // (the forward's barriers publish it)
-    if constexpr (NS == 1 && kNsPrio == 1) { if (__builtin_amdgcn_readfirstlane(role)) __builtin_amdgcn_s_setprio(1); }
     const int64_t rows_per_wg = (int64_t)WV * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
     const float prior_c = 0.5f * (float)g.d * kLog2Pi;
@@ -942,8 +787,8 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *scr = scr_wave + (size_t)l * R * 2 * NF * 64;
             if constexpr (NS) {
                 float *xb = xbuf + (size_t)(l & 1) * NW * XW;
-                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, (SHB && l >= sh_l0) ? hs_wave + (size_t)(l - sh_l0) * hs_layer : nullptr);
-                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr, psync, (SHB && l >= sh_l0) ? hs_wave + (size_t)(l - sh_l0) * hs_layer : nullptr);
+                if ((l + alt) & 1) layer_forward_ns<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr);
+                else layer_forward_ns<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, role, xb + wave * XW, xb + (wave ^ WV) * XW, xr, cr, ld, scr);
             } else {
                 if ((l + alt) & 1) layer_forward<NF, CQ, R, 1, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
                 else layer_forward<NF, CQ, R, 0, 2, ACT, BXF>(W, g, lane, xr, cr, ld, scr);
@@ -986,20 +831,14 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
             float *xo = NS ? xb + wave * XW : nullptr;
             const float *xp = NS ? xb + (wave ^ WV) * XW : nullptr;
             BwdPre<NF, CQ, R> nopre;            // (tile-split kernel only)
-            if (SHB && l >= sh_l0) {
-                const float *hsl = hs_wave + (size_t)(l - sh_l0) * hs_layer;
-                if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV, SHB>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, hsl);
-                else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV, SHB>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync, hsl);
-            } else {
-            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
-            else layer_bwd<NF, CQ, R, 0, NS, ACT, BX, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, prog, &prog_cnt, &fsync, &psync);
-            }
+            if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, NS, ACT, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, &fsync);
+            else layer_bwd<NF, CQ, R, 0, NS, ACT, WV>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, first, stp, xo, xp, 0, -1, nopre, false, nullptr, nullptr, &fsync);
         }
         if constexpr (NS) __syncthreads();      // exchange buffers are reused by the next group's first layer
         first = false;
     }
     if constexpr (NS == 1 || (kWideTFlush && NS == 0 && WV == 8)) {       // a wave of this workgroup gave up a bounded wait: the loss says so
-        if (__hip_atomic_load(prog + 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) wave_sum = __builtin_nanf("");
+        if (__hip_atomic_load(sync + 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) wave_sum = __builtin_nanf("");
     }
     if constexpr (WV > kWaves) {        // k_mfma_reduce adds kWaves loss partials per workgroup: fold the owners' sums, fixed order
         __syncthreads();
@@ -1026,14 +865,15 @@ __device__ __forceinline__ void train_body(const float *__restrict__ wp, const G
 
 // BXF (rnvp_shape.precision = RNVP_PREC_BX3, or AUTO where it resolves to BX3): GEMM1 of the FORWARD phase on split-bf16 MFMA
 // (rnvp_split.h); the backward keeps f32 -- its split operands do not fit in 256 registers next to the gradient state, and
-// the one-wave 512-register form that has the room is slower (k_mfma_train_bx below; profiles/r03_train_bx_ab.txt).
+// the one-wave 512-register form that has the room was slower in every A/B of round 3 (k_mfma_train_bx, removed from the tree
+// in round 6: profiles/r03_train_bx_ab.txt, r03_train_bx_experiments.txt and git history keep the record).
 // Measured (whole call, 65536 rows): C2 -1.5 %, C3 -2 %, C4 (NF = 8) +2 %: the wide geometry keeps f32 (train_bxf()).
 template <int NF, int CQ, int R, int NS, int ACT, bool BXF = false>
 __global__ void __launch_bounds__(kWaves * 64 * (1 + NS)) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_mfma_train(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
              const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
              float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
-    train_body<NF, CQ, R, NS, ACT, false, BXF>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
+    train_body<NF, CQ, R, NS, ACT, BXF>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
 }
 
 // Wide form: EIGHT row-owning waves per workgroup (no net split), one workgroup per CU.  Where a 65 536-row batch would
@@ -1046,31 +886,9 @@ __global__ void __launch_bounds__(kWideWaves * 64) __attribute__((amdgpu_waves_p
 k_mfma_train_wide(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
                   const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
                   float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
-    train_body<NF, CQ, R, 0, ACT, false, BXF, kWideWaves>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch,
+    train_body<NF, CQ, R, 0, ACT, BXF, kWideWaves>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch,
                                                           glayer_floats, sd);
 }
-
-// Split-GEMM1 form (BX, rnvp_split.h): GEMM1 of the forward phase, its recompute in the backward and g_h = W2^T g_out run on
-// v_mfma_f32_16x16x32_bf16 with three-term bf16 operands -- the products whose B operand is NOT a fresh activation (the
-// layer's inputs and g_out are split once per layer and row tile); GEMM2, the input gradient and the weight gradients keep
-// the f32 forms, because splitting a fresh tanh output costs the VALU more than the matrix pipe saves
-// (scripts/micro/unit_mix.hip, profiles/r03_micro_overlap.txt).  The split operands need 15-32 more registers per row tile,
-// so this form runs ONE wave per SIMD with the whole 512-entry register file (RNVP_BX_WPE 1): four waves per workgroup,
-// each with both nets of its R row tiles (no net split, no exchange through LDS).
-// NOT part of the product library: built only with -DRNVP_TRAIN_BX=1 (the A/B variant librnvp_hip_bxv.so of scripts/gpu_freeze.sh);
-// it lost every A/B of round 3 (profiles/r03_train_bx_experiments.txt) and is kept as the record of that negative result.
-#if RNVP_TRAIN_BX
-#ifndef RNVP_BX_WPE
-#define RNVP_BX_WPE 1
-#endif
-template <int NF, int CQ, int R, int ACT>
-__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_BX_WPE, RNVP_BX_WPE)))
-k_mfma_train_bx(const float *__restrict__ wp, Geo g, int L, int alt, const float *__restrict__ x,
-                const float *__restrict__ c, const int64_t *__restrict__ row_index, int64_t n, float inv_B,
-                float *gpart, float *losspart, float *scratch, int glayer_floats, Seeds sd) {
-    train_body<NF, CQ, R, 0, ACT, true>(wp, g, L, alt, x, c, row_index, n, inv_B, gpart, losspart, scratch, glayer_floats, sd);
-}
-#endif   // RNVP_TRAIN_BX
 
 
 // ---- tile-split step: batches of up to RNVP_TS_MAX_ROWS rows (d <= 16; half of that for wider rows) ------------------
@@ -1121,17 +939,13 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
     constexpr bool PRE = NF <= 4;
     TilePre<NF, CQ> pre;
     if (PRE && tile_hi > tile_lo) load_tile_pre<NF, CQ>(wp, g, lane, (wave >> 2) * g.HT + tile_lo, tile_hi - tile_lo, pre);
-    // RNVP_TS_SAVE_H: this wave's record [layer][its tiles][row tile][lane] f4
-    const size_t hs_layer = (size_t)tps * R * 256;
-    float *hs_wave = (kTsSaveH && sd.hsave) ? sd.hsave + ((size_t)blockIdx.x * kTsWaves + wave) * L * hs_layer : nullptr;
     for (int l = 0; l < L; ++l) {
         const float *W = wp + (size_t)l * g.layer_floats;
         const float *Wn = l + 1 < L ? W + g.layer_floats : nullptr;
         float *scr = scratch + (size_t)l * R * 2 * NF * 64;
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
-        float *hsl = kTsSaveH ? hs_wave + (size_t)l * hs_layer : nullptr;
-        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE, hsl);
-        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE, hsl);
+        if ((l + alt) & 1) layer_forward_ts<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE);
+        else layer_forward_ts<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, tile_lo, tile_hi - tile_lo, rb, xr, cr, ld, scr, Wn, pre, PRE);
     }
     __syncthreads();        // wave 0's scratch records; the rendezvous buffers change hands
     float wave_sum = 0.f;
@@ -1173,9 +987,8 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
         float *rb = red + (size_t)(l & 1) * kTsWaves * XW;
         const float *Wp = l > 0 ? W - g.layer_floats : nullptr;
         const float *sp = l > 0 ? scr - (size_t)R * 2 * NF * 64 : nullptr;
-        const float *hsl = kTsSaveH ? hs_wave + (size_t)l * hs_layer : nullptr;
-        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT, false, kWaves, kTsSaveH>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp, nullptr, nullptr, nullptr, nullptr, hsl);
-        else layer_bwd<NF, CQ, R, 0, 2, ACT, false, kWaves, kTsSaveH>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp, nullptr, nullptr, nullptr, nullptr, hsl);
+        if ((l + alt) & 1) layer_bwd<NF, CQ, R, 1, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp);
+        else layer_bwd<NF, CQ, R, 0, 2, ACT>(W, g, lane, wave, xr, cr, gy, gld, scr, lds, tb, gpl, true, stp, rb + wave * XW, rb, tile_lo, tile_hi, bpre, have_tiles, Wp, sp);
     }
     if (sd.gx && wave == 0) {                   // rnvp_backward: d loss / d x (every wave holds the same sums)
         const bool fullg = (g.d == D) && ((uintptr_t)sd.gx & 15) == 0;
@@ -1307,26 +1120,6 @@ int launch_train_ts(hipStream_t st, const KShape &k, const Geo &g, const TrainPl
 }
 
 
-#if RNVP_TRAIN_BX
-template <int NF, int CQ, int R, int ACT>
-int launch_train_bx(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed, const float *x,
-                    const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart, float *losspart,
-                    float *scratch, int grid, size_t lds_bytes, Seeds sd) {
-    auto kern = k_mfma_train_bx<NF, CQ, R, ACT>;
-    static std::atomic<uint64_t> attr_done{0};
-    const int arc = allow_big_lds(reinterpret_cast<const void *>(kern), 160 * 1024, attr_done);
-    if (arc) return arc;
-    note_dispatch(RNVP_PROFILE_TRAIN, "k_mfma_train_bx", RNVP_VARIANT_ROWPAR, R, kWaves, grid, RNVP_PREC_BX3, n);
-    {
-        const KernelEvents ev(RNVP_PROFILE_TRAIN);
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds_bytes, st, ev.start, ev.stop, 0, packed, g, k.L, k.alt, x,
-                              c, row_index, n, inv_B, gpart, losspart, scratch, pl.glayer_floats, sd);
-    }
-    RNVP_HIP_TRY(hipGetLastError());
-    return RNVP_OK;
-}
-#endif   // RNVP_TRAIN_BX
-
 template <int NF, int CQ, int R>
 int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan &pl, const float *packed,
                    const float *x, const float *c, const int64_t *row_index, int64_t n, float inv_B, float *gpart,
@@ -1339,17 +1132,6 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     const size_t per_wave = (size_t)DM::template slot<0>() + DM::template tbn<R, 0>();
     TrainPlan p0 = pl;                                   // partial layout of the launches without net split
     p0.glayer_floats = 2 * g.HT * DM::template tblk<0>() + DM::NT2 * 16;
-#if RNVP_TRAIN_BX
-    if (kTrainBx && g.NI1 > 0 && !(RNVP_NET_SPLIT && kTrainBxNsFirst && ngroups <= 256)) {          // split-GEMM1 form (the packed block carries its fragments)
-        lay->w2c = DM::template w2c<0>() ? 1 : 0;
-        lay->glayer_floats = p0.glayer_floats;
-        if (k.act == RNVP_ACT_TANH)
-            return launch_train_bx<NF, CQ, R, 0>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                                 kWaves * per_wave * sizeof(float) + kSyncBytes, sd);
-        return launch_train_bx<NF, CQ, R, 1>(st, k, g, p0, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, grid,
-                                             kWaves * per_wave * sizeof(float) + kSyncBytes, sd);
-    }
-#endif
     const size_t per_wave_ns = (size_t)DM::template slot<1>() + DM::template tbn<R, 1>();
     // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
     // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
@@ -1364,7 +1146,8 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     }
     lay->w2c = DM::template w2c<0>() ? 1 : 0;
     lay->glayer_floats = p0.glayer_floats;
-    if constexpr (kTrainWide && (NF == 4 || (NF == 8 && RNVP_TRAIN_WIDE8))) {       // d > 16: two 4-wave workgroups per CU become one 8-wave workgroup
+    if constexpr (kTrainWide && NF == 4) {       // d in (16, 32]: two 4-wave workgroups per CU become one 8-wave workgroup (d = 64: built, 147 KB of LDS,
+                                                 // measured 1.206-1.214 against 1.212-1.222 ms at 65 536 rows and slower at 262 144: not taken)
         const size_t lds_wide = kWideWaves * per_wave * sizeof(float) + kSyncBytes;
         if (ngroups > 256 && lds_wide <= 160 * 1024) {
             const int64_t rows_wide = (int64_t)kWideWaves * R * 16;

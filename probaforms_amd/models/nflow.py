@@ -342,6 +342,9 @@ class NormalizingFlow(nn.Module):
     # prior) / 33 ms (host prior) against 9.4 / 60 ms one-shot with a pageable download.
     PIPELINE_CHUNK_BYTES = 8 << 20
     PIPELINE_MIN_ROWS = 131072
+    ONE_SHOT_UPLOAD_BYTES = 2 << 30        # conditions larger than this (at their source width) are staged chunk by chunk
+    _UPLOAD_DTYPES = frozenset(__import__("numpy").dtype(t) for t in
+                               ("float16", "float32", "float64", "int8", "int16", "int32", "int64", "uint8", "bool"))
 
     def pipelined_rows(self, n):
         """rows per chunk (a multiple of 16, see row_chunks) if sample_to_host() would pipeline n rows, else 0"""
@@ -367,7 +370,12 @@ class NormalizingFlow(nn.Module):
             Cd = C.to(dev, torch.float32).contiguous() if on_dev else None
             Cn = None if on_dev else (C.detach().numpy() if torch.is_tensor(C) else np.asarray(C))
         rows = self.pipelined_rows(n)
-        if rows and Cn is not None and Cn.dtype.kind in "fiub" and Cn.flags.c_contiguous:
+        # (only dtypes torch.from_numpy takes -- numpy's longdouble / float128, uint16..64 on older builds and structured types keep
+        # the chunked numpy staging below, whose casting='unsafe' copy accepts them all -- and only while the whole array at its
+        # SOURCE width is a modest share of the device: a very large draw stays on bounded per-chunk staging)
+        one_shot = (rows and Cn is not None and Cn.flags.c_contiguous and Cn.flags.writeable
+                    and Cn.dtype in self._UPLOAD_DTYPES and Cn.nbytes <= self.ONE_SHOT_UPLOAD_BYTES)
+        if one_shot:
             # ONE pageable upload through the runtime's own staging (tens of GB/s on these hosts) and the float32 cast ON THE DEVICE
             # (the same round-to-nearest as the host cast; what RealNVP.fit does with X and C) instead of a single-threaded numpy
             # copy / cast into pinned memory per chunk -- that copy, not the GPU, bounded the call (16 MB of float32 conditions:
@@ -377,7 +385,8 @@ class NormalizingFlow(nn.Module):
         if rows == 0:
             if Cn is not None:
                 Cd = self._on_device(torch.from_numpy(np.ascontiguousarray(Cn)), eng)
-            return self.sample(n if Cd is None else Cd).cpu().detach().numpy()
+            with torch.no_grad():       # the result is detached on this very line (realnvp.py:280): record no graph, keep the fused-prior path
+                return self.sample(n if Cd is None else Cd).cpu().numpy()
         d = self.prior.var_size
         cdim = 0 if type(C) == type(1) else C.shape[1]
         host_rng = self.prior.host_rng

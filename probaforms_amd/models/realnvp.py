@@ -25,7 +25,7 @@ def _to_device_f32(a, device):
     a = np.asarray(a)
     if a.ndim > 0 and not a.flags.c_contiguous:
         a = np.ascontiguousarray(a)              # (a 0-d input stays 0-d: len() then raises TypeError as in the reference)
-    if a.dtype.kind not in "fiub":
+    if a.dtype.kind not in "fiub" or a.dtype.itemsize > 8:      # (numpy's longdouble: a width torch.from_numpy does not take)
         a = a.astype(np.float64)
     return torch.from_numpy(a).to(device).to(torch.float32).contiguous()
 

@@ -151,7 +151,7 @@ def test_load_reference_weights_and_compare_logprob(name):
     assert np.array_equal(lp, lp2)
 
 
-@pytest.mark.parametrize("cond", ["float64", "none", "device", "float32"])
+@pytest.mark.parametrize("cond", ["float64", "none", "device", "float32", "longdouble", "readonly", "int32"])
 @pytest.mark.parametrize("prior_rng", ["host", "device"])
 def test_pipelined_sample_equals_one_shot(cond, prior_rng):
     """the chunked prior/H2D | kernel | D2H pipeline returns what the one-shot
@@ -163,8 +163,12 @@ def test_pipelined_sample_equals_one_shot(cond, prior_rng):
     m = RealNVP(n_epochs=1, prior_rng=prior_rng)
     torch.manual_seed(1)
     m.fit(X, None if cond == "none" else Cfit)
+    # longdouble: a dtype torch.from_numpy refuses; readonly: an array it warns about -- both take the chunked numpy staging
+    ro = rng.standard_normal((n, c)); ro.setflags(write=False)
     C = {"float64": rng.standard_normal((n, c)), "float32": rng.standard_normal((n, c)).astype(np.float32),
-         "none": n, "device": torch.as_tensor(rng.standard_normal((n, c)), dtype=torch.float32).cuda()}[cond]
+         "none": n, "device": torch.as_tensor(rng.standard_normal((n, c)), dtype=torch.float32).cuda(),
+         "longdouble": rng.standard_normal((n, c)).astype(np.longdouble), "readonly": ro,
+         "int32": rng.integers(-3, 4, size=(n, c)).astype(np.int32)}[cond]
     assert m.nf.pipelined_rows(n) == 0
     torch.manual_seed(7)
     one = m.sample(C)
