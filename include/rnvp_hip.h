@@ -250,8 +250,10 @@ int rnvp_backward(void *stream, const rnvp_shape *shape,
  * `torch.cat((X * mask, C), dim=1)` (realnvp.py:92) and receives a gradient whenever it requires one -- a learned condition
  * encoder in a user's own training loop.
  *   gc_out [n_rows, c]  d loss / d c[r]   (nullable; ignored when shape->c == 0)       the other arguments as rnvp_backward.
- * Served by the any-shape 16-row MFMA kernel for every shape whose tile image fits a CU's LDS (RNVP_EUNSUPPORTED otherwise),
- * whatever rnvp_shape::family says; workspace: rnvp_backward_cond_workspace_bytes(shape, n_rows).  Deterministic (no float
+ * Served by the any-shape 16-row MFMA kernel for every shape whose tile image fits its LDS budget, whatever
+ * rnvp_shape::family says, and by the one-thread-per-row VALU kernel behind it (since round 6: e.g. hidden = (512,) on 16-d
+ * rows; RNVP_EUNSUPPORTED only where even an 8-row tile of that kernel exceeds a CU's LDS, e.g. hidden = (2048, 2048));
+ * workspace: rnvp_backward_cond_workspace_bytes(shape, n_rows), 0 for a shape no kernel serves.  Deterministic (no float
  * atomics).
  */
 size_t rnvp_backward_cond_workspace_bytes(const rnvp_shape *shape, int64_t max_rows);

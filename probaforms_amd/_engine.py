@@ -627,12 +627,13 @@ class FlowEngine:
 
 
 def _cond_workspace(engine, rows):
-    """workspace of rnvp_backward_cond / rnvp_inverse_backward for `rows` rows (the any-shape 16-row kernel, whatever family
-    serves the flow otherwise); raises where that kernel cannot take the shape"""
+    """workspace of rnvp_backward_cond / rnvp_inverse_backward for `rows` rows (the any-shape 16-row MFMA kernel, whatever
+    family serves the flow otherwise; the one-thread-per-row VALU kernel for the shapes whose tile image that kernel cannot
+    hold); raises where no kernel can take the shape"""
     nb = _hip.backward_cond_workspace_bytes(engine.shape, max(int(rows), 1))
     if nb == 0:
-        raise RuntimeError("the gradient with respect to the conditions and the backward through g / sample run on the "
-                           "any-shape 16-row kernel, whose LDS tile image (76 KB) this flow's hidden sizes exceed")
+        raise RuntimeError("the gradient with respect to the conditions and the backward through g / sample: this flow's "
+                           "hidden sizes exceed a CU's LDS even for an 8-row tile of the one-thread-per-row kernel")
     # kept on the engine like the other operations' workspaces (grown, never shrunk): a user's training loop calls this every step
     ws = getattr(engine, "_ws_cond", None)
     if ws is None:

@@ -342,7 +342,7 @@ def backward(shape, params, masks, x, c, row_index, n_rows, gz, gld, grad_out, g
 
 
 def backward_cond_workspace_bytes(shape, max_rows):
-    """bytes rnvp_backward_cond / rnvp_inverse_backward need; 0 when the shape's tile image does not fit the any-shape kernel"""
+    """bytes rnvp_backward_cond / rnvp_inverse_backward need; 0 when no kernel serves the shape (hidden sizes beyond a CU's LDS)"""
     return int(lib().rnvp_backward_cond_workspace_bytes(C.byref(shape), int(max_rows)))
 
 

@@ -264,10 +264,25 @@ static int cond_kshape(const rnvp_shape *shape, bool want_gc, KShape *k) {
     k->gcw = (want_gc && k->c > 0) ? 1 : 0;
     return lmm::use_lmm(*k, RNVP_OP_TRAIN) ? RNVP_OK : RNVP_EUNSUPPORTED;
 }
+// ... and behind it, for the shapes whose 16-row tile image exceeds the LDS budget of that kernel (e.g. hidden = (512,) on
+// C2-sized rows), the one-thread-per-row VALU kernel (rnvp_generic.hip), which carries the same seeds: slow, but the seam has
+// no shape hole (the reference differentiates any shape: realnvp.py:92,120-129, nflow.py:141-145)
+static int cond_kshape_any(const rnvp_shape *shape, bool want_gc, KShape *k, bool *valu) {
+    *valu = false;
+    int rc = cond_kshape(shape, want_gc, k);
+    if (rc != RNVP_EUNSUPPORTED) return rc;
+    rc = make_kshape(shape, k);
+    if (rc) return rc;
+    k->gcw = (want_gc && k->c > 0) ? 1 : 0;
+    *valu = true;
+    return generic_workspace_bytes(*k, RNVP_OP_TRAIN, 1) > 0 ? RNVP_OK : RNVP_EUNSUPPORTED;
+}
 
 size_t rnvp_backward_cond_workspace_bytes(const rnvp_shape *shape, int64_t max_rows) {
     KShape k;
-    if (cond_kshape(shape, true, &k) != RNVP_OK) return 0;
+    bool valu;
+    if (cond_kshape_any(shape, true, &k, &valu) != RNVP_OK) return 0;
+    if (valu) return generic_workspace_bytes(k, RNVP_OP_TRAIN, max_rows < 1 ? 1 : max_rows) + 256;
     return lmm::workspace_bytes(k, RNVP_OP_TRAIN, max_rows < 1 ? 1 : max_rows) + 256;
 }
 
@@ -275,7 +290,8 @@ static int cond_backward(void *stream, const rnvp_shape *shape, const float *par
                          const float *c, const int64_t *row_index, int64_t n_rows, Seeds sd, float *grad_out, void *workspace,
                          size_t workspace_bytes) {
     KShape k;
-    int rc = cond_kshape(shape, sd.gc != nullptr, &k);
+    bool valu;
+    int rc = cond_kshape_any(shape, sd.gc != nullptr, &k, &valu);
     if (rc) return rc;
     if (n_rows < 0 || !grad_out) return RNVP_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -285,6 +301,8 @@ static int cond_backward(void *stream, const rnvp_shape *shape, const float *par
     }
     if (!masks || bad_ptrs(k, params, masks, rows, c)) return RNVP_EINVAL;
     if (k.c == 0) sd.gc = nullptr;
+    if (valu)
+        return generic_loss_grad(st, k, params, masks, rows, c, row_index, n_rows, 0.0f, grad_out, nullptr, workspace, workspace_bytes, sd);
     return lmm::loss_grad(st, k, params, masks, rows, c, row_index, n_rows, 0.0f, grad_out, nullptr, workspace, workspace_bytes, sd);
 }
 

@@ -138,6 +138,12 @@ k_generic_inverse(KShape s, const float *__restrict__ params, const uint8_t *__r
 }
 
 // ---- loss + gradient (realnvp.py:246-250; backward derived in SURVEY.md 3.3) ---------------
+// Seeds (rnvp_common.h) select the differentiable-seam variants: gz / gld / gx (rnvp_backward), gc with KShape::gcw (the
+// conditions' gradient: rnvp_backward_cond -- they enter every net through torch.cat((X * mask, C)), realnvp.py:92), and inv
+// (rnvp_inverse_backward: the rows are z; phase 1 runs the INVERSE, realnvp.py:120-128 / nflow.py:141-145, saving behind each
+// layer the input of f's layer l; phase 2 walks the layers 0 .. L-1 -- the order in which g applied them last to first -- with
+// d/dt = -g_x e^{-s}, d/ds = -g_x x_u as the nets' output gradients and g_y = g_x e^{-s} as the chain; no loss term).  These
+// serve the shapes whose tile image the any-shape MFMA kernel (rnvp_lmm.hip) cannot hold.
 __global__ void __launch_bounds__(256)
 k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__restrict__ masks,
                 const float *__restrict__ x, const float *__restrict__ c,
@@ -156,7 +162,10 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
     float *gin = gxb + d * TBP;
     float *gA = gin + d * TBP;
     float *gB = gA + s.wmax * TBP;
-    float *red = gB + s.wmax * TBP;
+    float *gcb = gB + s.wmax * TBP;                          // [cd][TBP]: d loss / d c of the tile's rows (KShape::gcw only)
+    float *red = gcb + (s.gcw ? cd : 0) * TBP;
+    float *const gcond = (s.gcw && cd > 0) ? gcb : nullptr;
+    const bool inv = sd.inv != 0;
     const size_t P = (size_t)2 * s.npn * s.L;
     float *gp = gpart + (size_t)blockIdx.x * P;
     float *xs = xsave + (size_t)blockIdx.x * s.L * d * TB;
@@ -173,7 +182,20 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
             for (int j = 0; j < d; ++j) xcur[j * TBP + t] = valid ? x[src * d + j] : 0.f;
             for (int j = 0; j < cd; ++j) uin[(d + j) * TBP + t] = valid ? c[src * cd + j] : 0.f;
             float ld = 0.f;
-            for (int l = 0; l < s.L; ++l) {
+            if (gcond)
+                for (int j = 0; j < cd; ++j) gcond[j * TBP + t] = 0.f;
+            for (int l = s.L - 1; inv && l >= 0; --l) {      // x = g(z, c), keeping every layer's OUTPUT (= the input of f's layer l)
+                const uint8_t *m = masks + l * d;
+                const float *pl = params + (size_t)l * 2 * s.npn;
+                for (int j = 0; j < d; ++j) uin[j * TBP + t] = xcur[j * TBP + t] * (float)m[j];
+                net_forward<false>(pl, s, uin, gA, gB, tout, TBP, t);
+                net_forward<false>(pl + s.npn, s, uin, gA, gB, sout, TBP, t);
+                for (int j = 0; j < d; ++j) {
+                    if (!m[j]) xcur[j * TBP + t] = (xcur[j * TBP + t] - tout[j * TBP + t]) * expf(-sout[j * TBP + t]);
+                    xs[(l * d + j) * TB + t] = xcur[j * TBP + t];
+                }
+            }
+            for (int l = 0; !inv && l < s.L; ++l) {
                 const uint8_t *m = masks + l * d;
                 const float *pl = params + (size_t)l * 2 * s.npn;
                 for (int j = 0; j < d; ++j) {
@@ -193,7 +215,7 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
             }
             float ss = 0.f;
             for (int j = 0; j < d; ++j) { const float zv = xcur[j * TBP + t]; ss = fmaf(zv, zv, ss); }
-            lp = gz ? ld : ld + (-0.5f * ss - prior_c);
+            lp = inv ? 0.f : (gz ? ld : ld + (-0.5f * ss - prior_c));
             // seed: d(-mean logp)/dz = z / B   (zero for padding rows); with gz the caller's d loss / d z (another prior)
             for (int j = 0; j < d; ++j)
                 gy[j * TBP + t] = valid ? (gz ? gz[row * d + j] : xcur[j * TBP + t] * inv_B) : 0.f;
@@ -202,7 +224,8 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
         __syncthreads();
         if (t == 0) { float a = 0.f; for (int r = 0; r < TB; ++r) a += red[r]; block_sum += a; }
         const float gld = valid ? (sd.gld ? sd.gld[row] : -inv_B) : 0.f;      // d loss / d log_det (rnvp_backward: the caller's)
-        for (int l = s.L - 1; l >= 0; --l) {
+        for (int li = 0; li < s.L; ++li) {
+            const int l = inv ? li : s.L - 1 - li;
             const uint8_t *m = masks + l * d;
             const float *pl = params + (size_t)l * 2 * s.npn;
             float *gl = gp + (size_t)l * 2 * s.npn;
@@ -216,7 +239,10 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
                 net_forward<true>(pl + s.npn, s, uin, acts, nullptr, sout, TBP, t);     // nn_s
                 for (int j = 0; j < d; ++j) {
                     const float g = gy[j * TBP + t];
-                    if (!m[j]) {
+                    if (!m[j] && inv) {           // through g: y_u -> x_u = (y_u - t) e^{-s}; xcur holds x_u
+                        gxb[j * TBP + t] = g * expf(-sout[j * TBP + t]);
+                        gA[j * TBP + t] = -g * xcur[j * TBP + t];
+                    } else if (!m[j]) {
                         const float es = expf(sout[j * TBP + t]);
                         gxb[j * TBP + t] = g * es;
                         gA[j * TBP + t] = fmaf(g * xcur[j * TBP + t], es, gld);
@@ -226,18 +252,21 @@ k_generic_train(KShape s, const float *__restrict__ params, const uint8_t *__res
                     }
                 }
             }
-            net_backward(pl + s.npn, gl + s.npn, s, uin, acts, gA, gB, gin, TB, TBP, t, nthreads, first);
+            net_backward(pl + s.npn, gl + s.npn, s, uin, acts, gA, gB, gin, TB, TBP, t, nthreads, first, gcond);
             if (t < TB) {
                 net_forward<true>(pl, s, uin, acts, nullptr, tout, TBP, t);             // nn_t
-                for (int j = 0; j < d; ++j) gA[j * TBP + t] = m[j] ? 0.f : gy[j * TBP + t];
+                for (int j = 0; j < d; ++j)
+                    gA[j * TBP + t] = m[j] ? 0.f : (inv ? -gy[j * TBP + t] * expf(-sout[j * TBP + t]) : gy[j * TBP + t]);
             }
-            net_backward(pl, gl, s, uin, acts, gA, gB, gin, TB, TBP, t, nthreads, first);
+            net_backward(pl, gl, s, uin, acts, gA, gB, gin, TB, TBP, t, nthreads, first, gcond);
             if (t < TB)
                 for (int j = 0; j < d; ++j)
                     gy[j * TBP + t] = gxb[j * TBP + t] + (m[j] ? gin[j * TBP + t] : 0.f);
         }
-        if (sd.gx && valid)                                           // rnvp_backward: d loss / d x of the batch rows
+        if (sd.gx && valid)                                           // rnvp_backward: d loss / d x of the batch rows (inv: d loss / d z)
             for (int j = 0; j < d; ++j) sd.gx[row * d + j] = gy[j * TBP + t];
+        if (sd.gc && gcond && valid)
+            for (int j = 0; j < cd; ++j) sd.gc[row * cd + j] = gcond[j * TBP + t];
         first = false;
         __syncthreads();
     }
@@ -258,7 +287,7 @@ k_reduce_grad(const float *__restrict__ gpart, const float *__restrict__ losspar
 
 size_t lds_floats_per_row(const KShape &k, int op) {
     if (op == RNVP_OP_TRAIN)
-        return (size_t)k.d + (k.d + k.c) + k.hs + 2 * k.d + 3 * k.d + 2 * k.wmax;
+        return (size_t)k.d + (k.d + k.c) + k.hs + 2 * k.d + 3 * k.d + 2 * k.wmax + (k.gcw ? k.c : 0);
     return (size_t)k.d + (k.d + k.c) + 2 * k.hmax + 2 * k.d;
 }
 

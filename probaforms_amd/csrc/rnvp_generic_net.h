@@ -61,10 +61,12 @@ static __device__ void net_forward(const float *__restrict__ p, const KShape &s,
 // gA holds d(loss)/d(net output) [d][TBP] on entry.  Weight/bias gradients are summed over the
 // tile's rows by a "thread = parameter" sweep and stored (first tile) or added into the
 // block-private partial gp (same layout as one net's parameters).  d(loss)/d(net input) for
-// the x part is ADDED into gin [d][TBP].  Uniform control flow: contains barriers.
+// the x part is ADDED into gin [d][TBP]; with gcond (nullable: [nin[0] - d][TBP]) the part for the
+// remaining input columns -- the conditions, realnvp.py:92 -- is ADDED into gcond as well.
+// Uniform control flow: contains barriers.
 static __device__ void net_backward(const float *__restrict__ p, float *gp, const KShape &s,
                              const float *uin, const float *acts, float *gA, float *gB, float *gin,
-                             int TB, int TBP, int t, int nthreads, bool first) {
+                             int TB, int TBP, int t, int nthreads, bool first, float *gcond = nullptr) {
     float *gcur = gA, *gprev = gB;
     int aoff = s.hs;   // running offset (in features) of Linear k's own activation block
     for (int k = s.nh; k >= 0; --k) {
@@ -95,10 +97,11 @@ static __device__ void net_backward(const float *__restrict__ p, float *gp, cons
             for (int r = 0; r < TB; ++r) a += gq[r];
             gb[q] = first ? a : gb[q] + a;
         }
-        // input gradient: thread = row.  For Linear 0 only the x part is needed (C gets none).
+        // input gradient: thread = row.  For Linear 0 only the x part is needed (C gets none) unless the caller asked for
+        // the conditions' gradient (gcond).
         if (t < TB) {
             const float *__restrict__ W = p + s.woff[k];
-            const int ni = (k == 0) ? s.d : nin;
+            const int ni = (k == 0) ? (gcond ? nin : s.d) : nin;
             float *dst = (k == 0) ? gin : gprev;
             for (int i = 0; i < ni; i += 4) {
                 const int i1 = min(i + 1, ni - 1), i2 = min(i + 2, ni - 1), i3 = min(i + 3, ni - 1);
@@ -110,10 +113,11 @@ static __device__ void net_backward(const float *__restrict__ p, float *gp, cons
                     a2 = fmaf(g, w[i2], a2); a3 = fmaf(g, w[i3], a3);
                 }
                 if (k == 0) {
-                    dst[i * TBP + t] += a0;
-                    if (i + 1 < ni) dst[(i + 1) * TBP + t] += a1;
-                    if (i + 2 < ni) dst[(i + 2) * TBP + t] += a2;
-                    if (i + 3 < ni) dst[(i + 3) * TBP + t] += a3;
+                    const float av[4] = {a0, a1, a2, a3};
+                    for (int u = 0; u < 4 && i + u < ni; ++u) {
+                        if (i + u < s.d) dst[(i + u) * TBP + t] += av[u];
+                        else gcond[(i + u - s.d) * TBP + t] += av[u];
+                    }
                 } else {
                     dst[i * TBP + t] = a0;
                     if (i + 1 < ni) dst[(i + 1) * TBP + t] = a1;

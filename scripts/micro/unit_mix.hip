@@ -19,6 +19,8 @@ __device__ __forceinline__ f4 mfma32(u4 a, u4 b, f4 c) {
 }
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+using f16v = __attribute__((ext_vector_type(16))) float;
+__device__ __forceinline__ f16v mfma32x2(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ f4 tanh4(f4 u) {
     f2 e0, e1;
@@ -69,6 +71,7 @@ __device__ __forceinline__ u2 tr_read(const unsigned short *p) {
     return __builtin_bit_cast(u2, r);
 }
 
+constexpr int kBinPair = 5 * 4 * 1024;      // LDS-resident split inputs of V10 / V13: 5 u4 x 64 lanes x 4 row tiles, shared by the waves w and w + 4 (one row-tile set per pair, as in the net-split kernel)
 constexpr int PS = 20;        // row stride (16-bit elements) of a transposition plane: 40 B
 constexpr int kTS = 20;
 
@@ -76,6 +79,12 @@ constexpr int kTS = 20;
 //    2 bx3 backward unit with dW2 on the f32 4x4x1 form                3 f32 forward unit   4 bx3 GEMM1 + f32 4x4x1 GEMM2
 //    5 all-bx3 forward unit     6: V1 without the weight-gradient products   7: V1 without any LDS traffic (operands reused)
 //    8: V1 MFMAs only (no tanh / split)  9: V1 VALU only (no MFMAs)
+// round 6:
+//   10: V0 with the GEMM1 recompute on split-bf16, its split inputs READ FROM LDS (3 ds_read_b128 per row tile and hidden tile)
+//   11: V0 with the 4x4x1 products (g_in, dW2) as 16x16x4 products instead (half of each tile structural zeros)
+//   12: V3 (forward) with GEMM1 as v_mfma_f32_32x32x2_f32 over 2 hidden tiles x 2 row tiles (6 instructions per 4 units)
+//   13: V10 with g_h = W2^T g_out on split-bf16 from LDS as well (2 more ds_read_b128)
+//   14: V10 with the LDS reads of row tile rt + 1 requested before row tile rt's products (two fragment sets in registers)
 template <int V, int R, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4)))
 k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long long *clk) {
@@ -88,6 +97,7 @@ k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long
     float *bufP = bufH + 16 * kTS;
     float *bufG = bufP + 16 * kTS;
     u4 *opsT = reinterpret_cast<u4 *>(wl + 4096 + 3 * 16 * kTS * 4);                // inT / goutT operands: 6 x 64 u4 = 6 KB?  (kept small: 1 KB reused)
+    u4 *binL = reinterpret_cast<u4 *>(lds_raw + WAVES * 8192 + (wave & 3) * kBinPair);   // V10 / V13: [row tile][5][lane] u4
     // per-row-tile persistent state
     u4 bin[R][3], gob[R][2];
     f4 gin[R], acc_out[R];
@@ -101,6 +111,14 @@ k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long
 #pragma unroll
         for (int i = 0; i < 4; ++i) go[rt][i] = 0.001f * (lane + i);
         gin[rt] = f4{0, 0, 0, 0}; acc_out[rt] = f4{0, 0, 0, 0};
+    }
+    u4 bpipe[2][3];
+    if constexpr (V == 10 || V == 13 || V == 14) {
+#pragma unroll
+        for (int i = 0; i < 5 * R; ++i) binL[i * 64 + lane] = u4{0x3f803f80u + lane + i, 0x3f003f80u, 0x3e803f80u + i, 0x3f803e00u};
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { bpipe[0][i] = binL[i * 64 + lane]; bpipe[1][i] = bpipe[0][i]; }
     }
     f4 gW1 = f4{0, 0, 0, 0}, gW2 = f4{0, 0, 0, 0}, gW2b = f4{0, 0, 0, 0};
     unsigned long long t0 = 0, t1 = 0, rt0 = 0, rt1 = 0;
@@ -118,7 +136,26 @@ k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long
             for (int i = 0; i < NFR; ++i) nf[i] = *opaque(wp + ((size_t)nx * NFR + i) * 256);
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
-                if constexpr (V == 3 || V == 4 || V == 5) {
+                if constexpr (V == 12) {
+                    // ---- forward, GEMM1 on 32x32x2: 2 hidden tiles x 2 row tiles per 6 instructions (the other three visits of the
+                    //      2 x 2 block do nothing: same unit count per wave as the other variants)
+                    if ((t & 1) == 0 && (rt & 1) == 0) {
+                        f16v a16;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) a16[i] = 0.f;
+#pragma unroll
+                        for (int kk = 0; kk < 6; ++kk) a16 = mfma32x2(__uint_as_float(fr[kk >> 2][kk & 3]), xin[rt][kk % 3] + kk, a16);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const f4 hv = tanh4(f4{a16[4 * u], a16[4 * u + 1], a16[4 * u + 2], a16[4 * u + 3]});
+#pragma unroll
+                            for (int rho = 0; rho < 4; ++rho) {
+                                acc_out[rt + (u & 1)] = mfma4(__uint_as_float(fr[3][rho]), hv[rho], acc_out[rt + (u & 1)]);
+                                gin[rt + (u & 1)] = mfma4(__uint_as_float(fr[4][rho]), hv[rho], gin[rt + (u & 1)]);
+                            }
+                        }
+                    }
+                } else if constexpr (V == 3 || V == 4 || V == 5) {
                     // ---- forward unit: GEMM1 -> tanh -> GEMM2
                     f4 acc = f4{0, 0, 0, 0};
                     if constexpr (V == 3) {
@@ -141,23 +178,53 @@ k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long
                             gin[rt] = mfma4(__uint_as_float(fr[4][rho]), hv[rho], gin[rt]);
                         }
                     }
-                } else if constexpr (V == 0) {
+                } else if constexpr (V == 0 || V == 10 || V == 11 || V == 13 || V == 14) {
                     // ---- f32 backward unit
                     f4 acc = f4{0, 0, 0, 0}, gh = f4{0, 0, 0, 0};
+                    if constexpr (V == 14) {
+                        // bpipe[rt & 1] was requested one row tile ago; request the next row tile's now (the split inputs do not
+                        // depend on the hidden tile: after the last row tile comes the first one again)
+                        const int nrt = (rt + 1) % R;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) bpipe[(rt + 1) & 1][i] = binL[(nrt * 5 + i) * 64 + lane];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc = mfma32(fr[4 + i], bpipe[rt & 1][i], acc);
+                    } else if constexpr (V == 10 || V == 13) {
+                        u4 b[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) b[i] = binL[(rt * 5 + i) * 64 + lane];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc = mfma32(fr[4 + i], b[i], acc);
+                    } else {
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk) acc = mfma16(__uint_as_float(fr[0][kk]), xin[rt][kk], acc);
+                    }
+                    if constexpr (V == 13) {
+                        u4 b[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) b[i] = binL[(rt * 5 + 3 + i) * 64 + lane];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) gh = mfma32(fr[(7 + i) & 7], b[i], gh);
+                    } else {
 #pragma unroll
                     for (int v = 0; v < 2; ++v) gh = mfma16(__uint_as_float(fr[1][v]), go[rt][v], gh);
+                    }
                     const f4 hv = tanh4(acc);
                     const f4 gp = gh * (1.0f - hv * hv);
                     wave_lds_fence();
                     *reinterpret_cast<f4 *>(bufH + r * kTS + 4 * q) = hv;
                     *reinterpret_cast<f4 *>(bufP + r * kTS + 4 * q) = gp;
                     wave_lds_fence();
+                    if constexpr (V == 11) {
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho) gin[rt] = mfma16(__uint_as_float(fr[2][rho]), gp[rho], gin[rt]);
+                    } else {
 #pragma unroll
                     for (int rho = 0; rho < 4; ++rho) {
                         gin[rt] = mfma4(__uint_as_float(fr[2][rho]), gp[rho], gin[rt]);
                         acc_out[rt] = mfma4(__uint_as_float(fr[3][rho]), gp[rho], acc_out[rt]);
+                    }
                     }
                     float hT[4], pT[4]; f2 gB[4];
 #pragma unroll
@@ -168,8 +235,12 @@ k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long
                     }
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
+                        if constexpr (V == 11) {
+                            gW2 = mfma16(hT[ks], gB[ks].x, gW2);
+                        } else {
                         gW2 = mfma4(hT[ks], gB[ks].x, gW2);
                         gW2b = mfma4(hT[ks], gB[ks].y, gW2b);
+                        }
                         gW1 = mfma16(pT[ks], xin[rt][ks & 1] + ks, gW1);
                     }
                 } else {
@@ -279,13 +350,15 @@ k(const unsigned *__restrict__ w, float *out, int tiles, int reps, unsigned long
 template <int V, int R, int WAVES> void run(const unsigned *w, float *d, unsigned long long *clk, const char *name) {
     const int tiles = 64, reps = 41;
     auto kern = k<V, R, WAVES>;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * 8192);
+    const int lds_bytes = WAVES * 8192 + ((V == 10 || V == 13 || V == 14) ? 4 * kBinPair : 0);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), WAVES * 8192, 0, w, d, tiles, 3, clk);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds_bytes, 0, w, d, tiles, 3, clk);
+    { const hipError_t le = hipDeviceSynchronize() == hipSuccess ? hipGetLastError() : hipErrorUnknown; if (le != hipSuccess) { printf("  %-58s LAUNCH FAILED: %s\n", name, hipGetErrorString(le)); return; } }
     float best = 1e9f;
     for (int i = 0; i < 3; ++i) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), WAVES * 8192, 0, w, d, tiles, reps, clk);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds_bytes, 0, w, d, tiles, reps, clk);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -318,6 +391,14 @@ int main() {
     run<7, 4, 8>(w, d, clk, "bwd all bx3 without LDS traffic");
     run<8, 4, 8>(w, d, clk, "bwd all bx3, MFMAs + LDS only");
     run<9, 4, 8>(w, d, clk, "bwd all bx3, VALU + LDS only");
+    printf("-- round 6: the levers VERDICT r05 item 1 names, priced\n");
+    run<0, 4, 8>(w, d, clk, "bwd f32 (as rnvp_mfma_train)                         [V0]");
+    run<10, 4, 8>(w, d, clk, "bwd f32, GEMM1 recompute on bx3 from LDS            [V10]");
+    run<13, 4, 8>(w, d, clk, "bwd f32, GEMM1 recompute + g_h on bx3 from LDS      [V13]");
+    run<14, 4, 8>(w, d, clk, "bwd f32, GEMM1 on bx3 from LDS, reads one row tile ahead [V14]");
+    run<11, 4, 8>(w, d, clk, "bwd f32, g_in and dW2 as 16x16x4 instead of 4x4x1   [V11]");
+    run<3, 4, 8>(w, d, clk, "fwd f32: 3 mfma16 + tanh + 8 mfma4                   [V3]");
+    run<12, 4, 8>(w, d, clk, "fwd f32, GEMM1 as 32x32x2 over 2 tiles x 2 row tiles [V12]");
     run<1, 2, 8>(w, d, clk, "bwd all bx3");
     run<5, 2, 8>(w, d, clk, "fwd all bx3");
     run<1, 4, 4>(w, d, clk, "bwd all bx3");

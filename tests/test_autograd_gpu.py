@@ -22,6 +22,11 @@ CASES = [
     ("wide", 2, 40, 20, (64,), "tanh", 50, "alt"),            # d > 16, c > 16
     ("one_cond", 5, 2, 1, (10,), "tanh", 33, "alt"),          # README example
     ("no_cond", 4, 6, 0, (12,), "tanh", 40, "alt"),           # C = None: nothing to differentiate there, the rest unchanged
+    # round 6: shapes whose 16-row tile image exceeds the any-shape MFMA kernel's LDS budget -- served by the VALU kernel
+    # (rnvp_generic.hip: the same seeds), no RuntimeError any more
+    ("h512", 4, 16, 4, (512,), "tanh", 70, "alt"),            # the C2 arrays through hidden=(512,)
+    ("d80_h300", 2, 80, 20, (300,), "tanh", 40, "alt"),
+    ("h512_masks_relu", 2, 9, 5, (512,), "relu", 37, "random"),
 ]
 
 
@@ -128,6 +133,15 @@ def test_backward_through_the_inverse(cid, L, d, c, hidden, act, n, masks):
     Ze = torch.zeros(0, d, device="cuda", requires_grad=True)
     nf.engine().inverse_autograd(Ze, torch.zeros(0, c, device="cuda") if c else None).sum().backward()
     assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in nf.parameters())
+
+
+def test_wide_nets_take_the_valu_kernel_not_an_exception():
+    """the shape hole of round 5: rnvp_backward_cond_workspace_bytes used to return 0 for hidden=(512,) on the C2 arrays and
+    the Python nodes raised; now the workspace query answers and the call runs (values: the h512 cases above)"""
+    from probaforms_amd import _hip
+    for hidden in ((512,), (300,), (1024, 64)):
+        shape = _hip.RnvpShape.make(8, 16, 4, hidden, "tanh")
+        assert _hip.backward_cond_workspace_bytes(shape, 4096) > 0, hidden
 
 
 def test_nf_sample_and_layer_g_carry_a_graph_like_the_reference():
