@@ -323,8 +323,13 @@ def rank_steps_of_8(dev):
         X = torch.randn(n, d, device=dev, generator=gen); C = torch.randn(n, c, device=dev, generator=gen)
         perm = torch.randperm(n, device=dev, generator=gen); losses = torch.zeros(nsteps, device=dev)
         res = {}
+        def chunked(kc):          # the exchange in kc chunks of layers, each all-reduce on the communicator's side stream (rnvp_dp_set_chunks)
+            _hip.dp_set_chunks(comm, kc)
+            eng.fit_epoch_dp(opt, comm, X, C, perm, rb, losses)
+            _hip.dp_set_chunks(comm, 1)
         for name, fn, steps, rows in (
                 ("rank_step_8192_rows", lambda: eng.fit_epoch_dp(opt, comm, X, C, perm, rb, losses), nsteps, rb),
+                ("rank_step_8192_rows_exchange_in_4_chunks", lambda: chunked(4), nsteps, rb),
                 ("one_gpu_step_65536_rows", lambda: eng.fit_epoch(opt, X, C, perm, BATCH, losses), n // BATCH, BATCH)):
             fn(); torch.cuda.synchronize(dev)
             _hip.profile_enable(4 * nsteps)
@@ -345,7 +350,10 @@ def rank_steps_of_8(dev):
     except Exception:
         pass
     out["note"] = ("per-rank step of the 8-GPU data-parallel configuration (global batch 65536 = 8192 rows per rank) measured on one GPU "
-                   "with a one-rank RCCL communicator; the cross-GPU latency of the [gradient | loss] all-reduce is not in it")
+                   "with a one-rank RCCL communicator; the cross-GPU latency of the [gradient | loss] all-reduce is not in it.  "
+                   "`..._exchange_in_4_chunks`: the same step with the message cut into 4 groups of layers whose all-reduces run on a side "
+                   "stream under the next group's partial sums (rnvp_dp_set_chunks) -- on ONE rank there is no latency to hide, so the "
+                   "difference to the line above is what the extra launches cost; the cut exists for the multi-GPU job")
     return out
 
 
@@ -990,7 +998,7 @@ def main():
         d8 = out.get("secondary_configs", {}).get("dp8_rank_steps")
         if d8:
             out["strong_batch_8gpu_projection"] = {
-                "eight_rank_steps_over_one_gpu_step": {k: v["eight_rank_steps_over_one_gpu_step"] for k, v in d8.items() if isinstance(v, dict)},
+                "eight_rank_steps_over_one_gpu_step": {k: v["eight_rank_steps_over_one_gpu_step"] for k, v in d8.items() if isinstance(v, dict) and "eight_rank_steps_over_one_gpu_step" in v},
                 "note": "global batch 65536 over 8 ranks = 8192 rows per rank: 8 x (rows/s of one rank's step, measured on this GPU through "
                         "rnvp_fit_epoch_dp on a one-rank RCCL communicator) / (rows/s of the one-GPU 65536-row step); the cross-GPU all-reduce "
                         "latency comes on top -- north_star's >= 6x is NOT projected in this regime, the weak-batch regime keeps the one-GPU step"}

@@ -406,6 +406,30 @@ int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx,
                          int64_t first_step, void *workspace, size_t workspace_bytes);
 
 /*
+ * The step's exchange in CHUNKS OF LAYERS (round 6; register-chained kernels only, other shapes ignore it).  Unchunked, a rank's
+ * step is strictly serial: training kernel -> partial sums -> all-reduce of [gradient | loss] -> Adam + re-pack, so the
+ * cross-GPU latency of the all-reduce is paid in full.  With `chunks` = K > 1 the layers are cut into K groups, last layers
+ * first (the first message carries the batch loss), and per group:  partial sums of the group -> all-reduce of the group's
+ * slice of the flat gradient -> Adam + re-pack of the group's layers.
+ *   rnvp_dp_set_chunks(comm, K)    the library's RCCL communicator: group j's all-reduce runs on a side stream of the communicator
+ *                                  while the caller's stream sums group j + 1 (events order the two; the next batch starts behind the
+ *                                  last group's Adam).  K = 1 (default) restores the one-message loop.  1 <= K <= 8.
+ *   rnvp_fit_epoch_dp_cb_chunked   the caller's exchange, called K times per batch on `stream` (no overlap: the exchange is the
+ *                                  caller's to schedule) -- the same cut, for process groups that are not RCCL and for tests.
+ * Per parameter the arithmetic is the unchunked loop's (same partial sums in the same order, same Adam): identical bits on one
+ * rank and wherever the exchange's sum does not depend on how the message is cut (two ranks; any exchange adding in rank order).
+ * Every rank must use the same K.  One GPU cannot show the benefit (nothing to hide: K = 4 costs ~2 more launches' worth of
+ * queue time per step on a one-rank communicator, bench.py secondary_configs.dp8_rank_steps); it is there for the multi-GPU job.
+ */
+int rnvp_dp_set_chunks(void *comm, int chunks);
+int rnvp_fit_epoch_dp_cb_chunked(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world, int chunks,
+                                 const rnvp_shape *shape, float *params, const uint8_t *masks,
+                                 const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                                 float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                                 double lr, double beta1, double beta2, double eps, double weight_decay,
+                                 int64_t first_step, void *workspace, size_t workspace_bytes);
+
+/*
  * Measurement aid (bench.py): while enabled, the hot kernel of each call -- the fused forward+backward
  * kernel of rnvp_loss_grad / rnvp_train_step (RNVP_PROFILE_TRAIN), the stack kernel of
  * rnvp_forward_logprob (RNVP_PROFILE_FORWARD) and of rnvp_inverse / rnvp_sample (RNVP_PROFILE_INVERSE) --

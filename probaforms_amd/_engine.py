@@ -596,7 +596,7 @@ class FlowEngine:
                         opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)
         opt.step_count += n_epochs * len(batch_bounds(n, batch_size))
 
-    def fit_epoch_dp(self, opt, comm, x, c, perm, batch_size, losses, exchange=None, rank=0, world=1):
+    def fit_epoch_dp(self, opt, comm, x, c, perm, batch_size, losses, exchange=None, rank=0, world=1, chunks=1):
         """data parallel: all batches of one epoch in ONE library call on ONE stream: per batch this rank's loss + gradient, the
         all-reduce of [gradient | loss], loss read-out + Adam.  comm: the library's RCCL communicator (rnvp_fit_epoch_dp);
         exchange: a callable(tensor, count) summing in place over the ranks -- process groups that are not RCCL, e.g. gloo
@@ -609,7 +609,7 @@ class FlowEngine:
         if exchange is not None:
             _hip.fit_epoch_dp_cb(exchange, rank, world, self.shape, self.params, self.masks, x, c, perm, n, batch_size,
                                  g[:self.P + 1], losses, opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd,
-                                 opt.step_count + 1, ws)
+                                 opt.step_count + 1, ws, chunks=chunks)
         else:
             _hip.fit_epoch_dp(comm, self.shape, self.params, self.masks, x, c, perm, n, batch_size, g[:self.P + 1], losses,
                               opt.exp_avg[:self.P], opt.exp_avg_sq[:self.P], lr, b1, b2, eps, wd, opt.step_count + 1, ws)

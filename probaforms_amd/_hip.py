@@ -155,6 +155,9 @@ _SIGNATURES = {
                                     _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "rnvp_fit_epoch_dp_cb": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP,
                                        _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
+    "rnvp_dp_set_chunks": (C.c_int, [_VP, C.c_int]),
+    "rnvp_fit_epoch_dp_cb_chunked": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _SP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _VP, _VP,
+                                               _VP, _VP, _D, _D, _D, _D, _D, _I64, _VP, _SZ]),
     "cvae_param_count": (_SZ, [C.POINTER(CvaeShape)]),
     "cvae_workspace_bytes": (_SZ, [C.POINTER(CvaeShape), _I64]),
     "cvae_kernel_path": (C.c_int, [C.POINTER(CvaeShape)]),
@@ -451,27 +454,39 @@ def fit_epoch_dp(comm, shape, params, masks, x, c, perm, n, batch_size, grad_los
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)      # rnvp_all_reduce_fn
 
 
+def dp_set_chunks(comm, chunks):
+    """the library's communicator exchanges the step's [gradient | loss] message in `chunks` groups of layers, each group's
+    all-reduce on a side stream under the next group's partial sums (rnvp_dp_set_chunks); 1 = one message per step"""
+    check(lib().rnvp_dp_set_chunks(comm, int(chunks)), "rnvp_dp_set_chunks")
+
+
 def fit_epoch_dp_cb(all_reduce, rank, world, shape, params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, exp_avg,
-                    exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step, ws):
-    """rnvp_fit_epoch_dp with the exchange supplied by the caller: `all_reduce(buf_tensor_view, count)` must sum
-    grad_loss[:count] over the ranks in place, ordered with the current stream (a torch.distributed all_reduce on the tensor
-    is).  The library hands back raw pointers; the wrapper checks that they are the ones of `grad_loss` and passes that tensor."""
+                    exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step, ws, chunks=1):
+    """rnvp_fit_epoch_dp with the exchange supplied by the caller: `all_reduce(buf_tensor_view, count)` must sum the view
+    over the ranks in place, ordered with the current stream (a torch.distributed all_reduce on the tensor is).  The library
+    hands back raw pointers; the wrapper checks that they lie inside `grad_loss` and passes the matching view (the whole
+    message, or one chunk of layers with chunks > 1: rnvp_fit_epoch_dp_cb_chunked)."""
     wp, wn = _ws(ws)
     base = grad_loss.data_ptr()
     failure = []
 
     def _cb(_ctx, _stream, buf, count):
         try:
-            if buf != base or count > grad_loss.numel():
-                raise RuntimeError("rnvp_fit_epoch_dp_cb handed the exchange a buffer that is not grad_loss")
-            all_reduce(grad_loss[:count], int(count))
+            off = ((buf or 0) - base) // 4
+            if (buf or 0) < base or ((buf or 0) - base) % 4 or off + count > grad_loss.numel():
+                raise RuntimeError("rnvp_fit_epoch_dp_cb handed the exchange a buffer that is not inside grad_loss")
+            all_reduce(grad_loss[off:off + count], int(count))
             return 0
         except BaseException as e:          # an exception must not unwind through the C frames
             failure.append(e)
             return 1
 
     cb = ALL_REDUCE_FN(_cb)
-    st = lib().rnvp_fit_epoch_dp_cb(_stream(), C.cast(cb, C.c_void_p), None, int(rank), int(world), C.byref(shape),
+    head = (_stream(), C.cast(cb, C.c_void_p), None, int(rank), int(world))
+    fn = lib().rnvp_fit_epoch_dp_cb
+    if int(chunks) > 1:
+        head, fn = head + (int(chunks),), lib().rnvp_fit_epoch_dp_cb_chunked
+    st = fn(*head, C.byref(shape),
           _ptr(params, torch.float32, "params"), _ptr(masks, torch.uint8, "masks"),
           _ptr(x, torch.float32, "x"), _ptr(c, torch.float32, "c"), _ptr(perm, torch.int64, "perm"), int(n),
           int(batch_size), _ptr(grad_loss, torch.float32, "grad_loss"), _ptr(loss_hist, torch.float32, "loss_hist"),

@@ -56,10 +56,23 @@ int load_rccl() {
     return RNVP_OK;
 }
 
+constexpr int kMaxChunks = 8;
 struct DpComm {
     void *comm;
     int rank, world;
+    // rnvp_dp_set_chunks: the step's [gradient | loss] message in chunks of layers, each chunk's all-reduce on `side` while the
+    // main stream sums the next chunk's partials
+    int chunks = 1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_sum[kMaxChunks] = {}, ev_red[kMaxChunks] = {};
 };
+
+// chunk j of `chunks` over L layers, LAST layers first (chunk 0 ends at L and carries the batch loss, so that every later chunk's
+// Adam launch can read the all-reduced loss for the cross-rank error check): layers [l0, l1)
+inline void chunk_layers(int L, int chunks, int j, int *l0, int *l1) {
+    *l1 = L - (int)((int64_t)L * j / chunks);
+    *l0 = L - (int)((int64_t)L * (j + 1) / chunks);
+}
 
 }  // namespace
 
@@ -87,9 +100,28 @@ int rnvp_dp_init(const void *id, int rank, int world, void **comm_out) {
     return RNVP_OK;
 }
 
+int rnvp_dp_set_chunks(void *comm, int chunks) {
+    if (!comm || chunks < 1 || chunks > kMaxChunks) return RNVP_EINVAL;
+    DpComm *c = static_cast<DpComm *>(comm);
+    if (chunks > 1 && !c->side) {
+        RNVP_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        for (int j = 0; j < kMaxChunks; ++j) {
+            RNVP_HIP_TRY(hipEventCreateWithFlags(&c->ev_sum[j], hipEventDisableTiming));
+            RNVP_HIP_TRY(hipEventCreateWithFlags(&c->ev_red[j], hipEventDisableTiming));
+        }
+    }
+    c->chunks = chunks;
+    return RNVP_OK;
+}
+
 int rnvp_dp_destroy(void *comm) {
     if (!comm) return RNVP_OK;
     DpComm *c = static_cast<DpComm *>(comm);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        for (int j = 0; j < kMaxChunks; ++j) { (void)hipEventDestroy(c->ev_sum[j]); (void)hipEventDestroy(c->ev_red[j]); }
+        (void)hipStreamDestroy(c->side);
+    }
     if (c->comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->comm);
     delete c;
     return RNVP_OK;
@@ -107,16 +139,35 @@ static int rccl_all_reduce_cb(void *ctx, void *stream, float *buf, int64_t count
     return rnvp_dp_all_reduce(stream, ctx, buf, count);
 }
 
+static int fit_epoch_dp_impl(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world, int chunks, DpComm *overlap,
+                             const rnvp_shape *shape, float *params, const uint8_t *masks,
+                             const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                             float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                             double lr, double beta1, double beta2, double eps, double weight_decay,
+                             int64_t first_step, void *workspace, size_t workspace_bytes);
+
 int rnvp_fit_epoch_dp(void *stream, void *comm, const rnvp_shape *shape, float *params, const uint8_t *masks,
                       const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
                       float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
                       double lr, double beta1, double beta2, double eps, double weight_decay,
                       int64_t first_step, void *workspace, size_t workspace_bytes) {
     // comm == NULL: one rank, no exchange (the same step sequence, for tests of the loop itself)
-    const DpComm *dc = static_cast<const DpComm *>(comm);
-    return rnvp_fit_epoch_dp_cb(stream, dc ? rccl_all_reduce_cb : nullptr, comm, dc ? dc->rank : 0, dc ? dc->world : 1, shape,
-                                params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, exp_avg, exp_avg_sq, lr, beta1,
-                                beta2, eps, weight_decay, first_step, workspace, workspace_bytes);
+    DpComm *dc = static_cast<DpComm *>(comm);
+    return fit_epoch_dp_impl(stream, dc ? rccl_all_reduce_cb : nullptr, comm, dc ? dc->rank : 0, dc ? dc->world : 1, dc ? dc->chunks : 1,
+                             (dc && dc->chunks > 1) ? dc : nullptr, shape, params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist,
+                             exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step, workspace, workspace_bytes);
+}
+
+int rnvp_fit_epoch_dp_cb_chunked(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world, int chunks,
+                                 const rnvp_shape *shape, float *params, const uint8_t *masks,
+                                 const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                                 float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                                 double lr, double beta1, double beta2, double eps, double weight_decay,
+                                 int64_t first_step, void *workspace, size_t workspace_bytes) {
+    if (chunks < 1 || chunks > kMaxChunks) return RNVP_EINVAL;
+    return fit_epoch_dp_impl(stream, all_reduce, ctx, rank, world, chunks, nullptr, shape, params, masks, x, c, perm, n, batch_size,
+                             grad_loss, loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step, workspace,
+                             workspace_bytes);
 }
 
 int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world,
@@ -125,6 +176,24 @@ int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx,
                          float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
                          double lr, double beta1, double beta2, double eps, double weight_decay,
                          int64_t first_step, void *workspace, size_t workspace_bytes) {
+    return fit_epoch_dp_impl(stream, all_reduce, ctx, rank, world, 1, nullptr, shape, params, masks, x, c, perm, n, batch_size, grad_loss,
+                             loss_hist, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, first_step, workspace, workspace_bytes);
+}
+
+}  // extern "C"
+
+// chunks > 1 (register-chained kernels only): per batch the training launch, then for every chunk of layers (last layers first)
+// the partial sums of the chunk -> its all-reduce -> Adam + re-pack of the chunk.  With `overlap` (the library's communicator,
+// rnvp_dp_set_chunks) chunk j's all-reduce runs on the communicator's side stream while the main stream sums chunk j + 1: the
+// cross-GPU latency of the exchange hides under the sums instead of following them.  The arithmetic per parameter is that of the
+// unchunked loop (same partial sums, same Adam): identical bits on one rank and wherever the exchange's sum does not depend on how
+// the message is cut (two ranks; any exchange that adds in rank order).
+static int fit_epoch_dp_impl(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx, int rank, int world, int chunks, DpComm *overlap,
+                             const rnvp_shape *shape, float *params, const uint8_t *masks,
+                             const float *x, const float *c, const int64_t *perm, int64_t n, int64_t batch_size,
+                             float *grad_loss, float *loss_hist, float *exp_avg, float *exp_avg_sq,
+                             double lr, double beta1, double beta2, double eps, double weight_decay,
+                             int64_t first_step, void *workspace, size_t workspace_bytes) {
     if (n < 0 || batch_size < 1 || !perm || !loss_hist || !grad_loss || first_step < 1) return RNVP_EINVAL;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !all_reduce)) return RNVP_EINVAL;
     rnvp::KShape ks;
@@ -136,6 +205,7 @@ int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx,
     // register-chained kernels: the packed weight fragments live in the workspace for the whole call -- packed by the first
     // batch's rnvp_loss_grad, then re-packed by every batch's Adam launch (rnvp::mfma::adam_pack)
     const bool chained = rnvp::mfma::train_supported(ks);
+    const int nchunks = (chained && chunks > 1) ? (chunks < ks.L ? chunks : ks.L) : 1;
     bool packed_valid = false;
     int64_t k = 0;
     for (int64_t s0 = 0; s0 < n; s0 += batch_size, ++k) {
@@ -145,6 +215,52 @@ int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx,
         const int64_t base = rows / world, rem = rows % world;
         const int64_t lo = s0 + rank * base + (rank < rem ? rank : rem);
         const int64_t mine = base + (rank < rem ? 1 : 0);
+        if (chained && nchunks > 1) {
+            // (every rank issues the SAME sequence of exchanges, also one whose share of a ragged batch is empty: it contributes zeros)
+            if (!params || (!masks && !ks.alt) || !x || (ks.c > 0 && !c) || !exp_avg || !exp_avg_sq) return RNVP_EINVAL;
+            rnvp::mfma::PendingPartials pend{};
+            if (mine > 0) {
+                rc = rnvp::mfma::loss_partials(st, ks, params, x, c, perm + lo, mine, 1.0f / (float)rows, workspace, workspace_bytes,
+                                               packed_valid, &pend);
+                if (rc) return rc;
+            } else {
+                RNVP_HIP_TRY(hipMemsetAsync(grad_loss, 0, (size_t)(P + 1) * sizeof(float), st));
+            }
+            const int64_t per_layer = P / ks.L;
+            for (int j = 0; j < nchunks; ++j) {
+                int l0, l1;
+                chunk_layers(ks.L, nchunks, j, &l0, &l1);
+                if (mine > 0) {
+                    rc = rnvp::mfma::finish_sum_layers(st, ks, pend, l0, l1 - l0, grad_loss, j == 0 ? grad_loss + P : nullptr, workspace,
+                                                       workspace_bytes);
+                    if (rc) return rc;
+                }
+                float *msg = grad_loss + (int64_t)l0 * per_layer;
+                const int64_t cnt = (int64_t)(l1 - l0) * per_layer + (j == 0 ? 1 : 0);
+                if (!all_reduce) continue;
+                if (overlap) {
+                    RNVP_HIP_TRY(hipEventRecord(overlap->ev_sum[j], st));
+                    RNVP_HIP_TRY(hipStreamWaitEvent(overlap->side, overlap->ev_sum[j], 0));
+                    rc = all_reduce(ctx, overlap->side, msg, cnt);
+                    if (rc) return rc;
+                    RNVP_HIP_TRY(hipEventRecord(overlap->ev_red[j], overlap->side));
+                } else {
+                    rc = all_reduce(ctx, stream, msg, cnt);
+                    if (rc) return rc;
+                }
+            }
+            const rnvp::AdamK ak = rnvp::make_adam(lr, beta1, beta2, eps, weight_decay, first_step + k);
+            for (int j = 0; j < nchunks; ++j) {
+                int l0, l1;
+                chunk_layers(ks.L, nchunks, j, &l0, &l1);
+                if (overlap && all_reduce) RNVP_HIP_TRY(hipStreamWaitEvent(st, overlap->ev_red[j], 0));
+                rc = rnvp::mfma::adam_pack_layers(st, ks, params, grad_loss, grad_loss + P, j == 0 ? loss_hist + k : nullptr, exp_avg,
+                                                  exp_avg_sq, ak, workspace, workspace_bytes, l0, l1 - l0);
+                if (rc) return rc;
+            }
+            packed_valid = true;
+            continue;
+        }
         if (chained && mine > 0) {
             if (!params || (!masks && !ks.alt) || !x || (ks.c > 0 && !c)) return RNVP_EINVAL;
             rc = rnvp::mfma::loss_grad(st, ks, params, x, c, perm + lo, mine, 1.0f / (float)rows, grad_loss, grad_loss + P, workspace,
@@ -171,5 +287,3 @@ int rnvp_fit_epoch_dp_cb(void *stream, rnvp_all_reduce_fn all_reduce, void *ctx,
     }
     return RNVP_OK;
 }
-
-}  // extern "C"

@@ -116,6 +116,15 @@ int train_step(hipStream_t st, const KShape &k, float *params, const float *x, c
                float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes, bool packed_valid = false,
                bool pack_next = false);
 // data parallel, after the all-reduce: loss read-out + Adam from the flat gradient + re-pack, one launch
+// the data-parallel step in chunks of layers (rnvp_dp.hip, rnvp_dp_set_chunks): training launch alone, then per chunk the partial
+// sums, [the caller's all-reduce of the chunk,] Adam + re-pack of the chunk's layers
+struct PendingPartials { int glayer_floats, w2c, grid; float inv_B; };
+int loss_partials(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c, const int64_t *row_index,
+                  int64_t n, float inv_B, void *ws, size_t ws_bytes, bool packed_valid, PendingPartials *pending);
+int finish_sum_layers(hipStream_t st, const KShape &k, const PendingPartials &p, int l0, int nl, float *grad, float *loss_out,
+                      void *ws, size_t ws_bytes);
+int adam_pack_layers(hipStream_t st, const KShape &k, float *params, float *grad, const float *loss_in, float *loss_out,
+                     float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes, int l0, int nl);
 int adam_pack(hipStream_t st, const KShape &k, float *params, float *grad, const float *loss_in, float *loss_out,
               float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes);
 

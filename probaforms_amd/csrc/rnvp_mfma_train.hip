@@ -92,21 +92,23 @@ constexpr int kFinPer = 3;                        // parameters per thread: ceil
 #endif
 constexpr int kFinInFlight = RNVP_FIN_INFLIGHT;
 __global__ void __launch_bounds__(kFinThreads)
-k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, const float *__restrict__ gpart, int G,
+k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, int l0, int nl, const float *__restrict__ gpart, int G,
                const float *__restrict__ losspart, int n_loss, float inv_B, const float *loss_in, float *loss_out,
                float *grad, float *params, float *adam_m, float *adam_v, AdamK adam, float *packed, const int *err) {
     __shared__ __attribute__((aligned(16))) float rec[kFinRecMax];
     __shared__ f4 red[kFinThreads];
     __shared__ float pw[kFinParMax];
     const int t = threadIdx.x, b = blockIdx.x;
-    const int HT = g.HT, nrec = k.L * 2 * HT;
+    // the launch serves the layers l0 .. l0 + nl - 1 (all of them, or one chunk of the data-parallel step: rnvp_dp.hip); the loss
+    // block exists where loss_out is given
+    const int HT = g.HT, nrec = nl * 2 * HT;
     // a wave of the training launch gave up a bounded wait (spin_nap): its workgroup's partial is incomplete.  No Adam step, no
     // re-pack -- the parameters keep their last good values -- and the loss says so (kProtocolNaN)
     // (data parallel: ANY rank's error reaches every rank through the all-reduced loss -- NaN + x keeps the NaN's payload)
     const bool bad = (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ||
                      (!(mode & kFinSum) && loss_in && __float_as_uint(loss_in[0]) == kProtocolNaN);
     if (bad) mode &= ~(kFinAdam | kFinPack);
-    if (b == 2 * nrec + k.L) {              // the loss: partials added in a fixed order (one wave), or read out of the message
+    if (b == 2 * nrec + nl) {               // the loss: partials added in a fixed order (one wave), or read out of the message
         if (t < 64 && loss_out) {
             if (mode & kFinSum) {
                 float a = 0.f;
@@ -121,7 +123,7 @@ k_train_finish(KShape k, Geo g, int NTI, int glayer_floats, int w2c, int mode, c
     }
     const bool bias2 = b >= 2 * nrec;
     const int r = b >> 1, half = bias2 ? 2 : b & 1;           // 0: W1 | b1, 1: W2, 2: the layer's b2
-    const int l = bias2 ? b - 2 * nrec : r / (2 * HT);
+    const int l = l0 + (bias2 ? b - 2 * nrec : r / (2 * HT));
     const int net = bias2 ? 0 : (r / HT) & 1, ht = bias2 ? 0 : r % HT;
     const int tblk = w2c ? NTI * 256 + 128 : (NTI + g.OTL) * 256, netblock = HT * tblk;
     // this workgroup's floats inside the layer's record
@@ -291,10 +293,12 @@ size_t train_workspace_bytes(const KShape &k, int64_t max_rows) {
 
 static int launch_finish(hipStream_t st, const KShape &k, const Geo &g, int glayer_floats, int w2c, int mode, const float *gpart,
                          int G, const float *losspart, float inv_B, const float *loss_in, float *loss_out, float *grad,
-                         float *params, float *adam_m, float *adam_v, const AdamK &adam, float *packed, const int *err) {
+                         float *params, float *adam_m, float *adam_v, const AdamK &adam, float *packed, const int *err,
+                         int l0 = 0, int nl = -1) {
     const int NTI = (g.KS1 + 1 + 3) / 4;
-    const unsigned blocks = (unsigned)(2 * k.L * 2 * g.HT + k.L + 1);       // two per gradient record, one per layer (b2), the loss
-    hipLaunchKernelGGL(k_train_finish, dim3(blocks), dim3(kFinThreads), 0, st, k, g, NTI, glayer_floats, w2c, mode, gpart, G, losspart,
+    if (nl < 0) nl = k.L - l0;
+    const unsigned blocks = (unsigned)(2 * nl * 2 * g.HT + nl + 1);         // two per gradient record, one per layer (b2), the loss
+    hipLaunchKernelGGL(k_train_finish, dim3(blocks), dim3(kFinThreads), 0, st, k, g, NTI, glayer_floats, w2c, mode, l0, nl, gpart, G, losspart,
                        G * kWaves, inv_B, loss_in, loss_out, grad, params, adam_m, adam_v, adam, packed, err);
     RNVP_HIP_TRY(hipGetLastError());
     return RNVP_OK;
@@ -307,7 +311,7 @@ static int launch_finish(hipStream_t st, const KShape &k, const Geo &g, int glay
 static int step_impl(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,
                      const int64_t *row_index, int64_t n, float inv_B, float *grad_out, float *loss_out,
                      void *ws, size_t ws_bytes, float *adam_p, float *adam_m, float *adam_v, AdamK adam, Seeds sd,
-                     bool packed_valid, bool pack_next) {
+                     bool packed_valid, bool pack_next, PendingPartials *pending = nullptr) {
     if (!ws || ws_bytes < train_workspace_bytes(k, n)) return RNVP_EWORKSPACE;
     const Geo g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
     if ((sd.gld || sd.gx) && n > ts_max_rows(g)) return RNVP_EUNSUPPORTED;       // see backward_rows_ok
@@ -331,12 +335,57 @@ static int step_impl(hipStream_t st, const KShape &k, const float *params, const
     else if (g.NF == 8 && g.CQ == 4) rc = launch_train_8_4(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, &grid, sd, &lay);
     else return RNVP_EUNSUPPORTED;
     if (rc) return rc;
+    if (pending) {      // the caller sums the partials itself, in chunks of layers (finish_sum_layers): data-parallel step
+        pending->glayer_floats = lay.glayer_floats; pending->w2c = lay.w2c; pending->grid = grid; pending->inv_B = inv_B;
+        note_launches(RNVP_PROFILE_TRAIN, packed_valid ? 1 : 2);
+        return RNVP_OK;
+    }
     const int mode = kFinSum | (adam_p ? kFinAdam : 0) | (adam_p && pack_next ? kFinPack : 0);
     rc = launch_finish(st, k, g, lay.glayer_floats, lay.w2c, mode, gpart, grid, losspart, inv_B, nullptr, loss_out, grad_out, adam_p,
                        adam_m, adam_v, adam, packed, error_word(losspart));
     if (rc) return rc;
     note_launches(RNVP_PROFILE_TRAIN, packed_valid ? 2 : 3);       // [pack,] hot kernel, finish
     return RNVP_OK;
+}
+
+// the workspace regions of step_impl (one place for the chunked data-parallel calls below)
+struct WsView { float *packed, *gpart, *losspart; };
+static bool ws_view(const KShape &k, void *ws, size_t ws_bytes, Geo *g, TrainPlan *pl, WsView *v) {
+    if (!ws || ws_bytes < train_workspace_bytes(k, 1)) return false;
+    *g = make_geo(k.d, k.c, k.nout[0], kTrainSplit);
+    if (!plan_for(*g, k.L, pl)) return false;
+    char *w = static_cast<char *>(ws);
+    v->packed = reinterpret_cast<float *>(w);
+    w += align_up((size_t)g->layer_floats * k.L * sizeof(float), 256);
+    v->gpart = reinterpret_cast<float *>(w);
+    w += align_up((size_t)kMaxGridTrain * pl->glayer_floats * k.L * sizeof(float), 256);
+    v->losspart = reinterpret_cast<float *>(w);
+    return true;
+}
+
+// DATA-PARALLEL step in chunks of layers (rnvp_dp.hip): the training launch alone ...
+int loss_partials(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c, const int64_t *row_index,
+                  int64_t n, float inv_B, void *ws, size_t ws_bytes, bool packed_valid, PendingPartials *pending) {
+    return step_impl(st, k, params, x, c, row_index, n, inv_B, nullptr, nullptr, ws, ws_bytes, nullptr, nullptr, nullptr, AdamK{}, Seeds{},
+                     packed_valid, false, pending);
+}
+// ... then, per chunk of layers [l0, l0 + nl): the partial sums into the flat gradient (the batch loss with the chunk that is
+// handed loss_out) -- the same per-record arithmetic as the one-launch finish, bit for bit ...
+int finish_sum_layers(hipStream_t st, const KShape &k, const PendingPartials &p, int l0, int nl, float *grad, float *loss_out,
+                      void *ws, size_t ws_bytes) {
+    Geo g; TrainPlan pl; WsView v;
+    if (!ws_view(k, ws, ws_bytes, &g, &pl, &v)) return RNVP_EWORKSPACE;
+    return launch_finish(st, k, g, p.glayer_floats, p.w2c, kFinSum, v.gpart, p.grid, v.losspart, p.inv_B, nullptr, loss_out, grad, nullptr,
+                         nullptr, nullptr, AdamK{}, v.packed, error_word(v.losspart), l0, nl);
+}
+// ... and, behind the chunk's all-reduce, Adam + re-pack of exactly those layers (loss_in: the all-reduced batch loss, read by
+// every chunk for the cross-rank error check, written to loss_out by the chunk that is handed one)
+int adam_pack_layers(hipStream_t st, const KShape &k, float *params, float *grad, const float *loss_in, float *loss_out,
+                     float *exp_avg, float *exp_avg_sq, const AdamK &adam, void *ws, size_t ws_bytes, int l0, int nl) {
+    Geo g; TrainPlan pl; WsView v;
+    if (!ws_view(k, ws, ws_bytes, &g, &pl, &v)) return RNVP_EWORKSPACE;
+    return launch_finish(st, k, g, pl.glayer_floats, 0, kFinAdam | kFinPack, nullptr, 0, nullptr, 0.f, loss_in, loss_out, grad, params,
+                         exp_avg, exp_avg_sq, adam, v.packed, error_word(v.losspart), l0, nl);
 }
 
 int loss_grad(hipStream_t st, const KShape &k, const float *params, const float *x, const float *c,

@@ -12,6 +12,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _chunked_epoch_matches(rank, world):
+    from probaforms_amd import _engine
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    n, d, c = 20000, 16, 4
+    X = torch.randn(n, d, generator=g).to(dev); C = torch.randn(n, c, generator=g).to(dev)
+    perm = torch.randperm(n, generator=g).to(dev)
+    results = []
+    for chunks in (1, 3, 8):
+        torch.manual_seed(0)
+        layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, (128,), "tanh") for i in range(8)]
+        nf = NormalizingFlow(layers, StandardNormalPrior(d, dev))
+        for p in nf.parameters():
+            p.data = p.data.to(dev)
+        eng = nf.engine()
+        opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.01)
+        losses = torch.zeros(3, device=dev)
+        eng.fit_epoch_dp(opt, None, X, C, perm, 8192, losses, exchange=lambda t, count: _engine.all_reduce_sum(t), rank=rank,
+                         world=world, chunks=chunks)
+        torch.cuda.synchronize()
+        results.append(torch.cat([eng.flat.detach().reshape(-1), opt.exp_avg.reshape(-1), opt.exp_avg_sq.reshape(-1), losses]).clone())
+    ok = all(torch.equal(results[0], r) for r in results[1:]) and bool(torch.isfinite(results[0]).all())
+    both = [torch.empty_like(results[0]) for _ in range(world)]
+    dist.all_gather(both, results[1])
+    return bool(ok and all(torch.equal(both[0], b) for b in both))
+
+
 def main():
     out = sys.argv[1]
     dist.init_process_group("gloo")
@@ -61,6 +89,11 @@ def main():
     c2_flat = m2.nf.engine().flat.detach().cpu().numpy()
     if rank == 0:
         np.savez(out + ".c2fit.npz", hist=c2_hist, flat=c2_flat)
+    # round 6: the step's exchange in chunks of layers (rnvp_fit_epoch_dp_cb_chunked) against the one-message loop, two ranks,
+    # C2 flow, global batch 8192 (4096 rows per rank; ragged last batch): identical bits on both ranks
+    chunk_same = _chunked_epoch_matches(rank, world)
+    if rank == 0:
+        np.savez(out + ".chunks.npz", same=chunk_same)
     if rank == 0:
         np.savez(out, flat=flat.cpu().numpy(), hist=np.array([float(v) for v in m.loss_history]), same=same, xs=xs,
                  cvae_flat=cflat.cpu().numpy(), cvae_hist=np.array([float(v) for v in cv.loss_history]), cvae_same=csame)

@@ -69,7 +69,7 @@ def _install_oracle_backend():
         adam_step(params, grad_loss[:n], m, v, n, lr, b1, b2, eps, wd, step)
 
     def fit_epoch_dp_cb(all_reduce, rank, world, shape, params, masks, x, c, perm, n, batch_size, grad_loss, loss_hist, m, v,
-                        lr, b1, b2, eps, wd, first_step, ws):
+                        lr, b1, b2, eps, wd, first_step, ws, chunks=1):
         """stand-in for rnvp_fit_epoch_dp_cb (csrc/rnvp_dp.hip), the loop RealNVP.fit runs under a gloo process group: per
         global batch this rank's contiguous share (remainder rows to the low ranks), gradients scaled by 1 / B_global, ONE
         exchange of [gradient | loss], loss read-out + the identical Adam step.  (The C loop itself runs with two ranks in
@@ -81,7 +81,14 @@ def _install_oracle_backend():
             lo = s0 + rank * base + min(rank, rem)
             mine = base + (1 if rank < rem else 0)
             loss_grad(shape, params, masks, x, c, perm[lo:lo + mine], mine, 1.0 / rows, grad_loss[:P], grad_loss[P:P + 1], ws)
-            all_reduce(grad_loss[:P + 1], P + 1)
+            if chunks <= 1:
+                all_reduce(grad_loss[:P + 1], P + 1)
+            else:       # rnvp_fit_epoch_dp_cb_chunked: the message in chunks of layers, last layers first, the loss with the first
+                L, per = shape.L, P // shape.L
+                for j in range(min(chunks, L)):
+                    l1, l0 = L - L * j // min(chunks, L), L - L * (j + 1) // min(chunks, L)
+                    cnt = (l1 - l0) * per + (1 if j == 0 else 0)
+                    all_reduce(grad_loss[l0 * per:l0 * per + cnt], cnt)
             dp_finish_step(params, grad_loss, m, v, P, lr, b1, b2, eps, wd, first_step + k, loss_hist[k:k + 1])
 
     def prior_normal(seed, row_offset, n_rows, d, z_out):

@@ -65,6 +65,8 @@ def test_two_ranks_on_hip_kernels_match_single_process(tmp_path):
     np.testing.assert_allclose(got["hist"][:4], ref["loss_history"][:4], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(got["hist"], ref["loss_history"], rtol=1e-3, atol=1e-3)
     assert np.abs(got["flat"][:ref["params_after"].size] - ref["params_after"]).max() < 2e-3
+    # round 6: the exchange cut into chunks of layers gives the one-message loop's bits on both ranks
+    assert bool(np.load(out + ".chunks.npz")["same"])
     # sharded sampling: rank shares are consecutive blocks of the replicated draw; 'gather' rebuilds all of it
     s0, s1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
     assert s0["shard"].shape == (31, 5) and s1["shard"].shape == (30, 5)
@@ -133,3 +135,50 @@ def test_bench_data_parallel_step_over_rccl_single_rank():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3"])
+def test_chunked_exchange_is_the_one_message_loop_bit_for_bit(cfg):
+    """rnvp_dp_set_chunks / rnvp_fit_epoch_dp_cb_chunked (round 6): per batch the partial sums, the exchange and Adam + re-pack run
+    per chunk of layers -- on the library's one-rank RCCL communicator with the chunks' all-reduces on its side stream, and through
+    the caller's exchange -- and must leave exactly the parameters, moments and losses of the unchunked loop (and of
+    rnvp_fit_epoch, the single-GPU call)"""
+    from probaforms_amd import _engine, _hip
+    from probaforms_amd.models import NormalizingFlow, RealNVPLayer, StandardNormalPrior
+    L, d, c, h = (8, 16, 4, 128) if cfg == "c2" else (12, 32, 8, 256)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4)
+    n = 3 * 8192 + 1000
+    X = torch.randn(n, d, generator=g).to(dev); C = torch.randn(n, c, generator=g).to(dev)
+    perm = torch.randperm(n, generator=g).to(dev)
+    comm = _hip.dp_init(_hip.dp_unique_id(), 0, 1)
+
+    def run(mode, chunks):
+        torch.manual_seed(0)
+        layers = [RealNVPLayer(d, c, (torch.arange(d) + i) % 2, (h,), "tanh") for i in range(L)]
+        nf = NormalizingFlow(layers, StandardNormalPrior(d, dev))
+        for p in nf.parameters():
+            p.data = p.data.to(dev)
+        eng = nf.engine()
+        opt = _engine.FlatAdam(eng.flat.numel(), dev, lr=1e-3, weight_decay=0.0)
+        losses = torch.zeros(4, device=dev)
+        for _ in range(2):                       # two epochs: the re-packed fragments of one feed the next
+            if mode == "single":
+                eng.fit_epoch(opt, X, C, perm, 8192, losses)
+            elif mode == "rccl":
+                _hip.dp_set_chunks(comm, chunks)
+                eng.fit_epoch_dp(opt, comm, X, C, perm, 8192, losses)
+            else:
+                eng.fit_epoch_dp(opt, None, X, C, perm, 8192, losses, exchange=lambda t, count: None, rank=0, world=1, chunks=chunks)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(losses).all())
+        return torch.cat([eng.flat.detach().reshape(-1), opt.exp_avg.reshape(-1), opt.exp_avg_sq.reshape(-1), losses]).clone()
+
+    try:
+        base = run("rccl", 1)
+        for mode, chunks in (("rccl", 2), ("rccl", 4), ("rccl", 8), ("cb", 1), ("cb", 3), ("single", 1)):
+            got = run(mode, chunks)
+            assert torch.equal(got, base), (mode, chunks, float((got - base).abs().max()))
+    finally:
+        _hip.dp_set_chunks(comm, 1)
+        _hip.dp_destroy(comm)
