@@ -104,7 +104,7 @@ typedef struct rnvp_shape {
 #define RNVP_OP_INVERSE  1
 #define RNVP_OP_TRAIN    2
 
-#define RNVP_HIP_VERSION 500     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
+#define RNVP_HIP_VERSION 600     /* rnvp_version(): bumped whenever a struct layout or an argument list changes; a
                                     binding must refuse a library that reports another number                      */
 int         rnvp_version(void);
 const char *rnvp_status_string(int status);

@@ -12,7 +12,7 @@ import threading
 import torch
 
 MAX_HIDDEN = 8
-ABI_VERSION = 500          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
+ABI_VERSION = 600          # rnvp_version() of the library this binding matches (include/rnvp_hip.h RNVP_HIP_VERSION)
 OP_FORWARD, OP_INVERSE, OP_TRAIN = 0, 1, 2
 PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA, PATH_LMM = 0, 1, 2

@@ -112,36 +112,14 @@ constexpr size_t kSyncBytes = 128;                       // LDS behind a workgro
 // the step's error word: one int behind the kMaxGridTrain x kWaves loss partials of the workspace (spin_nap, k_train_finish)
 __host__ __device__ __forceinline__ int *error_word(float *losspart) { return reinterpret_cast<int *>(losspart + (size_t)kMaxGridTrain * kWaves); }
 struct FlushSync { int *arr; int *done; int win; Poison poison; };      // arr[2 g + p]: arrivals of net group g (t / s waves) at windows of parity p; done: window shares summed; win: windows this wave finished
-// RNVP_PARTIAL_WT (experiment, round 6): the workgroup's partial-gradient stores as WRITE-THROUGH stores (sc1): the bytes leave the
-// XCD's L2 while the kernel runs instead of in the write-back at its end, which the next kernel's start waits for
-#ifndef RNVP_PARTIAL_WT
-#define RNVP_PARTIAL_WT 0
-#endif
-__device__ __forceinline__ void store_partial(f4 *p, f4 v) {
-#if RNVP_PARTIAL_WT
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
-}
 // The (h, g_pre) transposition tiles of the backward: lane (q, r) writes row r, columns 4q .. 4q + 3 as one b128 and reads back
-// row 4 ks + q, column r as b32.  With the plain row stride kTS = 20 the b128 writes are conflict free but the lanes of q and
-// q + 1 of one 32-lane read group meet on 4 of the 32 banks (row stride 20: banks r and 20 + r overlap for r >= 12): every
-// transposed read is 2-way conflicted -- all of the kernel's SQ_LDS_BANK_CONFLICT (profiles/r06_lds_conflicts.txt).
-// RNVP_TT_SWIZZLE: row stride 16, the four f4 blocks of row R rotated by (R >> 1) & 3 -- rows 4 ks + q and 4 ks + q + 1 then sit
-// in opposite halves of the banks (reads conflict free) and the eight rows of a b128 write group land on eight different f4
-// bank blocks (writes conflict free).
-#ifndef RNVP_TT_SWIZZLE
-#define RNVP_TT_SWIZZLE 0
-#endif
-__device__ __forceinline__ int tt_write(int q, int r) {
-    if constexpr (RNVP_TT_SWIZZLE != 0) return r * 16 + 4 * ((q + (r >> 1)) & 3);
-    return r * kTS + 4 * q;
-}
-__device__ __forceinline__ int tt_read(int q, int r, int ks) {
-    if constexpr (RNVP_TT_SWIZZLE != 0) { const int R = 4 * ks + q; return R * 16 + 4 * (((r >> 2) + (R >> 1)) & 3) + (r & 3); }
-    return (4 * ks + q) * kTS + r;
-}
+// row 4 ks + q, column r as b32.  With the row stride kTS = 20 the b128 writes are conflict free, but the lanes of q and q + 1 of
+// one 32-lane read group meet on 4 of the 32 banks (banks r and 20 + r overlap for r >= 12): every transposed read is 2-way
+// conflicted.  That is 8.4 M of the kernel's 9.2 M SQ_LDS_BANK_CONFLICT cycles per 65 536-row launch (profiles/r06_lds_conflicts.txt:
+// product 9.175 M, without the tiles 0.786 M).  A conflict-free layout exists -- row stride 16, the four f4 blocks of row R rotated
+// by (R >> 1) & 3 -- and was built, parity green: conflicts 0.786 M, LDS-active cycles 39.7 M -> 31.3 M, launch time UNCHANGED
+// (0.3052-0.3077 against 0.3066-0.3070 ms, profiles/r06_tt_swizzle_ab.txt): the LDS pipe is not what the issue-bound SIMDs wait for.
+// Not kept ("only keep a change that shortens the launch").
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int NF, int CQ> struct Dims {
@@ -162,10 +140,9 @@ template <int NF, int CQ> struct Dims {
     // hidden tiles accumulated in LDS between two flushes: sized so that TWO workgroups fit in a CU's 160 KB
     // (2 waves per SIMD once the batch gives every CU two workgroups).  Measured against the previous 8/8/4:
     // C2 +9 % from 131 072 rows up (neutral at 65 536), C3 +7 % at 65 536 / +18 % at 262 144 rows, C4 +8.5 %.
-#ifndef RNVP_TRAIN_FT_NF2
-#define RNVP_TRAIN_FT_NF2 4
-#endif
-    static constexpr int FT = NF == 2 ? RNVP_TRAIN_FT_NF2 : (NF == 4 ? 2 : 1);
+    // (d <= 16 with windows of ONE tile, FT = 2 -- which would free 24.5 KB of LDS --: +0.8 % at 65 536 rows, +8 % at 16 960,
+    // profiles/r06_ft2_ab.txt)
+    static constexpr int FT = NF == 2 ? 4 : (NF == 4 ? 2 : 1);
 #endif
     static constexpr int SLOT = FT * (NTI + OTL) * 256 + NT2 * 16;      // floats of one wave's slot
     // W2C (d <= 16 in net-split mode: every wave owns ONE net): dW2 = h^T g_out runs as 16 independent 4x4x1 blocks per
@@ -424,8 +401,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                     const f4 hv = act4<ACT>(acc[u]);
                     gpv[u] = gh[u] * dact4<ACT>(hv);                                     // activation'
                     if (!(kAblate & 1)) {
-                        *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + tt_write(q, r)) = hv;
-                        *reinterpret_cast<f4 *>(bufH + (2 * u + 1) * 16 * kTS + tt_write(q, r)) = gpv[u];
+                        *reinterpret_cast<f4 *>(bufH + (2 * u) * 16 * kTS + r * kTS + 4 * q) = hv;
+                        *reinterpret_cast<f4 *>(bufH + (2 * u + 1) * 16 * kTS + r * kTS + 4 * q) = gpv[u];
                     } else {
                         asm volatile("" ::"v"(hv));
                     }
@@ -444,8 +421,8 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) {
                             if (!(kAblate & 1)) {
-                                hT[u][ks] = bufH[(2 * u) * 16 * kTS + tt_read(q, r, ks)];
-                                pT[u][ks] = bufH[(2 * u + 1) * 16 * kTS + tt_read(q, r, ks)];
+                                hT[u][ks] = bufH[(2 * u) * 16 * kTS + (4 * ks + q) * kTS + r];
+                                pT[u][ks] = bufH[(2 * u + 1) * 16 * kTS + (4 * ks + q) * kTS + r];
                             } else {
                                 hT[u][ks] = gpv[u][ks]; pT[u][ks] = gpv[u][ks];
                             }
@@ -600,7 +577,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                                 f4 v = s0[0];
 #pragma unroll
                                 for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4)];          // slot order: deterministic
-                                store_partial(dst, first ? v : v + oldv[n2]);
+                                *dst = first ? v : v + oldv[n2];
                             }
                         }
                         if (last_tile && (!TFW || net == 1) && tid < NT2 * 16) {       // db2: in the slots of the waves that ran net s
@@ -641,7 +618,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             f4 v = s0[i];
 #pragma unroll
                             for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];
-                            store_partial(fl_dst + i, first ? v : v + oldv[u]);
+                            fl_dst[i] = first ? v : v + oldv[u];
                         }
                     }
                     if (last_tile && tid < NT2 * 16) {
@@ -662,7 +639,7 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                             f4 v = s0[i];
 #pragma unroll
                             for (int w = 1; w < WV; ++w) v += s0[w * (SLOT / 4) + i];      // wave order: deterministic
-                            store_partial(fl_dst + i, first ? v : v + oldv[u]);
+                            fl_dst[i] = first ? v : v + oldv[u];
                         }
                     }
                     if (last_tile && net == 1 && tid < NT2 * 16) {
@@ -1042,6 +1019,10 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
 // (8192 rows: 0.300 -> 0.162 ms, 32768 rows: 0.319 -> 0.218 ms, 65536 rows and up: R = RMAX as before).
 // A row's gradient contribution does not depend on R; the summation order over rows does (still
 // deterministic for a given batch size).
+// The ragged last batch of the C2 epoch (16 960 rows) takes R = 2 on 133 workgroups, half the chip; round 6 measured the two ways
+// to give every CU rows with R = 1 (profiles/r06_ragged_wt_ab.txt, rnvp_loss_grad, ms): row-parallel on 265 four-wave workgroups,
+// two per CU, 0.197; net split on 256 workgroups of which nine take a second group 0.239; shipped 0.170 -- 1 060 row tiles over
+// 1 024 SIMDs need either a second round or a wave that runs both nets of its tile alone.
 template <int NF, int CQ> struct TrainRows { static constexpr int value = NF == 2 ? RNVP_TRAIN_R2 : (NF == 4 ? 2 : 1); };
 
 static int pick_rows(int rmax, int64_t n) {
@@ -1169,17 +1150,13 @@ int launch_train_r(hipStream_t st, const KShape &k, const Geo &g, const TrainPla
     // Net split: while there is at most one workgroup per CU (one wave per SIMD), give every row tile to a PAIR of
     // waves, one per net -- two waves per SIMD without loading any weight fragment twice.
     const size_t lds_ns = (2 * kWaves * per_wave_ns + 2 * 2 * kWaves * (size_t)R * NF * 64) * sizeof(float) + kSyncBytes;
-#ifndef RNVP_NS_MAX_GROUPS
-#define RNVP_NS_MAX_GROUPS 256
-#endif
-    if (RNVP_NET_SPLIT && ngroups <= RNVP_NS_MAX_GROUPS && lds_ns <= 160 * 1024) {
-        if (grid > 256) *grid_out = 256;
+    if (RNVP_NET_SPLIT && ngroups <= 256 && lds_ns <= 160 * 1024) {
         lay->w2c = DM::template w2c<1>() ? 1 : 0;
         lay->glayer_floats = 2 * g.HT * DM::template tblk<1>() + DM::NT2 * 16;
         TrainPlan pn = pl;
         pn.glayer_floats = lay->glayer_floats;
         return launch_train_ns<NF, CQ, R, 1>(st, k, g, pn, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch,
-                                             grid > 256 ? 256 : grid, lds_ns, sd);
+                                             grid, lds_ns, sd);
     }
     lay->w2c = DM::template w2c<0>() ? 1 : 0;
     lay->glayer_floats = p0.glayer_floats;
@@ -1237,11 +1214,7 @@ int launch_train(hipStream_t st, const KShape &k, const Geo &g, const TrainPlan 
             return launch_train_ts<NF, CQ, 1>(st, k, g, pl, packed, x, c, row_index, n, inv_B, gpart, losspart, scratch, sd, grid);
         }
     }
-#if defined(RNVP_FORCE_R) && defined(RNVP_FORCE_R_BELOW)      // experiment: row tiles per wave for the batches below a size
-    const int R = n < RNVP_FORCE_R_BELOW ? RNVP_FORCE_R : pick_rows(RMAX, n);
-#else
     const int R = pick_rows(RMAX, n);
-#endif
 #define RNVP_ROWS(r)                                                                                              \
     if constexpr (RMAX >= r) {                                                                                    \
         if (R == r)                                                                                               \
