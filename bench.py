@@ -68,8 +68,8 @@ BATCH = 65_536
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # split-bf16 GEMM1 (precision 'bx3'): six bf16 products per f32 product on the dense bf16 MFMA peak (16x the f32 one)
 BX3_EFFECTIVE_TFLOPS = 16.0 * F32_MFMA_PEAK_TFLOPS / 6.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic_pmc.json")             # the C2 step (this command, default workload)
-TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r05_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic_pmc.json")             # the C2 step (this command, default workload)
+TRAFFIC_FILE_C3C4 = os.path.join(ROOT, "profiles", "r06_traffic_pmc_c3c4.json")   # the C3 / C4 kernels (scripts/bench_kernels.py)
 
 
 def mixed_bound_seconds_per_row(d, c, hidden, L, passes=1):

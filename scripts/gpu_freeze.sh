@@ -3,7 +3,7 @@
 # one-wave split-GEMM1 variant librnvp_hip_bxv.so when it has been built), flow-kernel PMC for C2 / C4, the microbenchmarks, the
 # single-rank data-parallel A/B.  The bench line itself (which reads the traffic file) is a second gpurun call AFTER the results
 # were copied into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /root/repo; mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt; cat gpurun_out/${TAG}_gpu_tests.txt
 bash scripts/gpu_micro.sh $TAG > gpurun_out/${TAG}_micro.log 2>&1 || echo "gpu_micro.sh FAILED (see gpurun_out/${TAG}_micro.log)"; tail -3 gpurun_out/${TAG}_micro_overlap.txt

@@ -5,7 +5,7 @@
 #   2. HBM traffic, --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md "HBM":
 #      FETCH_SIZE x2 on gfx950), for bench.py and for the c3 / c4 kernels
 # The program itself follows `--` (python3 ...): no shell or env hop under the profiler.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /root/repo; mkdir -p gpurun_out; OUT=/root/repo/gpurun_out
 export TMPDIR=/tmp
 cd /tmp

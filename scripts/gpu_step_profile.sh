@@ -1,5 +1,5 @@
 # usage (GPU box): bash scripts/gpu_step_profile.sh <tag> ["CASES"]  -- per-kernel split of the fit-epoch step (rocprofv3 --kernel-trace --stats)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /root/repo; mkdir -p gpurun_out
 [ -n "$2" ] && export CASES="$2"
 python scripts/step_profile.py 2>&1 | tee gpurun_out/${TAG}_steps.txt
