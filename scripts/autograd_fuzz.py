@@ -14,6 +14,10 @@ for it in range(cases):
     L = int(rng.integers(1, 6)); d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 40, 70])); c = int(rng.choice([0, 1, 3, 4, 9, 17]))
     nh = int(rng.integers(1, 4)); hidden = tuple(int(rng.choice([3, 10, 16, 24, 33, 64])) for _ in range(nh))
     act = str(rng.choice(["tanh", "relu"])); n = int(rng.choice([1, 15, 16, 17, 100, 257, 1000]))
+    if os.environ.get("FUZZ_WIDE") == "1":      # round 6: nets whose tile image the any-shape MFMA kernel cannot hold -> the VALU kernel
+        L = int(rng.integers(1, 4)); d = int(rng.choice([2, 5, 16, 17, 40])); c = int(rng.choice([0, 1, 4, 9]))
+        hidden = (int(rng.choice([300, 512, 700])),) if rng.random() < 0.7 else (int(rng.choice([300, 512])), int(rng.choice([16, 64])))
+        n = int(rng.choice([1, 15, 17, 100, 257]))
     if d == 1:
         masks = [torch.tensor([i % 2]) for i in range(L)]
     elif rng.random() < 0.5:
