@@ -192,7 +192,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // ---- the fused step --------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
+// CVAE_TRAIN_WPE: the step kernel's 134 KB of LDS admit ONE workgroup of four waves per CU -- one wave per SIMD whatever the
+// attribute says -- so it is compiled for that: the whole 512-entry register file (no spills; with the translation unit's
+// -amdgpu-mfma-vgpr-form, csrc/Makefile, still VGPR-form MFMAs).  Step 55.5 -> 54.2 us (profiles/r06_sched_strategy_ab.txt, E).
+#ifndef CVAE_TRAIN_WPE
+#define CVAE_TRAIN_WPE 1
+#endif
+__global__ void __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(CVAE_TRAIN_WPE, CVAE_TRAIN_WPE)))
 k_cvae_mfma(CG g, const float *__restrict__ wp, const float *__restrict__ x, const float *__restrict__ c,
             const int64_t *__restrict__ row_index, const float *__restrict__ eps, int64_t n, float inv_B, float klw,
             float *gpart, float *losspart, int do_grad, float *hsave) {
