@@ -13,11 +13,11 @@ ws = torch.empty(_hip.cvae_workspace_bytes(shape, n), dtype=torch.uint8, device=
 grad = torch.empty(P, device="cuda"); loss = torch.empty(1, device="cuda"); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
 def step(i):
     _hip.cvae_train_step(shape, p, X, C, None, eps, n, 1.0 / n, 0.001, grad, loss, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, i + 1, ws)
-for i in range(5): step(i)
+for i in range(200): step(i)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
-for i in range(50): step(i + 5)
+for i in range(200): step(i + 200)
 b.record(); torch.cuda.synchronize()
 _hip.profile_enable(True) if hasattr(_hip, "profile_enable") else None
-print("lib %s: step %.2f us (n=%d) loss %.5f" % (os.path.basename(_hip.LIB_PATH), a.elapsed_time(b) / 50 * 1e3, n, float(loss)))
+print("lib %s: step %.2f us (n=%d) loss %.5f" % (os.path.basename(_hip.LIB_PATH), a.elapsed_time(b) / 200 * 1e3, n, float(loss)))
