@@ -308,7 +308,15 @@ int rnvp_dp_finish_step(void *stream, float *params, const float *grad_loss,
  * rnvp_loss_grad followed by rnvp_adam_step on the same stream (single-GPU training step,
  * realnvp.py:246-254).  loss_out [1] receives the batch loss (the value the reference
  * appends to loss_history).  grad_buf [P] is scratch owned by the caller.
+ *
+ * A failure INSIDE an enqueued training launch cannot come back as a status.  The one such failure the library knows -- a
+ * bounded wait of the register-chained training kernel's barrier-free gradient flush timing out (a protocol error; only the
+ * forced test has ever produced it) -- is reported through the loss: the step applies NO parameter update and no re-pack and
+ * the batch loss (rnvp_train_step, rnvp_fit_epoch*, rnvp_loss_grad) is the quiet NaN with the bit pattern RNVP_PROTOCOL_NAN_BITS;
+ * under data parallelism every rank receives it through the all-reduced loss.  Every later batch of the same call reports it too
+ * (fail-stop until the next call re-packs).  A NaN that training produced by itself carries another payload.
  */
+#define RNVP_PROTOCOL_NAN_BITS 0x7fc0deadu
 int rnvp_train_step(void *stream, const rnvp_shape *shape,
                     float *params, const uint8_t *masks,
                     const float *x, const float *c, const int64_t *row_index,

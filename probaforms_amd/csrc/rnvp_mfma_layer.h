@@ -162,7 +162,7 @@ constexpr int kTS = 20;                  // row stride (floats) of a 16-wide LDS
 // applies NO Adam step and NO re-pack -- the parameters keep their last good values -- and reports the loss kProtocolNaN, a NaN
 // with a payload no arithmetic produces, which RealNVP.fit turns into a RuntimeError (_engine.check_losses).  (`__builtin_trap()` there cost the C2 kernel 2.5 % and
 // the wide C3 kernel 6.5 % of its time through register allocation alone; `s_endpgm` costs nothing: profiles/r05_spin_bound_ab.txt.)
-constexpr unsigned kProtocolNaN = 0x7fc0deadu;
+constexpr unsigned kProtocolNaN = RNVP_PROTOCOL_NAN_BITS;       // include/rnvp_hip.h
 struct Poison { float *loss; int *flag; int *err; };          // this workgroup's loss partials (global), its LDS error flag, the step's error word (global)
 __device__ __forceinline__ void spin_nap(int &spins, const Poison &po) {
     __builtin_amdgcn_s_sleep(1);
