@@ -375,13 +375,12 @@ class NormalizingFlow(nn.Module):
         # SOURCE width is a modest share of the device: a very large draw stays on bounded per-chunk staging)
         one_shot = (rows and Cn is not None and Cn.flags.c_contiguous and Cn.flags.writeable
                     and Cn.dtype in self._UPLOAD_DTYPES and Cn.nbytes <= self.ONE_SHOT_UPLOAD_BYTES)
-        if one_shot:
-            # ONE pageable upload through the runtime's own staging (tens of GB/s on these hosts) and the float32 cast ON THE DEVICE
-            # (the same round-to-nearest as the host cast; what RealNVP.fit does with X and C) instead of a single-threaded numpy
-            # copy / cast into pinned memory per chunk -- that copy, not the GPU, bounded the call (16 MB of float32 conditions:
-            # 1.6 ms of host time against 1.1 ms of kernels for sample(1M) at C2; float64 input twice that)
-            Cd = torch.from_numpy(Cn).to(dev).to(torch.float32)
-            Cn = None
+        # one_shot: ONE pageable upload through the runtime's own staging (tens of GB/s on these hosts) and the float32 cast ON THE DEVICE
+        # (the same round-to-nearest as the host cast; what RealNVP.fit does with X and C) instead of a single-threaded numpy
+        # copy / cast into pinned memory per chunk -- that copy, not the GPU, bounded the call (16 MB of float32 conditions:
+        # 1.6 ms of host time against 1.1 ms of kernels for sample(1M) at C2; float64 input twice that).  The upload blocks the
+        # HOST for about a millisecond, so it is made further down, AFTER the first window of the prior draw has been enqueued:
+        # the draw (0.57 ms of GPU time on its own stream) then runs under it instead of behind it.
         if rows == 0:
             if Cn is not None:
                 Cd = self._on_device(torch.from_numpy(np.ascontiguousarray(Cn)), eng)
@@ -407,7 +406,7 @@ class NormalizingFlow(nn.Module):
             ev_win = [torch.cuda.Event() for _ in zwin]
             ev_used = [None for _ in zwin]                                    # the window buffer's last reader (an inverse kernel)
         zpin = [torch.empty((cap, d), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if (host_rng and hs is None) else None
-        stage_c = cdim > 0 and Cn is not None
+        stage_c = cdim > 0 and Cn is not None and not one_shot
         cdev = [torch.empty((cap, cdim), dtype=torch.float32, device=dev) for _ in range(NB)] if stage_c else None
         cpin = [torch.empty((cap, cdim), dtype=torch.float32, pin_memory=True) for _ in range(NB)] if stage_c else None
         cpin_np = [t.numpy() for t in cpin] if stage_c else None
@@ -435,6 +434,9 @@ class NormalizingFlow(nn.Module):
             if gen is not None:
                 gen.wait_stream(cur)
                 draw_window(0)
+            if one_shot:
+                Cd = torch.from_numpy(Cn).to(dev).to(torch.float32)
+                Cn = None
             for k, (lo, m) in enumerate(chunks):
                 i = k % NB
                 if k >= NB:
