@@ -928,6 +928,10 @@ def main():
                      "frac": fwd_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_launch": fwd_ms / n_fwd, "rows_per_launch": N_ROWS,
                      "launches": n_fwd, "where": "after the timed region"}
         sample_entry["dispatch"], fwd_entry["dispatch"] = disp_inv, disp_fwd
+        if do_sample:       # HBM bytes per launch of the sampling kernel from the committed PMC profile (None when the sources moved)
+            t = pmc_traffic(kernel_prefix(disp_inv, D, CDIM, True), TRAFFIC_FILE if args.workload == "c2" else TRAFFIC_FILE_C3C4)
+            sample_entry["traffic"] = None if t is None else t * N_ROWS / 1048576.0
+            sample_entry["algorithmic_bytes"] = 4 * N_ROWS * (CDIM + D)     # conditions in, samples out: the prior is drawn in the kernel
         if flow_bx3 and do_sample:
             sample_entry["frac_mixed_bound"] = mixed * N_ROWS * timed_steps / (inv_ms * 1e-3)
         if fwd_bx3:

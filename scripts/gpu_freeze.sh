@@ -17,7 +17,7 @@ if [ -f probaforms_amd/csrc/librnvp_hip_bxv.so ]; then
   { echo "whole rnvp_loss_grad call, 65536 rows (scripts/bench_kernels.py), ms; [] = product library, [_bxv] = one-wave split-GEMM1 variant"; OPS=train bash scripts/gpu_ab.sh "" _bxv; } > gpurun_out/${TAG}_train_bx_ab.txt 2>&1
 fi
 N=1048576 bash scripts/gpu_pmc.sh ${TAG}flowc2 c2 fwd,inv > gpurun_out/${TAG}_flow_pmc_c2.log 2>&1
-python scripts/make_train_pmc.py $TAG ${TAG}flowc2 "k_mfma_flow<2, 1, 4" ${TAG}_flow_pmc_c2.json "C2 forward / inverse, 1M rows, f32 kernels (what precision auto runs for d <= 16 since round 4)"
+python scripts/make_train_pmc.py $TAG ${TAG}flowc2 "k_flow_bx3<2, 1" ${TAG}_flow_pmc_c2.json "C2 forward / inverse, 1M rows, barrier-free split-bf16 kernels (what precision auto runs for d <= 16 with hidden > 96 since round 6)"
 N=1048576 bash scripts/gpu_pmc.sh ${TAG}flowc4 c4 fwd,inv > gpurun_out/${TAG}_flow_pmc_c4.log 2>&1
 python scripts/make_train_pmc.py $TAG ${TAG}flowc4 "k_flow_bx3<8, 4" ${TAG}_flow_pmc_c4.json "C4 forward / inverse, 1M rows, bx3 kernels (LDS-staged weights)"
 # single-rank data-parallel A/B: the same bench step through rnvp_fit_epoch (fused) and through rnvp_fit_epoch_dp on a one-rank RCCL communicator
