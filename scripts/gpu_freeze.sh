@@ -5,7 +5,7 @@
 # were copied into profiles/.
 TAG=${1:-r06}
 cd /root/repo; mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt; cat gpurun_out/${TAG}_gpu_tests.txt
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5 > gpurun_out/${TAG}_gpu_tests.txt; cat gpurun_out/${TAG}_gpu_tests.txt
 bash scripts/gpu_micro.sh $TAG > gpurun_out/${TAG}_micro.log 2>&1 || echo "gpu_micro.sh FAILED (see gpurun_out/${TAG}_micro.log)"; tail -3 gpurun_out/${TAG}_micro_overlap.txt
 python bench.py --no-cpu-baseline --no-api-level > gpurun_out/${TAG}_bench_plain.json 2> gpurun_out/${TAG}_bench_plain.err
 bash scripts/gpu_profiles.sh $TAG > gpurun_out/${TAG}_profiles.log 2>&1; tail -25 gpurun_out/${TAG}_profiles.log
