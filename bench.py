@@ -517,10 +517,10 @@ def precision_ab(Xh, Ch, dev):
         xs = torch.empty(N_ROWS, D, device=dev)
         res = {}
         _hip.profile_enable(64)
-        for name, kind, fn, reps in (("train_step_65536_rows", _hip.PROFILE_TRAIN, lambda: eng.train_step(opt, X, C, idx, BATCH, 1.0 / BATCH, loss), 20),
-                                     ("log_prob_1M_rows", _hip.PROFILE_FORWARD, lambda: eng.forward(X, C, want_z=False, want_logp=True), 5),
-                                     ("sample_1M_rows", _hip.PROFILE_INVERSE, lambda: eng.sample(N_ROWS, C, 5, row_offset=0, out=xs), 5)):
-            for _ in range(max(2, reps)):          # (warm-up as long as the timed loop: no clock ramp inside it)
+        for name, kind, fn, reps, warm in (("train_step_65536_rows", _hip.PROFILE_TRAIN, lambda: eng.train_step(opt, X, C, idx, BATCH, 1.0 / BATCH, loss), 40, 200),
+                                           ("log_prob_1M_rows", _hip.PROFILE_FORWARD, lambda: eng.forward(X, C, want_z=False, want_logp=True), 10, 50),
+                                           ("sample_1M_rows", _hip.PROFILE_INVERSE, lambda: eng.sample(N_ROWS, C, 5, row_offset=0, out=xs), 10, 50)):
+            for _ in range(warm):                  # ~50 ms of the same launches first: the chip's clock ramp ends before the timed loop (launches past the 64 event slots go unrecorded)
                 fn()
             torch.cuda.synchronize(dev); _hip.profile_read(kind)
             for _ in range(reps):
