@@ -93,8 +93,8 @@ typedef struct rnvp_shape {
                                     another order, so results differ from larger calls in the last bits              */
 
 #define RNVP_PREC_AUTO 0         /* the faster of the two for the shape: BX3 for d > 16 or cdim > 4 (measured 1.3-1.4x on every
-                                    operation); for d <= 16 with one hidden layer of more than 96 units BX3 too (training kernel's
-                                    forward phase 2-5 %, flow kernels 8 % with warm clocks: barrier-free form); F32 else */
+                                    operation); for d <= 16 with one hidden layer of more than 64 units BX3 too (training kernel's
+                                    forward phase 3-5 %, flow kernels 5-9 % with warm clocks: barrier-free form); F32 else */
 #define RNVP_PREC_F32  1         /* f32-input MFMA (v_mfma_f32_16x16x4_f32): bitwise an fmaf chain          */
 #define RNVP_PREC_BX3  2         /* operands split into three bf16 terms, six bf16 MFMA products per pair:
                                     float32-level accuracy (every dropped product < 2^-24), weights staged in LDS */

@@ -18,7 +18,7 @@ PROFILE_TRAIN, PROFILE_FORWARD, PROFILE_INVERSE = 0, 1, 2
 PATH_GENERIC, PATH_MFMA, PATH_LMM = 0, 1, 2
 # arithmetic of the first Linear of the s/t nets in the forward / inverse / sampling kernels (rnvp_shape.precision):
 # 'f32' = f32-input MFMA; 'bx3' = three-term bf16 split, six products (float32-level accuracy, see rnvp_bx3.h)
-# 'auto' lets the library take the faster one for the shape (bx3 for d > 16, cdim > 4 or one hidden layer of more than 96 units)
+# 'auto' lets the library take the faster one for the shape (bx3 for d > 16, cdim > 4 or one hidden layer of more than 64 units)
 PRECISIONS = {"auto": 0, "f32": 1, "bx3": 2}
 DEFAULT_PRECISION = os.environ.get("RNVP_PRECISION", "auto")
 

@@ -51,17 +51,21 @@ inline int make_kshape(const rnvp_shape *s, KShape *k) {
     k->prec_auto = s->precision == RNVP_PREC_AUTO;
     // auto: bx3 where the tile geometry has 4+ feature slots per lane (d > 16 or cdim > 4: rnvp_mfma.h pick_tiles) -- measured
     // 1.3-1.4x on every operation there.  In the d <= 16 geometry the split inputs cost 36 registers the f32 form does not need:
-    //   * the training kernel's forward phase takes them from seven hidden tiles on (hidden > 96: C2 step -1.5 .. -4.8 %,
-    //     profiles/r03_precision_auto.txt) -- its spills are cold (none inside a tile loop: profiles/r04_scratch_isa.txt);
+    //   * the training kernel's forward phase takes them from five hidden tiles on (hidden > 64) -- its spills are cold (none inside
+    //     a tile loop: profiles/r04_scratch_isa.txt);
     //   * the flow kernels take them from the same width on SINCE ROUND 6.  Rounds 3-5 measured the barrier-free split-bf16 form
-    //     (three row tiles per wave, 42-57 spilled registers: 295 vs 88 MB of HBM traffic per 1M rows) at 1-3 % ahead of the f32
+    //     (three row tiles per wave, 42-57 spilled registers: 281-295 vs 88 MB of HBM traffic per 1M rows) at 1-3 % ahead of the f32
     //     kernels and kept f32 -- with a dozen launches from an idle chip, i.e. under its clock ramp.  With warm clocks (>= 50 ms of
-    //     warm-up, 30 launches, three repetitions: profiles/r06_c2_flow_bx3_warm.txt) the f32 kernels hold a lower clock under
-    //     sustained load and the split form is 8.8 % (forward) / 8.1 % (inverse, sampling) faster: 0.968 / 0.960 against 1.061 /
-    //     1.045 ms per 1M rows; two row tiles (no spill) -3.7 / -2.6 %, four +20 %.  The spill traffic is 0.2 GB per millisecond of
-    //     an 8 TB/s part.  Log-prob MAE against float64: 2.7e-6 (f32 kernels 2.1e-6, the float32 oracle itself 2.5e-6).
+    //     warm-up, 30 launches, three repetitions: profiles/r06_c2_flow_bx3_warm.txt) the split form is 8.8 % (forward) / 8.1 %
+    //     (inverse, sampling) faster: 0.968 / 0.960 against 1.061 / 1.045 ms per 1M rows; two row tiles (no spill) -3.7 / -2.6 %,
+    //     four +20 %.  The counters agree (profiles/r06_flow_pmc_c2.json / _c2_f32.json, both warm): 2.27 against 2.50 M cycles per
+    //     launch at 2.32 against 2.37 GHz -- fewer cycles, not a higher clock.  The spill traffic is 0.2 GB per millisecond of an
+    //     8 TB/s part.  Log-prob MAE against float64: 2.7e-6 (f32 kernels 2.1e-6, the float32 oracle itself 2.5e-6).
+    //   Width sweep at d = 16, c = 4, warm clocks (profiles/r06_d16_width_prec_sweep.txt), bx3 against f32, forward / inverse / loss+grad
+    //   call: hidden 16 +33 / +35 / +5 %, 32 +14 / +14 / +1 %, 64 0 / 0 / -1.8 %, 96 -5.2 / -4.8 / -2.8 %, 128 -7.1 / -6.8 / -3.8 %,
+    //   256 -7.7 / -7.3 / -5.0 %: the switch sits above 64 units (rounds 3-5: above 96, from cold timings).
     const bool wide = s->d > 16 || s->c > 4;
-    k->prec = s->precision == RNVP_PREC_AUTO ? ((wide || (s->n_hidden == 1 && s->hidden[0] > 96)) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
+    k->prec = s->precision == RNVP_PREC_AUTO ? ((wide || (s->n_hidden == 1 && s->hidden[0] > 64)) ? RNVP_PREC_BX3 : RNVP_PREC_F32) : s->precision;
     k->prec_flow = k->prec;
     int in = s->d + s->c, off = 0;
     k->hs = 0; k->hmax = 0; k->wmax = in > s->d ? in : s->d;
