@@ -76,6 +76,10 @@ TRAIN_CASES = [
     ("c2-70000-auto", C2, 70000, "auto", "k_mfma_train", "rowpar", "bx3"),
     ("c2-65536-f32", C2, 65536, "f32", "k_mfma_train", "netsplit", "f32"),
     ("c2-8192-auto", C2, 8192, "auto", "k_mfma_train_ts", "tilesplit", "f32"),
+    # where `auto` switches for d <= 16 (round 6: above 64 hidden units -- five hidden tiles on)
+    ("c2h64-65536-auto", (8, 16, 4, 64), 65536, "auto", "k_mfma_train", "netsplit", "f32"),
+    ("c2h80-65536-auto", (8, 16, 4, 80), 65536, "auto", "k_mfma_train", "netsplit", "bx3"),
+    ("c2h96-65536-auto", (8, 16, 4, 96), 65536, "auto", "k_mfma_train", "netsplit", "bx3"),
     # C3 (configs[2]): 65 536 rows per rank and the ragged tail of a 1M-row epoch take the wide kernel; 30 000 rows the net-split one
     ("c3-65536-auto", C3, 65536, "auto", "k_mfma_train_wide", "wide", "bx3"),
     ("c3-40000-auto", C3, 40000, "auto", "k_mfma_train_wide", "wide", "bx3"),
@@ -144,6 +148,7 @@ FLOW_CASES = [
     ("c2-1M-f32", C2, 1_000_000, "f32"),            # the f32 register-chained kernels stay available on request (and serve hidden <= 64)
     ("c2h64-1M-auto", (8, 16, 4, 64), 1_000_000, "auto"),
     ("c2h96-1M-auto", (8, 16, 4, 96), 1_000_000, "auto"),
+    ("c2h80-300k-auto", (8, 16, 4, 80), 300_000, "auto"),
     ("c3-200k-auto", C3, 200_003, "auto"),
     ("c4-200k-auto", C4, 200_003, "auto"),
 ]
