@@ -317,6 +317,14 @@ __device__ __forceinline__ void issue_stage(const uint32_t *gsrc, uint32_t *ldst
 // STAGED: the workgroup's WAVES waves share each stage through LDS (above).  !STAGED (d <= 16, where a stage is small and
 // the barrier-paced schedule loses more than the shared copy saves): every wave reads the same stage images straight from
 // global memory, one hidden tile ahead, like the f32 kernels of rnvp_mfma_layer.h -- no LDS, no barriers.
+// the prior draw of a fused sampling call, out of line: its constants and Philox state stay out of the flow kernel's register
+// allocation (inlined, the compiler hoists them across the stage loop and spills them)
+__device__ __attribute__((noinline)) f4 prior_normal4_cold(uint64_t seed, int64_t row, int blk) {
+    float z[4];
+    prior_normal4(seed, row, blk, z);
+    return f4{z[0], z[1], z[2], z[3]};
+}
+
 template <int NF, int CQ, int R, bool INVERSE, int ACT, int WAVES, bool STAGED>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float *x, const float *__restrict__ c,
@@ -327,7 +335,7 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
     constexpr bool X4 = NF == 2;
     constexpr int NOUT = X4 ? 4 : NT2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];       // two stage buffers of g.SD dwords
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // known uniform: row bases in SGPRs
     const int q = lane >> 4, r = lane & 15;
     const int64_t rows_per_wg = (int64_t)WAVES * R * 16;
     const int64_t ngroups = (n + rows_per_wg - 1) / rows_per_wg;
@@ -358,8 +366,7 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
                 mfma::load_row<NF, CQ, false>(x, c, src, g.d, g.c, full, q, xr[rt], cr[rt]);
 #pragma unroll
                 for (int b = 0; b < 2 * NF / 4; ++b) {
-                    float z4[4];
-                    prior_normal4(seed, row0 + row, (q * 2 * NF) / 4 + b, z4);
+                    const f4 z4 = prior_normal4_cold(seed, row0 + row, (q * 2 * NF) / 4 + b);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xr[rt][4 * b + e] = (q * 2 * NF + 4 * b + e < g.d) ? z4[e] : 0.f;
                 }
@@ -433,11 +440,15 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
                 }
             }
         }
+        // (the epilogue derives its rows from an opaque copy of the lane's row number: nothing row-related stays live -- or gets
+        // spilled -- across the stage loop)
+        int r_out = r, q_out = q;
+        asm volatile("" : "+v"(r_out), "+v"(q_out));
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
-            const int64_t row = base + rt * 16 + r;
+            const int64_t row = base + rt * 16 + r_out;
             const bool valid = row < n;
-            if (out_x && valid) mfma::store_row<NF>(out_x, row, g.d, full, q, xr[rt]);
+            if (out_x && valid) mfma::store_row<NF>(out_x, row, g.d, full, q_out, xr[rt]);
             if (!INVERSE) {
                 float ss = 0.f;
 #pragma unroll
@@ -446,12 +457,12 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
                 l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
                 ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
                 const float lpv = l1 + (-0.5f * ss - prior_c);          // nflow.py:115
-                if (valid && q == 0) {
+                if (valid && q_out == 0) {
                     if (logdet_out) logdet_out[row] = l1;
                     if (logp_out) logp_out[row] = lpv;
                 }
                 if (part) {
-                    float v = (valid && q == 0) ? lpv : 0.f;
+                    float v = (valid && q_out == 0) ? lpv : 0.f;
                     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
                     wave_sum += v;
                 }
