@@ -393,6 +393,15 @@ k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float 
             const int pc = (l + alt) & 1;
             const int nt = (g.HT - ch * g.TC) < g.TC ? (g.HT - ch * g.TC) : g.TC;
             if (rem == 0) {                                  // layer start: GEMM1's B operand, accumulators
+                if constexpr (!STAGED && CQ > 0) {
+                    // the conditions' bf16 terms are the same in every layer: left alone, the compiler computes them once per row
+                    // group, finds no register for them and parks them in scratch (written through to HBM, re-read per layer);
+                    // 7 VALU operations per value and layer instead
+#pragma unroll
+                    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+                        for (int u = 0; u < CQ; ++u) asm volatile("" : "+v"(cr[rt][u]));
+                }
                 if (pc) build_bin<NF, CQ, 1, R>(xr, cr, bin); else build_bin<NF, CQ, 0, R>(xr, cr, bin);
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt)
