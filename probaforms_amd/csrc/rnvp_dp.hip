@@ -104,11 +104,20 @@ int rnvp_dp_set_chunks(void *comm, int chunks) {
     if (!comm || chunks < 1 || chunks > kMaxChunks) return RNVP_EINVAL;
     DpComm *c = static_cast<DpComm *>(comm);
     if (chunks > 1 && !c->side) {
-        RNVP_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        for (int j = 0; j < kMaxChunks; ++j) {
-            RNVP_HIP_TRY(hipEventCreateWithFlags(&c->ev_sum[j], hipEventDisableTiming));
-            RNVP_HIP_TRY(hipEventCreateWithFlags(&c->ev_red[j], hipEventDisableTiming));
+        // all or nothing: a communicator never keeps a side stream without its events (rnvp_dp_destroy would destroy handles that
+        // were never created)
+        hipStream_t side = nullptr;
+        hipEvent_t ev[2 * kMaxChunks] = {};
+        hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        int made = 0;
+        for (; e == hipSuccess && made < 2 * kMaxChunks; ++made) e = hipEventCreateWithFlags(&ev[made], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int j = 0; j < made - 1; ++j) (void)hipEventDestroy(ev[j]);
+            if (side) (void)hipStreamDestroy(side);
+            return (int)e;
         }
+        for (int j = 0; j < kMaxChunks; ++j) { c->ev_sum[j] = ev[2 * j]; c->ev_red[j] = ev[2 * j + 1]; }
+        c->side = side;
     }
     c->chunks = chunks;
     return RNVP_OK;

@@ -345,14 +345,23 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
         }
         for (int ht = ht_lo; ht < ht_hi; ++ht) {
             const int nx = (kAblate & 64) ? 0 : ((ht + 1 < ht_hi) ? ht + 1 : ht);
+            // The next tile's weight fragments.  d <= 16: a second register set, requested here, a whole iteration ahead, and
+            // copied over at the loop's end.  Wider rows (INPL): loaded IN PLACE right after their last use in this tile (a1 / b1 /
+            // a2t after phase 1 of the last row-tile half, a1t after its phase 3) -- half an iteration of cover is enough for the
+            // L2-resident fragments, and the 20-36 registers and 10-18 copies per tile buy more than the distance: round 6, same
+            // box, 65 536 rows: C3 1.188 -> 1.170 ms, C4 1.067 -> 1.032; C2 0.2674 -> 0.2681 (hence not there)
+            // (profiles/r06_bwd_inplace_ab.txt)
+            constexpr bool INPL = NF >= 4;
             f4 na1[K4], na2t[OTL], na1t[NGI], nb1;
+            if constexpr (!INPL) {
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
-            nb1 = *opaque(pB1 + nx * 16);
+                for (int k4 = 0; k4 < K4; ++k4) na1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
+                nb1 = *opaque(pB1 + nx * 16);
 #pragma unroll
-            for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
+                for (int o = 0; o < OTL; ++o) na2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
 #pragma unroll
-            for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
+                for (int m = 0; m < NGI; ++m) na1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
+            }
             BWD_SCHED_BARRIER();
 
             f4 gW2[W2C ? 2 : OTL], gW1[NTI];           // W2C: one accumulator per column block cb
@@ -388,6 +397,15 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                         for (int u = 0; u < RH; ++u)
                             gh[u] = mfma16(a2t[0][2 * net + v], go[r0 + u][0][2 * net + v], gh[u]);
+                }
+                if constexpr (INPL) {
+                    if (r0 + RH >= R) {
+#pragma unroll
+                        for (int k4 = 0; k4 < K4; ++k4) a1[k4] = *opaque(pA1 + ((size_t)nx * K4 + k4) * 256);
+                        b1 = *opaque(pB1 + nx * 16);
+#pragma unroll
+                        for (int o = 0; o < OTL; ++o) a2t[o] = *opaque(pA2T + ((size_t)nx * OTL + o) * 256);
+                    }
                 }
                 BWD_SCHED_BARRIER();
                 STAMP_ADD(stp.p1, t0);
@@ -446,6 +464,12 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
 #pragma unroll
                             for (int u = 0; u < RH; ++u)
                                 gin[r0 + u][m] = mfma16(a1t[m][rho], gpv[u][rho], gin[r0 + u][m]);
+                }
+                if constexpr (INPL) {
+                    if (r0 + RH >= R) {
+#pragma unroll
+                        for (int m = 0; m < NGI; ++m) a1t[m] = *opaque(pA1T + ((size_t)nx * NGI + m) * 256);
+                    }
                 }
                 read_transposed();
                 BWD_SCHED_BARRIER();
@@ -656,13 +680,15 @@ __device__ __forceinline__ void layer_bwd(const float *__restrict__ W, const Geo
                 STAMP_ADD(stp.bflush, t0);
                 }
             }
+            if constexpr (!INPL) {
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
-            b1 = nb1;
+                for (int k4 = 0; k4 < K4; ++k4) a1[k4] = na1[k4];
+                b1 = nb1;
 #pragma unroll
-            for (int o = 0; o < OTL; ++o) a2t[o] = na2t[o];
+                for (int o = 0; o < OTL; ++o) a2t[o] = na2t[o];
 #pragma unroll
-            for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
+                for (int m = 0; m < NGI; ++m) a1t[m] = na1t[m];
+            }
         }
     };
     if constexpr (TS) {

@@ -1,0 +1,8 @@
+# round 6: backward tile loop with the next tile's weight fragments loaded IN PLACE after their last use (no second register set, no rotation copies)
+cd /root/repo
+RNVP_HIP_LIB=/root/repo/probaforms_amd/csrc/librnvp_hip_inpl.so python -m pytest tests/test_bench_sizes_gpu.py tests/test_hip_kernels.py -x -q 2>&1 | grep -E "passed|failed|rror|ERROR" | tail -3
+OPS=train ITERS=200 WARM_S=0.2 NT=65536 CFGS="c2 c3 c4" bash scripts/gpu_ab.sh "" _inpl
+for rep in 1 2; do for v in "" _inpl; do echo -n "bench20 [$v] "; RNVP_HIP_LIB=/root/repo/probaforms_amd/csrc/librnvp_hip$v.so python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-level 2>/dev/null | python3 -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f M rows/s  %.3f ms/step  frac %.4f' % (j['value'] / 1e6, j['ms_per_step'], j['roofline']['frac']))"
+done; done
