@@ -237,7 +237,9 @@ k_lmm_flow(KShape s, LGeo g, const float *__restrict__ packed, const float *__re
            const uint8_t *__restrict__ masks, const float *x, const float *__restrict__ c,
            const int64_t *__restrict__ row_index, int64_t n, float *out_x, float *logdet_out, float *logp_out, float *part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
+    // (the wave number through readfirstlane: known uniform, so the per-wave row bases and LDS offsets are scalar arithmetic --
+    // round 6, same box: loss + gradient call of hidden=(128,128) 4.42 -> 4.37 ms, (10,20,15) 1.607 -> 1.589: profiles/r06_wave_sgpr_sweep.txt)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
     float *XC = lds, *H0 = XC + (d + cd) * RS, *H1 = H0 + g.hmax * RS, *T = H1 + g.hmax * RS, *S = T + d * RS;
     float *RED = lds + g.lds_flow / sizeof(float) - 2 * kW * 16;
     for (int e = tid; e < (int)(g.lds_flow / sizeof(float)); e += 64 * kW) lds[e] = 0.f;      // see linear_mb: stale rows must be finite
@@ -362,7 +364,7 @@ k_lmm_train(KShape s, LGeo g, const float *__restrict__ packed, const float *__r
             const int64_t *__restrict__ row_index, int64_t n, float inv_B, Seeds sd,
             float *__restrict__ dump, float *__restrict__ xsave, float *losspart, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, r = lane & 15, d = s.d, cd = s.c;
     const int jq = q + 4 * wave, jstep = 4 * kW;           // this lane's features in the elementwise passes
     const float *__restrict__ gz = sd.gz;
     float *XC = lds, *ACT = XC + (d + cd) * RS, *T = ACT + g.hs * RS, *S = T + d * RS, *GY = S + d * RS, *GIN = GY + d * RS;
@@ -480,7 +482,7 @@ k_lmm_cvae_train(CvaeL s, const float *__restrict__ packed_e, const float *__res
                  const float *__restrict__ eps, int64_t n, float inv_B, float klw, float *__restrict__ dump_e,
                  float *__restrict__ dump_d, float *losspart, int first_chunk, int do_grad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, r = lane & 15;
     const int d = s.d, cd = s.c, lat = s.lat;
     const int jq = q + 4 * wave, jstep = 4 * kW;
     float *EIN = lds, *EACT = EIN + (d + cd) * RS, *EO = EACT + s.enc.hs * RS, *DIN = EO + 2 * lat * RS;
@@ -549,7 +551,7 @@ k_lmm_cvae_mlp(CvaeL s, const float *__restrict__ packed, const float *__restric
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const KShape &m = ENCODE ? s.enc : s.dec;
     const LGeo &g = ENCODE ? s.ge : s.gd;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int na = ENCODE ? s.d : s.lat, cd = s.c, no = ENCODE ? 2 * s.lat : s.d;
     const size_t bytes = ENCODE ? s.lds_enc : s.lds_dec;
     float *IN = lds, *H0 = IN + (na + cd) * RS, *H1 = H0 + m.hmax * RS, *O = H1 + m.hmax * RS;

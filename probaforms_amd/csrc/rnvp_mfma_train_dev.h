@@ -947,7 +947,11 @@ k_mfma_train_ts(const float *__restrict__ wp, Geo g, int L, int alt, const float
     constexpr int D = 8 * NF, CD = 4 * CQ;
     constexpr int XW = R * NF * 64, TBN = DM::template tbn<R, 0>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave number as an SGPR where that pays (scalar address arithmetic instead of per-lane: the C2 kernel's static VALU count
+    // 1 689 -> 1 506): round 6, same box, per call: C3 at 32 / 1 024 / 8 192 rows -2.3 / -2.0 / -3.0 %, C2 at 8 192 rows -2.0 %, at
+    // 1 024 0, at 32 rows +1.0 % -- hence not for d <= 16 with one row tile (profiles/r06_ts_wave_sgpr_ab.txt)
+    const int lane = threadIdx.x & 63;
+    const int wave = (NF >= 4 || R >= 2) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     const int q = lane >> 4, r = lane & 15;
     float *tb = lds + wave * TBN;
     float *red = lds + kTsWaves * TBN;                    // 2 x kTsWaves x XW, double buffered by layer parity
