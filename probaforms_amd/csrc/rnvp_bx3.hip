@@ -314,9 +314,6 @@ __device__ __forceinline__ void issue_stage(const uint32_t *gsrc, uint32_t *ldst
     }
 }
 
-// STAGED: the workgroup's WAVES waves share each stage through LDS (above).  !STAGED (d <= 16, where a stage is small and
-// the barrier-paced schedule loses more than the shared copy saves): every wave reads the same stage images straight from
-// global memory, one hidden tile ahead, like the f32 kernels of rnvp_mfma_layer.h -- no LDS, no barriers.
 // the prior draw of a fused sampling call, out of line: its constants and Philox state stay out of the flow kernel's register
 // allocation (inlined, the compiler hoists them across the stage loop and spills them)
 __device__ __attribute__((noinline)) f4 prior_normal4_cold(uint64_t seed, int64_t row, int blk) {
@@ -325,6 +322,9 @@ __device__ __attribute__((noinline)) f4 prior_normal4_cold(uint64_t seed, int64_
     return f4{z[0], z[1], z[2], z[3]};
 }
 
+// STAGED: the workgroup's WAVES waves share each stage through LDS (above).  !STAGED (d <= 16, where a stage is small and
+// the barrier-paced schedule loses more than the shared copy saves): every wave reads the same stage images straight from
+// global memory, one hidden tile ahead, like the f32 kernels of rnvp_mfma_layer.h -- no LDS, no barriers.
 template <int NF, int CQ, int R, bool INVERSE, int ACT, int WAVES, bool STAGED>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNVP_WPE, RNVP_WPE)))
 k_flow_bx3(const uint32_t *__restrict__ wp, Geo3 g, int L, int alt, const float *x, const float *__restrict__ c,
